@@ -1,0 +1,79 @@
+"""The oracle restatement vs the golden vectors the UNMODIFIED reference produced
+(oracle/make_golden.py), and - where /root/reference exists - vs the live reference."""
+import os
+
+import pytest
+import torch
+
+from oracle.cases import CASES, build_case, default_shapes, input_checksum, with_grad
+from oracle.transfusion_oracle import forward_train, naive_mask
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+FAST = ['tiny1', 'small2', 'mid2']
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, f'{name}.pt'), weights_only=False)
+
+
+@pytest.mark.parametrize('name', FAST + ['canon512'])
+def test_oracle_matches_reference_golden(name):
+    g = load_golden(name)
+    cfg, sd, batch, times, noise = build_case(name)
+    assert abs(input_checksum(sd, batch, times, noise) - g['input_checksum']) <= 1e-6 * abs(g['input_checksum']), \
+        'deterministic input factory drifted from the one that made the golden vectors'
+    sdg = with_grad(sd)
+    out = forward_train(sdg, cfg, batch, times, noise, return_all=True)
+    # fp32 CPU vs fp32 CPU, different op order only: tight tolerances
+    assert abs(float(out['loss']) - float(g['loss'])) < 2e-5
+    assert abs(float(out['text_loss']) - float(g['text_loss'])) < 2e-5
+    for a, b in zip(out['flow_losses'], g['flow_losses']):
+        assert abs(float(a) - float(b)) < 2e-5
+    rs = g['row_step']
+    assert (out['logits'][:, ::rs] - g['logits']).abs().max() < 2e-4
+    assert (out['embed'][:, ::rs] - g['embed']).abs().max() < 2e-4
+    out['loss'].backward()
+    for k, gn in g['grad_norms'].items():
+        go = sdg[k].grad
+        assert go is not None, k
+        assert abs(float(go.double().norm()) - gn) <= 1e-4 * gn + 1e-9, k
+        head = g['grad_head'][k]
+        assert (go.reshape(-1)[:head.numel()] - head).abs().max() <= 1e-4 * head.abs().max() + 1e-8, k
+    if 'grads' in g:
+        for k, gr in g['grads'].items():
+            assert (sdg[k].grad - gr).norm() <= 1e-5 * gr.norm() + 1e-9, k
+    # the prefix-extension mask equals the reference's naive mask (T:452-470)
+    P = out['packed']
+    b, n = out['kv_end'].shape
+    assert torch.equal(naive_mask(P.positions, b, n), torch.arange(n)[None, None, :] < out['kv_end'][:, :, None])
+
+
+def test_packed_layout_known_answers():
+    """canonical sample packs to 1025 tokens, first instance at offset 28, stride 32."""
+    cfg, sd, batch, times, noise = build_case('canon512')
+    from oracle.transfusion_oracle import pack_batch
+    P = pack_batch(cfg, batch)
+    assert P.text.shape == (2, 1025)
+    assert P.positions[0][:3] == [(0, 28, 4), (0, 60, 4), (0, 92, 4)]
+    assert P.total_tokens == 2 * 1025
+    cfg, sd, batch, times, noise = build_case('mid2')
+    P = pack_batch(cfg, batch)
+    assert P.text.shape == (2, 1025)
+    assert P.positions[0][:3] == [(0, 29, 4), (1, 62, 2), (0, 93, 4)]
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize('name', ['tiny1'])
+def test_oracle_matches_live_reference(name):
+    from oracle import ref_runner
+    if not ref_runner.reference_available():
+        pytest.skip('/root/reference not present (GPU box)')
+    cfg, sd, batch, times, noise = build_case(name)
+    ref, _ = ref_runner.reference_forward_backward(cfg, sd, batch, times, noise, modality_default_shape=default_shapes(cfg))
+    sdg = with_grad(sd)
+    out = forward_train(sdg, cfg, batch, times, noise, return_all=True)
+    out['loss'].backward()
+    assert abs(float(out['loss']) - float(ref['loss'])) < 1e-5
+    assert (out['logits'] - ref['logits']).abs().max() < 1e-4
+    for k, gr in ref['grads'].items():
+        assert (sdg[k].grad - gr).norm() <= 1e-5 * gr.norm() + 1e-9, k
