@@ -1,0 +1,242 @@
+/* tfx.h — C ABI of libtfx_hip.so: the MI355X (gfx950) Transfusion hot path.
+ *
+ * Plain C: raw device pointers, sizes, a hipStream_t passed as void*.  No torch types.
+ * Every entry point enqueues work on `stream` and returns immediately (no host sync);
+ * return value 0 = ok, non-zero = argument / launch error (hipError_t or negative code).
+ * bf16 tensors are `uint16_t*` storage here (`__bf16` on the device).
+ *
+ * Reference interfaces replaced (file:line relative to /root/reference/transfusion_pytorch;
+ * T = transfusion.py, MP = modality_processing.py):
+ *
+ *   tfx_gemm_nt / tfx_gemm_tn    every nn.Linear on the path and its backward: to_qk/to_v/to_gates/to_out
+ *                                T:877-916, FeedForward T:845-853 (GEGLU epilogue T:831-834), skip_proj
+ *                                T:1083,1214-1219, to_time_cond T:1068-1072, to_film/to_ada_ln_zero T:664-665,
+ *                                latent_to_model / model_to_latent T:1478-1479, to_text_logits T:1507
+ *   tfx_attn_fwd/_bwd_*          Attention.forward score pipeline T:998-1027 (softclamp T:280-281, mask
+ *                                naive_attn_mask T:452-470 in prefix-extension form, sigmoid value gate T:1027)
+ *   tfx_qk_norm_rope_*           q_norm/k_norm RMSNorm T:950-952,779-786 + apply_rotary_emb T:965 + q*scale T:998
+ *   tfx_adaln_pre_* / _post_*    AdaptiveWrapper.forward T:721-775
+ *   tfx_attnres_*                AttentionResidual.forward T:807-829
+ *   tfx_rmsnorm_*                RMSNorm T:779-786 (final norm T:1250)
+ *   tfx_embed_*                  text_embed gather + einx.where select T:3173-3184
+ *   tfx_noise_mix                process_type_flat noising MP:654-656
+ *   tfx_fourier                  RandomFourierEmbed T:617-635
+ *   tfx_ce_* / tfx_mse_*         loss block T:3320-3376
+ *   tfx_adam_*                   train_toy.py:55-57 (clip_grad_norm_ + Adam)
+ */
+#ifndef TFX_H
+#define TFX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef TFX_BF16_DEFINED
+typedef uint16_t tfx_bf16;
+#endif
+
+/* ---- GEMM ------------------------------------------------------------------------------------ */
+enum { TFX_EPI_BF16 = 0, TFX_EPI_F32 = 1, TFX_EPI_SILU = 2, TFX_EPI_RESID = 3, TFX_EPI_GEGLU = 4, TFX_EPI_GEGLU_BWD = 5 };
+
+/* C[M,N] = A[M,K] . B[N,K]^T (+ epilogue).  K % 64 == 0; lda/ldb % 8 == 0; all bases 16-byte aligned.
+ * Optional second A source A2 for k >= K1 (skip-proj concat without the cat copy, T:1214-1219).
+ * a_rowmap: gather A rows (row index = a_rowmap[m]); rowmap: scatter output rows (negative = drop).
+ * GEGLU layout: physical column c of the 2*dip-wide [value|gate] buffer: block j = c/64, c%64 < 32 is
+ * value feature j*32 + c%32, else gate feature j*32 + c%64-32 (weights/bias shadows use the same order). */
+typedef struct {
+  const tfx_bf16* A; int32_t lda;
+  const tfx_bf16* A2; int32_t lda2; int32_t K1;
+  const tfx_bf16* B; int32_t ldb;
+  int32_t M, N, K;
+  int32_t epi;
+  void* C; int32_t ldc;
+  void* C2; int32_t ldc2;
+  const float* bias;
+  const tfx_bf16* R; int32_t ldr; int32_t resid_mapped;   /* residual row = scattered row if set */
+  const int32_t* rowmap;
+  const int32_t* a_rowmap;
+  const tfx_bf16* aux; int32_t ldaux;
+} tfx_gemm_nt_args;
+int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
+
+/* C[rowmap[n]][k] (+)= alpha * sum_m A[m][n] * B[m][k]   (fp32 C; split-M with fp32 atomics).
+ * a_cols/b_cols: number of readable columns of A/B (multiples of 8); k_valid: columns of C written. */
+typedef struct {
+  const tfx_bf16* A; int32_t lda; int32_t a_cols;
+  const tfx_bf16* B; int32_t ldb; int32_t b_cols;
+  int32_t M, N, K;
+  float* C; int32_t ldc;
+  const int32_t* rowmap;
+  int32_t k_valid;
+  int32_t splits;
+  int32_t accumulate;
+  float alpha;
+} tfx_gemm_tn_args;
+int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
+
+/* ---- attention ------------------------------------------------------------------------------- */
+/* q,k,v: bf16, token-major; element (token t, head h, i) at ptr[t*ld + h*64 + i]; dim_head == 64.
+ * kv_end[t] (per token, relative to its sample): key j visible iff j < kv_end.  q_start[j]: first query
+ * position that sees key j.  gate: logits at gate[t*ld_gate + h].  out: gated output og (bf16). */
+typedef struct {
+  const tfx_bf16 *q, *k, *v; int32_t ld_q, ld_k, ld_v;
+  const tfx_bf16* gate; int32_t ld_gate;
+  const int32_t* kv_end;
+  const int32_t* q_start;
+  tfx_bf16* out; int32_t ld_out;
+  float* lse;                 /* [b, h, n] */
+  int32_t b, h, n;
+  float softcap;
+  /* backward */
+  const tfx_bf16* dout; int32_t ld_dout;     /* grad wrt gated output */
+  tfx_bf16* do_eff; int32_t ld_do;           /* scratch: dout * sigmoid(gate) */
+  float* delta;                               /* [b, h, n] */
+  tfx_bf16* dgate; int32_t ld_dgate;         /* grad wrt gate logits */
+  tfx_bf16 *dq, *dk, *dv; int32_t ld_dq, ld_dk, ld_dv;
+} tfx_attn_args;
+int tfx_attn_fwd(const tfx_attn_args* a, void* stream);
+int tfx_attn_bwd(const tfx_attn_args* a, void* stream);   /* prep + dK/dV kernel + dQ kernel */
+
+/* ---- token-wise kernels ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t T, d;
+  const tfx_bf16* x; tfx_bf16* u;            /* [T,d] */
+  const int32_t* tok_inst;                    /* [T] instance id or -1 (text) */
+  const float* table; int32_t ld_table;       /* fp32 [I, ld]; this wrapper's gamma at +0, beta at +d, z at +2d */
+  const float* gamma_text;                    /* layernorm_gamma [d] */
+  float* mean; float* rstd;                   /* [T] saved stats */
+  /* backward */
+  const tfx_bf16* du; tfx_bf16* dx;           /* dx += LN backward (in place accumulate) */
+  float* dtable;                              /* fp32 [I, ld] (atomic accumulate) */
+  float* dgamma_text;                         /* [d] (atomic accumulate) */
+} tfx_adaln_pre_args;
+int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* stream);
+int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* stream);
+
+typedef struct {
+  int32_t T, d;
+  const tfx_bf16* x; const tfx_bf16* y; tfx_bf16* out;   /* out = x + y * scale */
+  const int32_t* tok_inst;
+  const float* table; int32_t ld_table;       /* z logits at table[inst*ld + 2d + col] */
+  const float* layerscale;                    /* [d] */
+  /* backward: g = grad wrt out (also the residual grad, passed through untouched) */
+  const tfx_bf16* g; tfx_bf16* dy;
+  float* dtable; float* dlayerscale;
+} tfx_adaln_post_args;
+int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* stream);
+int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* stream);
+
+typedef struct {
+  int32_t T, H;                               /* dim_head == 64 */
+  const tfx_bf16* qkv; int32_t ld_qkv;        /* q at col h*64, k at col H*64 + h*64 (pre-norm) */
+  tfx_bf16* qk; int32_t ld_qk;                /* post norm+rope(+q scale), same column layout */
+  const float* gamma_q; const float* gamma_k; /* [64] */
+  const int32_t* rot_pos;                     /* [T] */
+  const float* cos_tab; const float* sin_tab; /* [P, 32] */
+  float q_scale;
+  /* backward */
+  const tfx_bf16* dqk; int32_t ld_dqk;        /* grad wrt post-norm q,k */
+  tfx_bf16* dqkv; int32_t ld_dqkv;            /* grad wrt pre-norm q,k (written) */
+  float* dgamma_q; float* dgamma_k;           /* atomic accumulate */
+} tfx_qk_norm_rope_args;
+int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* stream);
+int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* stream);
+
+typedef struct {
+  int32_t T, d, L;                            /* L = number of hiddens h_0..h_{L-1} */
+  const tfx_bf16* hiddens; int64_t stride_h;  /* hiddens + l*stride_h -> [T,d] */
+  const float* gamma; const float* pq;        /* norm_keys.gamma, pseudo_queries [d] */
+  tfx_bf16* out;
+  /* backward */
+  const tfx_bf16* g; const tfx_bf16* g2;      /* grad wrt out (+ optional second addend) */
+  tfx_bf16* dhiddens; int64_t stride_dh;      /* accumulate (or store if `first`) */
+  int32_t first;
+  float* dgamma; float* dpq;                  /* atomic accumulate */
+} tfx_attnres_args;
+int tfx_attnres_fwd(const tfx_attnres_args* a, void* stream);
+int tfx_attnres_bwd(const tfx_attnres_args* a, void* stream);
+
+typedef struct {
+  int32_t T, d;
+  const tfx_bf16* x; tfx_bf16* y; const float* gamma;
+  const tfx_bf16* dy; tfx_bf16* dx; float* dgamma;
+} tfx_rmsnorm_args;
+int tfx_rmsnorm_fwd(const tfx_rmsnorm_args* a, void* stream);
+int tfx_rmsnorm_bwd(const tfx_rmsnorm_args* a, void* stream);
+
+/* text embedding gather into the token buffer (only tokens with tok_inst < 0), and its backward */
+typedef struct {
+  int32_t T, d;
+  const int32_t* text_ids; const int32_t* tok_inst;
+  const tfx_bf16* table;                      /* bf16 shadow of text_embed.weight [V, d] */
+  tfx_bf16* x;
+  const tfx_bf16* dx; float* dtable;          /* backward: fp32 [V, d] atomic accumulate */
+} tfx_embed_args;
+int tfx_embed_fwd(const tfx_embed_args* a, void* stream);
+int tfx_embed_bwd(const tfx_embed_args* a, void* stream);
+
+/* x_t = t*x + (1-t)*eps (bf16, padded to ld_xt with zeros), flow = x - eps (fp32)   MP:654-656 */
+typedef struct {
+  int32_t R, dl;
+  const float* x; const float* eps;           /* [R, dl] */
+  const int32_t* row_inst; const float* inst_time;
+  tfx_bf16* xt; int32_t ld_xt;
+  float* flow;                                /* [R, dl] (may be NULL) */
+} tfx_noise_mix_args;
+int tfx_noise_mix(const tfx_noise_mix_args* a, void* stream);
+
+/* e[i,:] = [t, sin(2 pi t w), cos(2 pi t w)] bf16, zero padded to ld   T:617-635 */
+typedef struct { int32_t I, half; const float* times; const float* w; tfx_bf16* out; int32_t ld; } tfx_fourier_args;
+int tfx_fourier(const tfx_fourier_args* a, void* stream);
+
+/* fused cross-entropy forward + backward over fp32 logits [T, ld] (V valid columns)   T:3320-3331 */
+typedef struct {
+  int32_t T, V; const float* logits; int32_t ld;
+  const int32_t* labels;                      /* -1 = ignore */
+  float grad_scale;                           /* text_loss_weight / total_tokens */
+  tfx_bf16* dlogits; int32_t ld_d;            /* bf16 [T, ld_d], pad columns zeroed */
+  float* acc;                                 /* acc[0] += sum of token CE, acc[1] += #valid */
+} tfx_ce_args;
+int tfx_ce_fwd_bwd(const tfx_ce_args* a, void* stream);
+
+/* fused MSE forward + backward: pred/flow fp32 [R, dl]   T:3359-3362 */
+typedef struct {
+  int32_t R, dl; const float* pred; int32_t ld_pred; const float* flow;
+  float grad_scale;                           /* 2 * weight / (R*dl) */
+  tfx_bf16* dpred; int32_t ld_d;              /* bf16 [R, ld_d], pad columns zeroed */
+  float* acc;                                 /* acc[0] += sum of squared error */
+} tfx_mse_args;
+int tfx_mse_fwd_bwd(const tfx_mse_args* a, void* stream);
+
+/* ---- parameter plumbing ---------------------------------------------------------------------- */
+/* dst[r][c] (bf16, ld_dst, Rd rows, Cd cols) = src[rowmap ? rowmap[r] : r][c] or 0 when out of range / map < 0 */
+typedef struct { const float* src; int32_t ld_src, Rs, Cs; const int32_t* rowmap; tfx_bf16* dst; int32_t ld_dst, Rd, Cd; } tfx_cast_args;
+int tfx_cast_rows(const tfx_cast_args* a, void* stream);
+/* dst[c][r] = src[rowmap ? rowmap[r] : r][c]  (transposed shadow for the dX GEMMs) */
+int tfx_cast_rows_t(const tfx_cast_args* a, void* stream);
+/* out_f32[i] = gather of fp32 vector through a map (bias shadows): dst[i] = map[i] >= 0 ? src[map[i]] : 0 */
+int tfx_gather_f32(const float* src, const int32_t* map, float* dst, int32_t n, void* stream);
+int tfx_f32_to_bf16(const float* src, tfx_bf16* dst, int64_t n, void* stream);
+/* dst(bf16) = a(bf16) * silu'(pre(bf16))  (time-MLP backward) */
+int tfx_silu_bwd(const tfx_bf16* dy, const tfx_bf16* pre, tfx_bf16* dx, int64_t n, void* stream);
+/* column sums: out[c] += sum_r src[r][c]  (bias gradients); src bf16 or fp32 */
+int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const int32_t* colmap, float* out, void* stream);
+int tfx_colsum_f32(const float* src, int32_t ld, int32_t R, int32_t C, float* out, void* stream);
+int tfx_add_bf16(const tfx_bf16* a, const tfx_bf16* b, tfx_bf16* out, int64_t n, void* stream);
+
+/* fused global-norm clip + Adam over flat fp32 buffers   train_toy.py:55-57
+ * sumsq[0] must hold the sum of squared gradients (tfx_sumsq accumulates into it; zero it first). */
+int tfx_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+typedef struct {
+  float* p; const float* g; float* m; float* v; int64_t n;
+  float lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale;
+  int32_t step; const float* sumsq;
+} tfx_adam_args;
+int tfx_adam_step(const tfx_adam_args* a, void* stream);
+
+const char* tfx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

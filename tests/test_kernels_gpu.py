@@ -1,0 +1,468 @@
+"""Per-kernel parity: every HIP kernel (through the C ABI) vs a plain PyTorch fp32 reference of the same op.
+Tolerances: bf16 outputs rel-Frobenius <= 1e-2 (bf16 eps = 3.9e-3); fp32 outputs of bf16 MFMA GEMMs <= 5e-3."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from transfusion_pytorch_amd import capi  # noqa: E402
+
+DEV = 'cuda'
+BF = torch.bfloat16
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def check(name, got, ref, tol):
+    assert torch.isfinite(got.float()).all(), f'{name}: non-finite output'
+    e = relerr(got, ref)
+    print(f'{name}: rel err {e:.3e} (tol {tol})')
+    assert e <= tol, f'{name}: rel err {e} > {tol}'
+
+
+def rnd(*shape, scale=1.0, dtype=BF):
+    return (torch.randn(*shape, device=DEV) * scale).to(dtype)
+
+
+def gemm_nt(**kw):
+    a = capi.make_args('tfx_gemm_nt_args', **kw)
+    capi.call('tfx_gemm_nt', a, stream())
+
+
+# ---------------------------------------------------------------------------------------------- GEMM NT
+@pytest.mark.parametrize('M,N,K', [(300, 200, 128), (128, 128, 64), (1000, 1544, 512), (4096, 512, 1408), (77, 390, 192)])
+def test_gemm_nt_bf16_bias(M, N, K):
+    torch.manual_seed(0)
+    A, B = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    Np = (N + 3) // 4 * 4
+    bias = torch.randn(Np, device=DEV)
+    C = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+    gemm_nt(A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS['TFX_EPI_BF16'], C=C, ldc=N, bias=bias)
+    ref = A.float() @ B.float().T + bias[:N]
+    check(f'gemm_nt bf16 {M}x{N}x{K}', C, ref, 6e-3)
+    C32 = torch.full((M, N), float('nan'), device=DEV)
+    gemm_nt(A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS['TFX_EPI_F32'], C=C32, ldc=N, bias=bias)
+    check(f'gemm_nt f32 {M}x{N}x{K}', C32, ref, 1e-5 * 50)
+
+
+def test_gemm_nt_asymmetric_identity():
+    # transpose-detecting check: A = I, asymmetric B
+    M = N = K = 128
+    A = torch.eye(M, device=DEV).to(BF)
+    B = (torch.arange(N * K, device=DEV).reshape(N, K) % 251).float().to(BF)
+    C = torch.zeros(M, N, device=DEV)
+    gemm_nt(A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS['TFX_EPI_F32'], C=C, ldc=N)
+    assert torch.equal(C, B.float().T)
+
+
+def test_gemm_nt_split_a_rowmaps_resid():
+    torch.manual_seed(1)
+    M, N, K1, K2 = 333, 256, 128, 192
+    A1, A2 = rnd(M, K1), rnd(M, K2)
+    B = rnd(N, K1 + K2, scale=(K1 + K2) ** -0.5)
+    R = rnd(M, N)
+    C = torch.zeros(M, N, device=DEV, dtype=BF)
+    gemm_nt(A=A1, lda=K1, A2=A2, lda2=K2, K1=K1, B=B, ldb=K1 + K2, M=M, N=N, K=K1 + K2,
+            epi=capi.ENUMS['TFX_EPI_RESID'], C=C, ldc=N, R=R, ldr=N)
+    ref = torch.cat([A1, A2], 1).float() @ B.float().T + R.float()
+    check('gemm_nt split-A + resid', C, ref, 6e-3)
+    # gather A rows + scatter C rows (negative = drop) + residual read at the scattered row
+    Msrc, T = 500, 700
+    Asrc = rnd(Msrc, K1)
+    amap = torch.randint(0, Msrc, (M,), device=DEV, dtype=torch.int32)
+    omap = torch.randperm(T, device=DEV)[:M].to(torch.int32)
+    omap[::17] = -1
+    Bs = rnd(N, K1, scale=K1 ** -0.5)
+    Cbig = rnd(T, N)
+    Cref = Cbig.float().clone()
+    gemm_nt(A=Asrc, lda=K1, a_rowmap=amap, B=Bs, ldb=K1, M=M, N=N, K=K1, epi=capi.ENUMS['TFX_EPI_RESID'],
+            C=Cbig, ldc=N, R=Cbig, ldr=N, resid_mapped=1, rowmap=omap)
+    prod = Asrc[amap.long()].float() @ Bs.float().T
+    keep = omap >= 0
+    Cref[omap[keep].long()] += prod[keep]
+    check('gemm_nt gather/scatter/resid_mapped', Cbig, Cref, 6e-3)
+
+
+def test_gemm_nt_silu():
+    torch.manual_seed(2)
+    M, N, K = 200, 512, 576
+    A, B = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    bias = torch.randn(N, device=DEV)
+    C = torch.zeros(M, N, device=DEV, dtype=BF); C2 = torch.zeros(M, N, device=DEV, dtype=BF)
+    gemm_nt(A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS['TFX_EPI_SILU'], C=C, ldc=N, C2=C2, ldc2=N, bias=bias)
+    pre = A.float() @ B.float().T + bias
+    check('gemm_nt silu pre', C2, pre, 6e-3)
+    check('gemm_nt silu act', C, F.silu(pre), 6e-3)
+
+
+def geglu_perm(dip):
+    """physical column c of the interleaved layout -> (is_gate, feature)."""
+    c = torch.arange(2 * dip)
+    blk, within = c // 64, c % 64
+    is_gate = within >= 32
+    feat = blk * 32 + within % 32
+    return is_gate, feat
+
+
+def test_gemm_nt_geglu_fwd_bwd():
+    torch.manual_seed(3)
+    M, d, dip = 300, 128, 192
+    u = rnd(M, d)
+    Wa, Wg = rnd(dip, d, scale=d ** -0.5), rnd(dip, d, scale=d ** -0.5)
+    ba, bg = torch.randn(dip, device=DEV), torch.randn(dip, device=DEV)
+    is_gate, feat = geglu_perm(dip)
+    is_gate, feat = is_gate.to(DEV), feat.to(DEV)
+    Wphys = torch.where(is_gate[:, None], Wg[feat], Wa[feat]).contiguous()
+    bphys = torch.where(is_gate, bg[feat], ba[feat]).contiguous()
+    ag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF); hm = torch.zeros(M, dip, device=DEV, dtype=BF)
+    gemm_nt(A=u, lda=d, B=Wphys, ldb=d, M=M, N=2 * dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU'], C=ag, ldc=2 * dip,
+            C2=hm, ldc2=dip, bias=bphys)
+    a = u.float() @ Wa.float().T + ba
+    g = u.float() @ Wg.float().T + bg
+    ag_ref = torch.where(is_gate[None], g[:, feat], a[:, feat])
+    check('geglu pre-activation (interleaved)', ag, ag_ref, 6e-3)
+    check('geglu hidden', hm, a * F.gelu(g), 8e-3)
+    # backward epilogue: dh = dy @ W2t^T (here: plain GEMM against random B), d[a|g] from saved ag
+    K2 = 128
+    dy, W2t = rnd(M, K2), rnd(dip, K2, scale=K2 ** -0.5)
+    dag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF)
+    gemm_nt(A=dy, lda=K2, B=W2t, ldb=K2, M=M, N=dip, K=K2, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip,
+            aux=ag, ldaux=2 * dip)
+    dh = dy.float() @ W2t.float().T
+    a_s, g_s = ag.float()[:, ~is_gate], ag.float()[:, is_gate]     # saved (bf16-rounded) pre-activations, feature order
+    g_s = g_s.requires_grad_(True); a_s = a_s.requires_grad_(True)
+    (a_s * F.gelu(g_s)).backward(dh)
+    dag_ref = torch.zeros(M, 2 * dip, device=DEV)
+    dag_ref[:, ~is_gate] = a_s.grad; dag_ref[:, is_gate] = g_s.grad
+    check('geglu backward epilogue', dag, dag_ref, 8e-3)
+
+
+# ---------------------------------------------------------------------------------------------- GEMM TN
+@pytest.mark.parametrize('M,N,K,splits', [(1000, 200, 136, 1), (1000, 200, 136, 4), (4096, 1544, 512, 8), (100, 64, 64, 3)])
+def test_gemm_tn(M, N, K, splits):
+    torch.manual_seed(4)
+    lda = (N + 7) // 8 * 8 + 8
+    ldb = (K + 7) // 8 * 8
+    A = rnd(M, lda, scale=0.5); B = rnd(M, ldb, scale=0.5)
+    kv = K - 3
+    rowmap = torch.arange(N, device=DEV, dtype=torch.int32).flip(0).contiguous()
+    rowmap[5] = -1
+    C = torch.full((N, K), 1.0, device=DEV)
+    a = capi.make_args('tfx_gemm_tn_args', A=A, lda=lda, a_cols=(N + 7) // 8 * 8, B=B, ldb=ldb, b_cols=ldb, M=M, N=N, K=K,
+                       C=C, ldc=K, rowmap=rowmap, k_valid=kv, splits=splits, accumulate=1, alpha=0.5)
+    capi.call('tfx_gemm_tn', a, stream())
+    prod = 0.5 * (A[:, :N].float().T @ B[:, :K].float())
+    ref = torch.full((N, K), 1.0, device=DEV)
+    keep = rowmap >= 0
+    ref[rowmap[keep].long(), :kv] += prod[keep][:, :kv]
+    check(f'gemm_tn {M}x{N}x{K} splits={splits}', C, ref, 5e-3)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def make_kv_end(b, n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    kv_end = torch.arange(1, n + 1).repeat(b, 1)
+    q_start = torch.arange(n).repeat(b, 1)
+    for bi in range(b):
+        pos = 3
+        while pos < n - 2:
+            L = int(torch.randint(1, 9, (1,), generator=g))
+            L = min(L, n - pos)
+            kv_end[bi, pos:pos + L] = pos + L
+            q_start[bi, pos:pos + L] = pos
+            pos += L + int(torch.randint(1, 30, (1,), generator=g))
+    return kv_end.to(torch.int32), q_start.to(torch.int32)
+
+
+def attn_ref(q, k, v, gate, kv_end, cap):
+    # q,k,v (b,h,n,64) fp32 ; gate (b,h,n)
+    n = q.shape[2]
+    sim = torch.einsum('bhid,bhjd->bhij', q, k)
+    sim = torch.tanh(sim / cap) * cap
+    mask = torch.arange(n, device=q.device)[None, None, :] < kv_end[:, :, None]
+    sim = sim.masked_fill(~mask[:, None], -torch.finfo(torch.float32).max)
+    p = sim.softmax(-1)
+    o = torch.einsum('bhij,bhjd->bhid', p, v)
+    return o * gate.sigmoid()[..., None]
+
+
+@pytest.mark.parametrize('b,h,n', [(2, 2, 200), (1, 3, 128), (2, 1, 333), (1, 8, 1024)])
+def test_attention_fwd_bwd(b, h, n):
+    torch.manual_seed(5)
+    T, HD = b * n, h * 64
+    ldq, ldv = 2 * HD, 3 * HD + 8
+    qk = rnd(T, ldq, scale=1.0)                                   # q | k, token-major
+    qk[:, :HD] *= 0.35                                            # q~ carries the 1/8 scale -> moderate logits
+    qk[:, HD:] *= 2.5
+    qkv = rnd(T, ldv)                                             # (unused q,k cols) | v | gates
+    kv_end, q_start = make_kv_end(b, n)
+    kv_end, q_start = kv_end.to(DEV), q_start.to(DEV)
+    out = torch.zeros(T, HD, device=DEV, dtype=BF)
+    lse = torch.zeros(b, h, n, device=DEV)
+    dout = rnd(T, HD)
+    do_eff = torch.zeros(T, HD, device=DEV, dtype=BF)
+    delta = torch.zeros(b, h, n, device=DEV)
+    dqk = torch.zeros(T, ldq, device=DEV, dtype=BF)
+    dqkv = torch.zeros(T, ldv, device=DEV, dtype=BF)
+    gate_view = qkv[:, 3 * HD:]
+    a = capi.make_args(
+        'tfx_attn_args', q=qk, k=qk[:, HD:], v=qkv[:, 2 * HD:], ld_q=ldq, ld_k=ldq, ld_v=ldv,
+        gate=gate_view, ld_gate=ldv, kv_end=kv_end, q_start=q_start, out=out, ld_out=HD, lse=lse, b=b, h=h, n=n, softcap=50.0,
+        dout=dout, ld_dout=HD, do_eff=do_eff, ld_do=HD, delta=delta, dgate=dqkv[:, 3 * HD:], ld_dgate=ldv,
+        dq=dqk, dk=dqk[:, HD:], dv=dqkv[:, 2 * HD:], ld_dq=ldq, ld_dk=ldq, ld_dv=ldv)
+    capi.call('tfx_attn_fwd', a, stream())
+    capi.call('tfx_attn_bwd', a, stream())
+    torch.cuda.synchronize()
+
+    def heads(x):  # (T, HD) -> (b,h,n,64)
+        return x.float().reshape(b, n, h, 64).transpose(1, 2)
+    q = heads(qk[:, :HD]).requires_grad_(True)
+    k = heads(qk[:, HD:]).requires_grad_(True)
+    v = heads(qkv[:, 2 * HD:3 * HD]).requires_grad_(True)
+    g = gate_view[:, :h].float().reshape(b, n, h).transpose(1, 2).requires_grad_(True)
+    ref = attn_ref(q, k, v, g, kv_end.long(), 50.0)
+    ref.backward(heads(dout))
+    check(f'attn fwd b{b} h{h} n{n}', heads(out), ref, 8e-3)
+    check('attn dq', heads(dqk[:, :HD]), q.grad, 2e-2)
+    check('attn dk', heads(dqk[:, HD:]), k.grad, 2e-2)
+    check('attn dv', heads(dqkv[:, 2 * HD:3 * HD]), v.grad, 2e-2)
+    check('attn dgate', dqkv[:, 3 * HD:3 * HD + h].float().reshape(b, n, h).transpose(1, 2), g.grad, 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------- token-wise
+def tok_setup(T, d, I, seed=0):
+    torch.manual_seed(seed)
+    tok_inst = torch.full((T,), -1, dtype=torch.int32)
+    idx = torch.randperm(T)[: T // 3]
+    tok_inst[idx] = torch.randint(0, I, (len(idx),), dtype=torch.int32)
+    ld = 3 * d + 8
+    table = torch.randn(I, ld, device=DEV) * 0.5
+    return tok_inst.to(DEV), table, ld
+
+
+@pytest.mark.parametrize('T,d', [(1000, 512), (333, 64), (257, 768), (130, 1024)])
+def test_adaln_pre_post(T, d):
+    I = 37
+    tok_inst, table, ld = tok_setup(T, d, I)
+    x = rnd(T, d, scale=2.0); gt = torch.randn(d, device=DEV) * 0.3
+    u = torch.zeros(T, d, device=DEV, dtype=BF)
+    mean = torch.zeros(T, device=DEV); rstd = torch.zeros(T, device=DEV)
+    du = rnd(T, d)
+    dx = rnd(T, d); dx0 = dx.float().clone()
+    dtable = torch.zeros_like(table); dgt = torch.zeros(d, device=DEV)
+    a = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x, u=u, tok_inst=tok_inst, table=table, ld_table=ld, gamma_text=gt,
+                       mean=mean, rstd=rstd, du=du, dx=dx, dtable=dtable, dgamma_text=dgt)
+    capi.call('tfx_adaln_pre_fwd', a, stream())
+    capi.call('tfx_adaln_pre_bwd', a, stream())
+    xr = x.float().requires_grad_(True); tr = table.clone().requires_grad_(True); gr = gt.clone().requires_grad_(True)
+    im = (tok_inst >= 0)[:, None]
+    ii = tok_inst.clamp(min=0).long()
+    xh = F.layer_norm(xr, (d,))
+    ref = torch.where(im, xh * (tr[ii, :d] + 1) + tr[ii, d:2 * d], xh * (gr + 1))
+    ref.backward(du.float())
+    check(f'adaln_pre fwd d{d}', u, ref, 6e-3)
+    check('adaln_pre dx', dx.float() - dx0, xr.grad, 1.5e-2)
+    check('adaln_pre dtable', dtable, tr.grad, 5e-3)
+    check('adaln_pre dgamma_text', dgt, gr.grad, 5e-3)
+    # post
+    y = rnd(T, d); ls = torch.randn(d, device=DEV) * 0.3
+    out = torch.zeros(T, d, device=DEV, dtype=BF); g = rnd(T, d); dy = torch.zeros(T, d, device=DEV, dtype=BF)
+    dtable2 = torch.zeros_like(table); dls = torch.zeros(d, device=DEV)
+    a = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x, y=y, out=out, tok_inst=tok_inst, table=table, ld_table=ld,
+                       layerscale=ls, g=g, dy=dy, dtable=dtable2, dlayerscale=dls)
+    capi.call('tfx_adaln_post_fwd', a, stream())
+    capi.call('tfx_adaln_post_bwd', a, stream())
+    yr = y.float().requires_grad_(True); tr = table.clone().requires_grad_(True); lr = ls.clone().requires_grad_(True)
+    ref = x.float() + torch.where(im, yr * tr[ii, 2 * d:3 * d].sigmoid(), yr * (lr + 1))
+    ref.backward(g.float())
+    check('adaln_post fwd', out, ref, 6e-3)
+    check('adaln_post dy', dy, yr.grad, 6e-3)
+    check('adaln_post dtable', dtable2, tr.grad, 5e-3)
+    check('adaln_post dlayerscale', dls, lr.grad, 5e-3)
+
+
+@pytest.mark.parametrize('T,d', [(777, 512), (100, 128), (130, 1024)])
+def test_rmsnorm(T, d):
+    torch.manual_seed(0)
+    x = rnd(T, d, scale=3.0); gm = torch.randn(d, device=DEV) * 0.3
+    y = torch.zeros(T, d, device=DEV, dtype=BF); dy = rnd(T, d); dx = torch.zeros(T, d, device=DEV, dtype=BF); dg = torch.zeros(d, device=DEV)
+    a = capi.make_args('tfx_rmsnorm_args', T=T, d=d, x=x, y=y, gamma=gm, dy=dy, dx=dx, dgamma=dg)
+    capi.call('tfx_rmsnorm_fwd', a, stream()); capi.call('tfx_rmsnorm_bwd', a, stream())
+    xr = x.float().requires_grad_(True); gr = gm.clone().requires_grad_(True)
+    ref = F.normalize(xr, dim=-1) * d ** 0.5 * (gr + 1)
+    ref.backward(dy.float())
+    check('rmsnorm fwd', y, ref, 6e-3); check('rmsnorm dx', dx, xr.grad, 1e-2); check('rmsnorm dgamma', dg, gr.grad, 5e-3)
+
+
+@pytest.mark.parametrize('T,d,L', [(500, 512, 5), (300, 64, 3), (100, 1024, 9), (64, 256, 1)])
+def test_attnres(T, d, L):
+    torch.manual_seed(0)
+    H = rnd(L, T, d, scale=2.0); gm = torch.randn(d, device=DEV) * 0.3; pq = torch.randn(d, device=DEV) * 0.5
+    out = torch.zeros(T, d, device=DEV, dtype=BF)
+    g = rnd(T, d); g2 = rnd(T, d)
+    dH = rnd(L, T, d); dH0 = dH.float().clone()
+    dgm = torch.zeros(d, device=DEV); dpq = torch.zeros(d, device=DEV)
+    a = capi.make_args('tfx_attnres_args', T=T, d=d, L=L, hiddens=H, stride_h=T * d, gamma=gm, pq=pq, out=out, g=g, g2=g2,
+                       dhiddens=dH, stride_dh=T * d, first=0, dgamma=dgm, dpq=dpq)
+    capi.call('tfx_attnres_fwd', a, stream()); capi.call('tfx_attnres_bwd', a, stream())
+    Hr = H.float().requires_grad_(True); gr = gm.clone().requires_grad_(True); pr = pq.clone().requires_grad_(True)
+    keys = F.normalize(Hr, dim=-1) * d ** 0.5 * (gr + 1)
+    sim = torch.einsum('ltd,d->tl', keys, pr) * d ** -0.5
+    ref = torch.einsum('tl,ltd->td', sim.softmax(-1), Hr)
+    ref.backward(g.float() + g2.float())
+    check(f'attnres fwd L{L} d{d}', out, ref, 6e-3)
+    check('attnres dH (accumulate)', dH.float() - dH0, Hr.grad, 2e-2)
+    check('attnres dgamma', dgm, gr.grad, 1e-2); check('attnres dpq', dpq, pr.grad, 1e-2)
+    dH2 = torch.full_like(dH, float('nan'))
+    a = capi.make_args('tfx_attnres_args', T=T, d=d, L=L, hiddens=H, stride_h=T * d, gamma=gm, pq=pq, out=out, g=g,
+                       dhiddens=dH2, stride_dh=T * d, first=1, dgamma=dgm, dpq=dpq)
+    capi.call('tfx_attnres_bwd', a, stream())
+    Hr.grad = None
+    keys = F.normalize(Hr, dim=-1) * d ** 0.5 * (gm + 1)
+    sim = torch.einsum('ltd,d->tl', keys, pq) * d ** -0.5
+    torch.einsum('tl,ltd->td', sim.softmax(-1), Hr).backward(g.float())
+    check('attnres dH (first=store)', dH2, Hr.grad, 1e-2)
+
+
+@pytest.mark.parametrize('T,H', [(500, 2), (1000, 8)])
+def test_qk_norm_rope(T, H):
+    torch.manual_seed(0)
+    HD = H * 64; ld = 3 * HD + 8
+    qkv = rnd(T, ld, scale=1.5)
+    gq = torch.randn(64, device=DEV) * 0.3; gk = torch.randn(64, device=DEV) * 0.3
+    pos = torch.randint(0, 900, (T,), device=DEV, dtype=torch.int32)
+    freqs = 1. / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(1024).float()[:, None] * freqs[None]
+    cos_t, sin_t = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    qk = torch.zeros(T, 2 * HD, device=DEV, dtype=BF)
+    dqk = rnd(T, 2 * HD); dqkv = torch.zeros(T, ld, device=DEV, dtype=BF)
+    dgq = torch.zeros(64, device=DEV); dgk = torch.zeros(64, device=DEV)
+    a = capi.make_args('tfx_qk_norm_rope_args', T=T, H=H, qkv=qkv, ld_qkv=ld, qk=qk, ld_qk=2 * HD, gamma_q=gq, gamma_k=gk,
+                       rot_pos=pos, cos_tab=cos_t, sin_tab=sin_t, q_scale=0.125, dqk=dqk, ld_dqk=2 * HD, dqkv=dqkv, ld_dqkv=ld,
+                       dgamma_q=dgq, dgamma_k=dgk)
+    capi.call('tfx_qk_norm_rope_fwd', a, stream()); capi.call('tfx_qk_norm_rope_bwd', a, stream())
+    x = qkv[:, :2 * HD].float().reshape(T, 2, H, 64).requires_grad_(True)
+    gqr = gq.clone().requires_grad_(True); gkr = gk.clone().requires_grad_(True)
+    gam = torch.stack([gqr, gkr])[None, :, None, :]
+    y = F.normalize(x, dim=-1) * 8 * (gam + 1)
+    angp = ang.to(DEV)[pos.long()].repeat_interleave(2, dim=-1)[:, None, None, :]
+    y2 = y.reshape(T, 2, H, 32, 2)
+    rot = torch.stack((-y2[..., 1], y2[..., 0]), -1).reshape(T, 2, H, 64)
+    out = y * angp.cos() + rot * angp.sin()
+    out = out * torch.tensor([0.125, 1.0], device=DEV)[None, :, None, None]
+    out.backward(dqk.float().reshape(T, 2, H, 64))
+    check('qk_norm_rope fwd', qk.reshape(T, 2, H, 64), out, 6e-3)
+    check('qk_norm_rope dx', dqkv[:, :2 * HD].reshape(T, 2, H, 64), x.grad, 1.2e-2)
+    check('qk_norm_rope dgamma_q', dgq, gqr.grad, 1e-2); check('qk_norm_rope dgamma_k', dgk, gkr.grad, 1e-2)
+
+
+def test_embed_noise_fourier():
+    torch.manual_seed(0)
+    T, d, V = 700, 512, 390
+    ids = torch.randint(-1, V, (T,), device=DEV, dtype=torch.int32)
+    tok_inst = torch.where(torch.rand(T, device=DEV) < 0.3, torch.zeros(T, device=DEV), -torch.ones(T, device=DEV)).to(torch.int32)
+    table = rnd(V, d)
+    x = torch.zeros(T, d, device=DEV, dtype=BF); dx = rnd(T, d); dtab = torch.zeros(V, d, device=DEV)
+    a = capi.make_args('tfx_embed_args', T=T, d=d, text_ids=ids, tok_inst=tok_inst, table=table, x=x, dx=dx, dtable=dtab)
+    capi.call('tfx_embed_fwd', a, stream()); capi.call('tfx_embed_bwd', a, stream())
+    text = tok_inst < 0
+    ref = torch.where(text[:, None], table[ids.clamp(min=0).long()].float(), torch.zeros(T, d, device=DEV))
+    check('embed fwd', x, ref, 1e-6)
+    dref = torch.zeros(V, d, device=DEV).index_add_(0, ids.clamp(min=0).long()[text], dx.float()[text])
+    check('embed bwd', dtab, dref, 1e-5)
+    # noise mix
+    R, dl, ldx = 300, 48, 64
+    xs = torch.randn(R, dl, device=DEV); eps = torch.randn(R, dl, device=DEV)
+    I = 40
+    row_inst = torch.randint(0, I, (R,), device=DEV, dtype=torch.int32); times = torch.rand(I, device=DEV)
+    xt = torch.full((R, ldx), float('nan'), device=DEV, dtype=BF); flow = torch.zeros(R, dl, device=DEV)
+    a = capi.make_args('tfx_noise_mix_args', R=R, dl=dl, x=xs, eps=eps, row_inst=row_inst, inst_time=times, xt=xt, ld_xt=ldx, flow=flow)
+    capi.call('tfx_noise_mix', a, stream())
+    tt = times[row_inst.long()][:, None]
+    check('noise_mix xt', xt[:, :dl], xs * tt + eps * (1 - tt), 4e-3)
+    assert (xt[:, dl:] == 0).all()
+    check('noise_mix flow', flow, xs - eps, 1e-6)
+    # fourier
+    half, ldf = 32, 128
+    w = torch.randn(half, device=DEV); out = torch.full((I, ldf), float('nan'), device=DEV, dtype=BF)
+    a = capi.make_args('tfx_fourier_args', I=I, half=half, times=times, w=w, out=out, ld=ldf)
+    capi.call('tfx_fourier', a, stream())
+    fr = times[:, None] * w[None] * 2 * math.pi
+    check('fourier', out[:, :2 * half + 1], torch.cat([times[:, None], fr.sin(), fr.cos()], -1), 4e-3)
+    assert (out[:, 2 * half + 1:] == 0).all()
+
+
+def test_losses():
+    torch.manual_seed(0)
+    T, V, ld = 1000, 390, 448
+    logits = torch.randn(T, ld, device=DEV) * 2
+    labels = torch.randint(0, V, (T,), device=DEV, dtype=torch.int32)
+    labels[::3] = -1
+    dlog = torch.full((T, ld), float('nan'), device=DEV, dtype=BF); acc = torch.zeros(4, device=DEV)
+    scale = 1.0 / 1234
+    a = capi.make_args('tfx_ce_args', T=T, V=V, logits=logits, ld=ld, labels=labels, grad_scale=scale, dlogits=dlog, ld_d=ld, acc=acc)
+    capi.call('tfx_ce_fwd_bwd', a, stream())
+    lr = logits[:, :V].clone().requires_grad_(True)
+    ce = F.cross_entropy(lr, labels.long(), ignore_index=-1, reduction='sum')
+    (ce * scale).backward()
+    assert abs(acc[0].item() - ce.item()) < 1e-3 * ce.item()
+    assert acc[1].item() == (labels >= 0).sum().item()
+    check('ce dlogits', dlog[:, :V], lr.grad, 6e-3)
+    assert (dlog[:, V:] == 0).all()
+    R, dl, ldp, ldd = 500, 48, 48, 64
+    pred = torch.randn(R, ldp, device=DEV); flow = torch.randn(R, dl, device=DEV)
+    dp = torch.full((R, ldd), float('nan'), device=DEV, dtype=BF); acc = torch.zeros(4, device=DEV)
+    a = capi.make_args('tfx_mse_args', R=R, dl=dl, pred=pred, ld_pred=ldp, flow=flow, grad_scale=0.37, dpred=dp, ld_d=ldd, acc=acc)
+    capi.call('tfx_mse_fwd_bwd', a, stream())
+    assert abs(acc[0].item() - ((pred - flow) ** 2).sum().item()) < 1e-3 * acc[0].item()
+    check('mse dpred', dp[:, :dl], (pred - flow) * 0.37, 4e-3)
+    assert (dp[:, dl:] == 0).all()
+
+
+def test_param_plumbing():
+    torch.manual_seed(0)
+    Rs, Cs = 200, 70
+    src = torch.randn(Rs, Cs, device=DEV)
+    Rd, Cd, ldd = 256, 128, 128
+    rowmap = torch.randint(-1, Rs, (Rd,), device=DEV, dtype=torch.int32)
+    dst = torch.full((Rd, ldd), float('nan'), device=DEV, dtype=BF)
+    a = capi.make_args('tfx_cast_args', src=src, ld_src=Cs, Rs=Rs, Cs=Cs, rowmap=rowmap, dst=dst, ld_dst=ldd, Rd=Rd, Cd=Cd)
+    capi.call('tfx_cast_rows', a, stream())
+    ref = torch.zeros(Rd, ldd, device=DEV)
+    keep = rowmap >= 0
+    ref[keep, :Cs] = src[rowmap[keep].long()]
+    check('cast_rows', dst, ref, 4e-3)
+    # transposed: dst[c][r] = src[map(r)][c]; dst rows = padded Cs (128), cols = padded #r (256)
+    dstT = torch.full((128, 256), float('nan'), device=DEV, dtype=BF)
+    a = capi.make_args('tfx_cast_args', src=src, ld_src=Cs, Rs=Rs, Cs=Cs, rowmap=rowmap, dst=dstT, ld_dst=256, Rd=128, Cd=Rd)
+    capi.call('tfx_cast_rows_t', a, stream())
+    check('cast_rows_t', dstT, ref[:, :128].T, 4e-3)
+    # colsum
+    X = rnd(1000, 136); out = torch.ones(136, device=DEV)
+    capi.check(capi.lib().tfx_colsum_bf16(X.data_ptr(), 136, 1000, 130, None, out.data_ptr(), stream()), 'colsum')
+    ref = torch.ones(136, device=DEV); ref[:130] += X.float()[:, :130].sum(0)
+    check('colsum_bf16', out, ref, 1e-4)
+    # adam + clip
+    n = 100003
+    p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    pr = p.clone().requires_grad_(True); opt = torch.optim.Adam([pr], lr=3e-4)
+    ss = torch.zeros(1, device=DEV)
+    for step in (1, 2, 3):
+        g = torch.randn(n, device=DEV) * 0.01
+        ss.zero_()
+        capi.check(capi.lib().tfx_sumsq(g.data_ptr(), n, ss.data_ptr(), stream()), 'sumsq')
+        a = capi.make_args('tfx_adam_args', p=p, g=g, m=m, v=v, n=n, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                           max_norm=0.5, grad_scale=1.0, step=step, sumsq=ss)
+        capi.call('tfx_adam_step', a, stream())
+        pr.grad = g.clone(); torch.nn.utils.clip_grad_norm_([pr], 0.5); opt.step()
+    check('adam+clip', p, pr.detach(), 1e-6)

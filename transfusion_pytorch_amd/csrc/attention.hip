@@ -1,0 +1,376 @@
+// Flash attention for the Transfusion score pipeline (reference T:998-1027), dim_head = 64, gfx950 MFMA.
+//
+//   S = q~ k~^T ; S <- cap*tanh(S/cap) ; key j visible to query i iff j < kv_end[i] (prefix-extension
+//   form of naive_attn_mask T:452-470) ; P = softmax(S) ; O = P V ; out = O * sigmoid(gate)
+//
+// All matmuls are v_mfma_f32_32x32x16_bf16.  Layout trick: scores are computed TRANSPOSED
+// (S^T = K.Q^T, lane = query row) so every per-row softmax quantity is per-lane, and P^T feeds the
+// second MFMA straight from registers; the operand that is contracted over its row index (V, or K / Q /
+// dO in the backward) is gathered from row-major LDS tiles with ds_read_b64_tr_b16 (lds_tr8).
+// MFMA contraction "slots" e=0..7 of lane-half hi map to rows 16*tt + 8*(e>>2) + 4*hi + (e&3) of a
+// 32-row block: both operands use the same map, so the sum is unchanged.
+#include "tfx_kernels.h"
+
+namespace tfx {
+
+constexpr int DH = 64;
+constexpr int LDT = 72;            // LDS row stride (elements): 64 + 8 pad -> conflict-free ds_read_b128
+
+// cooperative [64][64] bf16 tile: global (row stride ld, rows clamped to [0, nrows)) -> registers -> LDS
+struct TileRegs { u32x4 r[2]; };
+TFX_DEV void tile_gload(TileRegs& tr, const bf16* base, int ld, int row0, int nrows) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    int c = threadIdx.x + 256 * i;
+    int row = min(row0 + (c >> 3), nrows - 1);
+    tr.r[i] = *(const u32x4*)(base + (size_t)row * ld + (c & 7) * 8);
+  }
+}
+TFX_DEV void tile_sstore(const TileRegs& tr, bf16* lds) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    int c = threadIdx.x + 256 * i;
+    *(u32x4*)(lds + (c >> 3) * LDT + (c & 7) * 8) = tr.r[i];
+  }
+}
+// row-operand fragment (lane: row r0 + (l&31), 8 contiguous columns 16*ks + 8*hi) from an LDS tile
+TFX_DEV bf16x8 lds_rowfrag(const bf16* lds, int r0, int ks) {
+  const int l = threadIdx.x & 63;
+  return *(const bf16x8*)(lds + (r0 + (l & 31)) * LDT + 16 * ks + 8 * (l >> 5));
+}
+// same fragment straight from global memory (row clamped)
+TFX_DEV bf16x8 g_rowfrag(const bf16* base, int ld, int row, int nrows, int ks) {
+  const int l = threadIdx.x & 63;
+  row = min(row, nrows - 1);
+  return *(const bf16x8*)(base + (size_t)row * ld + 16 * ks + 8 * (l >> 5));
+}
+TFX_DEV float fast_tanh(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = f2bf(v[tt * 8 + e]);
+  return o;
+}
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// forward: block = 128 query rows (4 waves x 32), loop over 64-key tiles
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
+  __shared__ __attribute__((aligned(16))) bf16 Ks[64 * LDT];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[64 * LDT];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
+  const int n = p.n, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128;
+  const size_t tok0 = (size_t)b * n;
+  const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
+  const bf16* kb_ = p.k + tok0 * p.ld_k + h * DH;
+  const bf16* vb = p.v + tok0 * p.ld_v + h * DH;
+  const int qrow = q0 + w * 32 + (l & 31);
+  const int qc = min(qrow, n - 1);
+  const int kve = p.kv_end[tok0 + qc];
+  const int kv_limit = p.kv_end[tok0 + min(q0 + 127, n - 1)];     // kv_end is non-decreasing in the query index
+  const int nt = (kv_limit + 63) / 64;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[i][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const float cap = p.softcap, icap = 1.f / p.softcap;
+
+  TileRegs kr, vr;
+  tile_gload(kr, kb_, p.ld_k, 0, n);
+  tile_gload(vr, vb, p.ld_v, 0, n);
+  for (int j = 0; j < nt; j++) {
+    __syncthreads();
+    tile_sstore(kr, Ks); tile_sstore(vr, Vs);
+    __syncthreads();
+    if (j + 1 < nt) { tile_gload(kr, kb_, p.ld_k, (j + 1) * 64, n); tile_gload(vr, vb, p.ld_v, (j + 1) * 64, n); }
+
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) s[kb] = MFMA(lds_rowfrag(Ks, kb * 32, ks), qf[ks], s[kb]);   // S^T[key][q]
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float v = cap * fast_tanh(s[kb][r] * icap);
+        v = key < kve ? v : -INFINITY;
+        s[kb][r] = v; mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);             // finite after tile 0 (key 0 is visible to every query)
+    const float alpha = __expf(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { float e = __expf(s[kb][r] - mn); s[kb][r] = e; ps += e; }
+    ps += __shfl_xor(ps, 32, 64);
+    lsum = lsum * alpha + ps; m = mn;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const bf16x8 pf = pack8(s[kb], tt);
+        const int ra = kb * 32 + 16 * tt + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 2; db++) o[db] = MFMA(lds_tr8(Vs, LDT, ra, ra + 8, db * 32), pf, o[db]);   // O^T[d][q]
+      }
+  }
+  if (qrow < n) {
+    const float g = sigmoidf_(bf2f(p.gate[(tok0 + qrow) * p.ld_gate + h]));
+    const float sc = g / lsum;
+    bf16* op = p.out + (tok0 + qrow) * p.ld_out + h * DH;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = f2bf(o[db][rg * 4 + e] * sc);
+        *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
+      }
+    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = m + __logf(lsum);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward prep: delta = sum_d dout*og ; dgate = delta*(1-sigmoid(g)) ; do_eff = dout*sigmoid(g)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(tfx_attn_args p) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vid = gid >> 3;
+  const int sub = gid & 7;
+  const long long T = (long long)p.b * p.n;
+  if (vid >= T * p.h) return;
+  const long long t = vid / p.h; const int h = (int)(vid % p.h);
+  const bf16x8 d8 = *(const bf16x8*)(p.dout + t * p.ld_dout + h * DH + sub * 8);
+  const bf16x8 o8 = *(const bf16x8*)(p.out + t * p.ld_out + h * DH + sub * 8);
+  const float g = sigmoidf_(bf2f(p.gate[t * p.ld_gate + h]));
+  float dl = 0.f; bf16x8 e8;
+#pragma unroll
+  for (int e = 0; e < 8; e++) { float d = bf2f(d8[e]); dl += d * bf2f(o8[e]); e8[e] = f2bf(d * g); }
+  *(bf16x8*)(p.do_eff + t * p.ld_do + h * DH + sub * 8) = e8;
+  dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+  if (sub == 0) {
+    const long long bb = t / p.n, i = t % p.n;
+    p.delta[(bb * p.h + h) * p.n + i] = dl;
+    p.dgate[t * p.ld_dgate + h] = f2bf(dl * (1.f - g));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dQ: block = 128 query rows, loop over 64-key tiles (forward structure + one more MFMA)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
+  __shared__ __attribute__((aligned(16))) bf16 Ks[64 * LDT];
+  __shared__ __attribute__((aligned(16))) bf16 Vs[64 * LDT];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
+  const int n = p.n, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128;
+  const size_t tok0 = (size_t)b * n;
+  const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
+  const bf16* kb_ = p.k + tok0 * p.ld_k + h * DH;
+  const bf16* vb = p.v + tok0 * p.ld_v + h * DH;
+  const bf16* dob = p.do_eff + tok0 * p.ld_do + h * DH;
+  const int qrow = q0 + w * 32 + (l & 31);
+  const int qc = min(qrow, n - 1);
+  const int kve = p.kv_end[tok0 + qc];
+  const int kv_limit = p.kv_end[tok0 + min(q0 + 127, n - 1)];
+  const int nt = (kv_limit + 63) / 64;
+  const float lse = p.lse[((size_t)b * p.h + h) * n + qc];
+  const float dlt = p.delta[((size_t)b * p.h + h) * n + qc];
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) { qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks); dof[ks] = g_rowfrag(dob, p.ld_do, qrow, n, ks); }
+  f32x16 dq[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
+  const float cap = p.softcap, icap = 1.f / p.softcap;
+
+  TileRegs kr, vr;
+  tile_gload(kr, kb_, p.ld_k, 0, n);
+  tile_gload(vr, vb, p.ld_v, 0, n);
+  for (int j = 0; j < nt; j++) {
+    __syncthreads();
+    tile_sstore(kr, Ks); tile_sstore(vr, Vs);
+    __syncthreads();
+    if (j + 1 < nt) { tile_gload(kr, kb_, p.ld_k, (j + 1) * 64, n); tile_gload(vr, vb, p.ld_v, (j + 1) * 64, n); }
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        s = MFMA(lds_rowfrag(Ks, kb * 32, ks), qf[ks], s);         // S^T[key][q]
+        dp = MFMA(lds_rowfrag(Vs, kb * 32, ks), dof[ks], dp);      // dP^T[key][q]
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float th = fast_tanh(s[r] * icap);
+        const float pr = key < kve ? __expf(cap * th - lse) : 0.f;
+        s[r] = pr * (dp[r] - dlt) * (1.f - th * th);               // dS_raw^T
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const bf16x8 dsf = pack8(s, tt);
+        const int ra = kb * 32 + 16 * tt + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 2; db++) dq[db] = MFMA(lds_tr8(Ks, LDT, ra, ra + 8, db * 32), dsf, dq[db]);   // dQ^T[d][q]
+      }
+    }
+  }
+  if (qrow < n) {
+    bf16* op = p.dq + (tok0 + qrow) * p.ld_dq + h * DH;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = f2bf(dq[db][rg * 4 + e]);
+        *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dK/dV: block = 128 keys (4 waves x 32), loop over 64-query tiles that can see them
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(tfx_attn_args p) {
+  __shared__ __attribute__((aligned(16))) bf16 Qs[64 * LDT];
+  __shared__ __attribute__((aligned(16))) bf16 Ds[64 * LDT];
+  __shared__ __attribute__((aligned(16))) float s_lse[64], s_dlt[64];
+  __shared__ __attribute__((aligned(16))) int s_kve[64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
+  const int n = p.n, h = blockIdx.y, b = blockIdx.z;
+  const int k0 = blockIdx.x * 128;
+  const size_t tok0 = (size_t)b * n;
+  const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
+  const bf16* kb_ = p.k + tok0 * p.ld_k + h * DH;
+  const bf16* vb = p.v + tok0 * p.ld_v + h * DH;
+  const bf16* dob = p.do_eff + tok0 * p.ld_do + h * DH;
+  const float* lseb = p.lse + ((size_t)b * p.h + h) * n;
+  const float* dltb = p.delta + ((size_t)b * p.h + h) * n;
+  const int krow = k0 + w * 32 + (l & 31);                 // this lane's key
+  const int qt0 = p.q_start[tok0 + min(k0, n - 1)] / 64;   // q_start is non-decreasing in the key index
+  const int qt1 = (n + 63) / 64;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) { kf[ks] = g_rowfrag(kb_, p.ld_k, krow, n, ks); vf[ks] = g_rowfrag(vb, p.ld_v, krow, n, ks); }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+  const float cap = p.softcap, icap = 1.f / p.softcap;
+
+  TileRegs qr, dr;
+  tile_gload(qr, qb, p.ld_q, qt0 * 64, n);
+  tile_gload(dr, dob, p.ld_do, qt0 * 64, n);
+  for (int jt = qt0; jt < qt1; jt++) {
+    __syncthreads();
+    tile_sstore(qr, Qs); tile_sstore(dr, Ds);
+    if (threadIdx.x < 64) {
+      const int qi = jt * 64 + threadIdx.x;
+      const int qcl = min(qi, n - 1);
+      s_lse[threadIdx.x] = lseb[qcl];
+      s_dlt[threadIdx.x] = dltb[qcl];
+      s_kve[threadIdx.x] = qi < n ? p.kv_end[tok0 + qcl] : 0;       // rows past the end see nothing
+    }
+    __syncthreads();
+    if (jt + 1 < qt1) { tile_gload(qr, qb, p.ld_q, (jt + 1) * 64, n); tile_gload(dr, dob, p.ld_do, (jt + 1) * 64, n); }
+#pragma unroll
+    for (int qb2 = 0; qb2 < 2; qb2++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        s = MFMA(lds_rowfrag(Qs, qb2 * 32, ks), kf[ks], s);       // S[q][key]
+        dp = MFMA(lds_rowfrag(Ds, qb2 * 32, ks), vf[ks], dp);     // dP[q][key]
+      }
+      f32x16 pr;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int ql = qb2 * 32 + 8 * rg + 4 * hi;
+        const f32x4 ls4 = *(const f32x4*)(s_lse + ql), dl4 = *(const f32x4*)(s_dlt + ql);
+        const int* kv4 = s_kve + ql;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = rg * 4 + e;
+          const float th = fast_tanh(s[r] * icap);
+          const float pv = krow < kv4[e] ? __expf(cap * th - ls4[e]) : 0.f;
+          pr[r] = pv;
+          s[r] = pv * (dp[r] - dl4[e]) * (1.f - th * th);          // dS_raw[q][key]
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const bf16x8 pf = pack8(pr, tt), dsf = pack8(s, tt);
+        const int ra = qb2 * 32 + 16 * tt + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 2; db++) {
+          dv[db] = MFMA(lds_tr8(Ds, LDT, ra, ra + 8, db * 32), pf, dv[db]);    // dV^T[d][key]
+          dk[db] = MFMA(lds_tr8(Qs, LDT, ra, ra + 8, db * 32), dsf, dk[db]);   // dK^T[d][key]
+        }
+      }
+    }
+  }
+  if (krow < n) {
+    bf16* okp = p.dk + (tok0 + krow) * p.ld_dk + h * DH;
+    bf16* ovp = p.dv + (tok0 + krow) * p.ld_dv + h * DH;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a[e] = f2bf(dk[db][rg * 4 + e]); c[e] = f2bf(dv[db][rg * 4 + e]); }
+        *(bf16x4*)(okp + db * 32 + 8 * rg + 4 * hi) = a;
+        *(bf16x4*)(ovp + db * 32 + 8 * rg + 4 * hi) = c;
+      }
+  }
+}
+
+int attn_fwd(const tfx_attn_args& p, hipStream_t s) {
+  if (p.n <= 0 || p.b <= 0 || p.h <= 0) return -1;
+  if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out) & 7) return -2;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
+  if (p.n <= 0 || p.b <= 0 || p.h <= 0) return -1;
+  if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out | p.ld_dout | p.ld_do | p.ld_dq | p.ld_dk | p.ld_dv) & 7) return -2;
+  long long nthreads = (long long)p.b * p.n * p.h * 8;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace tfx

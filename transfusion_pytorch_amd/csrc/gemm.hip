@@ -1,0 +1,362 @@
+// bf16 MFMA GEMMs for gfx950 (CDNA4), fp32 accumulate.
+//
+//   gemm_nt : C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous; forward + dX GEMMs)
+//   gemm_tn : C[N,K] += A[M,N]^T . B[M,K]  (contraction over rows; weight-gradient GEMMs, split-M + fp32 atomics)
+//
+// Tile 128x128, 256 threads = 4 waves (2x2), wave tile 64x64 = 2x2 v_mfma_f32_32x32x16_bf16.
+// Operands are computed SWAPPED (D' = B.A^T) so that a lane owns one output row and 4-element runs of
+// consecutive columns: the epilogue stores 8-byte bf16x4 / 16-byte f32x4 vectors and per-row side data
+// (row scatter map) is one lookup per lane.
+#include "tfx_common.h"
+#include "tfx_kernels.h"
+
+namespace tfx {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+// ------------------------------------------------------------------------------------------------
+// epilogues.  `v` = 4 consecutive columns n..n+3 of output row m (already bounds-checked for m).
+// ------------------------------------------------------------------------------------------------
+template <int EPI> struct Epilogue;
+
+TFX_DEV void store_bf16x4(bf16* dst, f32x4 v) {
+  bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+  *(bf16x4*)dst = o;
+}
+
+TFX_DEV f32x4 add_bias(const GemmNT& p, int n, f32x4 v) {
+  if (p.bias) { f32x4 b = *(const f32x4*)(p.bias + n); v += b; }
+  return v;
+}
+
+template <> struct Epilogue<EPI_BF16> {      // C(bf16) = acc + bias
+  static TFX_DEV void apply(const GemmNT& p, int m, int mo, int n, f32x4 v) {
+    v = add_bias(p, n, v);
+    bf16* c = (bf16*)p.C + (size_t)mo * p.ldc + n;
+    if (n + 3 < p.N) store_bf16x4(c, v);
+    else for (int e = 0; e < 4; e++) if (n + e < p.N) c[e] = f2bf(v[e]);
+  }
+};
+template <> struct Epilogue<EPI_F32> {       // C(fp32) = acc + bias
+  static TFX_DEV void apply(const GemmNT& p, int m, int mo, int n, f32x4 v) {
+    v = add_bias(p, n, v);
+    float* c = (float*)p.C + (size_t)mo * p.ldc + n;
+    if (n + 3 < p.N) *(f32x4*)c = v;
+    else for (int e = 0; e < 4; e++) if (n + e < p.N) c[e] = v[e];
+  }
+};
+template <> struct Epilogue<EPI_SILU> {      // C2(bf16) = pre = acc + bias ; C(bf16) = silu(pre)
+  static TFX_DEV void apply(const GemmNT& p, int m, int mo, int n, f32x4 v) {
+    v = add_bias(p, n, v);
+    f32x4 s; for (int e = 0; e < 4; e++) s[e] = v[e] * sigmoidf_(v[e]);
+    bf16* c = (bf16*)p.C + (size_t)mo * p.ldc + n;
+    bf16* c2 = (bf16*)p.C2 + (size_t)mo * p.ldc2 + n;
+    if (n + 3 < p.N) { store_bf16x4(c, s); store_bf16x4(c2, v); }
+    else for (int e = 0; e < 4; e++) if (n + e < p.N) { c[e] = f2bf(s[e]); c2[e] = f2bf(v[e]); }
+  }
+};
+template <> struct Epilogue<EPI_RESID> {     // C(bf16) = acc + bias + R
+  static TFX_DEV void apply(const GemmNT& p, int m, int mo, int n, f32x4 v) {
+    v = add_bias(p, n, v);
+    const bf16* r = p.R + (size_t)(p.resid_mapped ? mo : m) * p.ldr + n;
+    bf16* c = (bf16*)p.C + (size_t)mo * p.ldc + n;
+    if (n + 3 < p.N) {
+      bf16x4 rv = *(const bf16x4*)r;
+      for (int e = 0; e < 4; e++) v[e] += bf2f(rv[e]);
+      store_bf16x4(c, v);
+    } else for (int e = 0; e < 4; e++) if (n + e < p.N) c[e] = f2bf(v[e] + bf2f(r[e]));
+  }
+};
+
+// GEGLU pair epilogues work on the wave's two 32-column halves (value half / gate half of one 64-column
+// interleave block, see tfx_kernels.h "GEGLU layout").
+struct GegluFwd {   // C(bf16, ld 2*dip) = [a|g] pre-activation (+bias) ; C2(bf16, ld dip) = a * gelu(g)
+  static TFX_DEV void apply(const GemmNT& p, int m, int n_a, f32x4 a, f32x4 g) {
+    // n_a = physical column of the value half inside the interleaved layout (multiple of 4, (n_a % 64) < 32)
+    if (p.bias) { a += *(const f32x4*)(p.bias + n_a); g += *(const f32x4*)(p.bias + n_a + 32); }
+    bf16* c = (bf16*)p.C + (size_t)m * p.ldc + n_a;
+    store_bf16x4(c, a); store_bf16x4(c + 32, g);
+    f32x4 h; for (int e = 0; e < 4; e++) h[e] = a[e] * gelu_erf(g[e]);
+    int feat = (n_a >> 6) * 32 + (n_a & 31);
+    store_bf16x4((bf16*)p.C2 + (size_t)m * p.ldc2 + feat, h);
+  }
+};
+
+// dh -> d[a|g]:  acc = dh[m][feat..feat+3];  aux = saved [a|g] pre-activation (ld 2*dip)
+template <> struct Epilogue<EPI_GEGLU_BWD> {
+  static TFX_DEV void apply(const GemmNT& p, int m, int mo, int n, f32x4 dh) {
+    if (n >= p.N) return;                       // N (= dip) is a multiple of 64
+    int col = (n >> 5) * 64 + (n & 31);
+    const bf16* ag = p.aux + (size_t)m * p.ldaux + col;
+    bf16x4 a4 = *(const bf16x4*)ag, g4 = *(const bf16x4*)(ag + 32);
+    f32x4 da, dg;
+    for (int e = 0; e < 4; e++) {
+      float a = bf2f(a4[e]), g = bf2f(g4[e]);
+      da[e] = dh[e] * gelu_erf(g);
+      dg[e] = dh[e] * a * gelu_erf_grad(g);
+    }
+    bf16* c = (bf16*)p.C + (size_t)mo * p.ldc + col;
+    store_bf16x4(c, da); store_bf16x4(c + 32, dg);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* As = (bf16*)smem_raw;                 // [2][128*64]
+  bf16* Bs = As + 2 * BM * BK;                // [2][128*64]
+
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1, hi = l >> 5;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int nk = p.K / BK;
+
+  // per-thread staging coordinates: 4 x 16-byte chunks of A and of B per k-tile
+  int srow[4], skc[4];
+  const bf16 *ga[4], *ga2[4], *gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int c = t + 256 * i;
+    srow[i] = c >> 3; skc[i] = c & 7;
+    int rm = min(m0 + srow[i], p.M - 1);
+    if (p.a_rowmap) rm = p.a_rowmap[rm];
+    int rn = min(n0 + srow[i], p.N - 1);
+    ga[i] = p.A + (size_t)rm * p.lda + skc[i] * 8;
+    ga2[i] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + skc[i] * 8 : nullptr;
+    gb[i] = p.B + (size_t)rn * p.ldb + skc[i] * 8;
+  }
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bf16* src = (p.A2 && k0 >= p.K1) ? ga2[i] + (k0 - p.K1) : ga[i] + k0;
+      ra[i] = *(const u32x4*)src;
+      rb[i] = *(const u32x4*)(gb[i] + k0);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int off = srow[i] * BK + ((skc[i] ^ (srow[i] & 7)) << 3);
+      *(u32x4*)(As + buf * BM * BK + off) = ra[i];
+      *(u32x4*)(Bs + buf * BN * BK + off) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  const int arow0 = wm * 64 + (l & 31), brow0 = wn * 64 + (l & 31);
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const bf16* as = As + cur * BM * BK;
+    const bf16* bs = Bs + cur * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        int ar = arow0 + i * 32, br = brow0 + i * 32;
+        af[i] = *(const bf16x8*)(as + ar * BK + (((ks * 2 + hi) ^ (ar & 7)) << 3));
+        bfr[i] = *(const bf16x8*)(bs + br * BK + (((ks * 2 + hi) ^ (br & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D'[n][m]
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane owns row m (= column of D'), register group g owns columns n..n+3
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int m = m0 + wm * 64 + i * 32 + (l & 31);
+    if (m >= p.M) continue;
+    const int mo = p.rowmap ? p.rowmap[m] : m;
+    if (mo < 0) continue;
+    if constexpr (EPI == EPI_GEGLU) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int n_a = n0 + wn * 64 + 8 * g + 4 * hi;
+        if (n_a >= p.N) continue;
+        f32x4 a, gt;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e]; gt[e] = acc[i][1][4 * g + e]; }
+        GegluFwd::apply(p, mo, n_a, a, gt);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e];
+          Epilogue<EPI>::apply(p, m, mo, n, v);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn: C[rowmap[n]][k] += sum_m A[m][n] * B[m][k]
+// ------------------------------------------------------------------------------------------------
+constexpr int TN_BMK = 64;      // contraction rows per LDS tile
+constexpr int TN_LD = 160;      // padded LDS row stride (elements): conflict-free ds_read_b64_tr_b16
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* As = (bf16*)smem_raw;                         // [2][64*160]
+  bf16* Bs = As + 2 * TN_BMK * TN_LD;                 // [2][64*160]
+
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wn = w >> 1, wk = w & 1, hi = l >> 5;
+  const int ntn = (p.N + 127) / 128, ntk = (p.K + 127) / 128;
+  int bid = blockIdx.x;
+  const int split = bid / (ntn * ntk); bid -= split * ntn * ntk;
+  const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
+  const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
+  const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
+  if (mbeg >= mend) return;
+  const int nsteps = (mend - mbeg + TN_BMK - 1) / TN_BMK;
+
+  int srow[4], sch[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { int c = t + 256 * i; srow[i] = c >> 4; sch[i] = c & 15; }
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int st) {
+    int mrow0 = mbeg + st * TN_BMK;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int m = mrow0 + srow[i];
+      int ca = n0 + sch[i] * 8, cb = k0 + sch[i] * 8;
+      u32x4 z = {0, 0, 0, 0};
+      ra[i] = (m < mend && ca < p.a_cols) ? *(const u32x4*)(p.A + (size_t)m * p.lda + ca) : z;
+      rb[i] = (m < mend && cb < p.b_cols) ? *(const u32x4*)(p.B + (size_t)m * p.ldb + cb) : z;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int off = srow[i] * TN_LD + sch[i] * 8;
+      *(u32x4*)(As + buf * TN_BMK * TN_LD + off) = ra[i];
+      *(u32x4*)(Bs + buf * TN_BMK * TN_LD + off) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; st++) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) gload(st + 1);
+    const bf16* as = As + cur * TN_BMK * TN_LD;
+    const bf16* bs = Bs + cur * TN_BMK * TN_LD;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const int r0 = ks * 16 + 8 * hi;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        af[i] = lds_tr8(as, TN_LD, r0, r0 + 4, wn * 64 + i * 32);
+        bfr[i] = lds_tr8(bs, TN_LD, r0, r0 + 4, wk * 64 + i * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);   // D[n][k]
+    }
+    if (st + 1 < nsteps) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D layout: col = lane&31 -> k, row(reg) -> n.  fp32 atomics: 32 consecutive k per half-wave.
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (n >= p.N) continue;
+      const int no = p.rowmap ? p.rowmap[n] : n;
+      if (no < 0) continue;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int k = k0 + wk * 64 + j * 32 + (l & 31);
+        if (k < p.k_valid) {
+          float v = acc[i][j][r] * p.alpha;
+          if (p.splits == 1 && !p.accumulate) p.C[(size_t)no * p.ldc + k] = v;
+          else atomicAdd(p.C + (size_t)no * p.ldc + k, v);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
+  const int smem = 2 * (BM * BK + BN * BK) * 2;
+  int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
+  return (int)hipGetLastError();
+}
+
+int gemm_nt(const GemmNT& p, hipStream_t s) {
+  if (p.K % BK != 0 || (p.A2 && p.K1 % BK != 0) || p.M <= 0 || p.N <= 0) return -1;
+  if ((p.lda | p.ldb) & 7) return -2;
+  switch (p.epi) {
+    case EPI_BF16: return launch_nt<EPI_BF16>(p, s);
+    case EPI_F32: return launch_nt<EPI_F32>(p, s);
+    case EPI_SILU: return launch_nt<EPI_SILU>(p, s);
+    case EPI_RESID: return launch_nt<EPI_RESID>(p, s);
+    case EPI_GEGLU: return (p.N % 64) ? -3 : launch_nt<EPI_GEGLU>(p, s);
+    case EPI_GEGLU_BWD: return (p.N % 64) ? -3 : launch_nt<EPI_GEGLU_BWD>(p, s);
+  }
+  return -4;
+}
+
+int gemm_tn(const GemmTN& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 1) return -1;
+  if ((p.lda | p.ldb | p.a_cols | p.b_cols) & 7) return -2;
+  static bool attr_set = false;
+  const int smem = 2 * 2 * TN_BMK * TN_LD * 2;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  int grid = ((p.N + 127) / 128) * ((p.K + 127) / 128) * p.splits;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), smem, s, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace tfx

@@ -1,0 +1,68 @@
+// Common device helpers for the Transfusion MI355X (gfx950 / CDNA4) kernels.
+// wave = 64 lanes; MFMA fragment layouts verified on hardware by tools/probe_layouts.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define TFX_DEV __device__ __forceinline__
+
+TFX_DEV float bf2f(bf16 v) { return (float)v; }
+TFX_DEV bf16 f2bf(float v) { return (bf16)v; }   // round-to-nearest-even
+
+TFX_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+TFX_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware, bijective block remap (cdna_hip_programming.md T1): each of the 8 XCDs (private L2)
+// gets a contiguous chunk of tile ids so neighbouring tiles share operand panels in L2.
+TFX_DEV int xcd_remap(int bid, int nblk) {
+  const int nx = 8;
+  int q = nblk / nx, r = nblk % nx;
+  int xcd = bid % nx, idx = bid / nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// LDS transpose read (gfx950 ds_read_b64_tr_b16).  Within each 16-lane group, lane q' supplies the
+// address of 4 contiguous bf16 (row q'/4, 4-element chunk q'%4 of a [4][16] block); lane q receives
+// column q of that block (rows 0..3).  Verified by tools/probe_layouts.hip.
+TFX_DEV s16x4 lds_tr4(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+
+// 8-element MFMA operand (for lane l: fixed column c0 + (l&31), 8 contraction rows) gathered from a
+// row-major [row][col] LDS tile with `stride` elements per row.  rowA / rowB give this lane-half's first
+// row of the first / second group of 4 contraction rows.
+TFX_DEV bf16x8 lds_tr8(const bf16* tile, int stride, int rowA, int rowB, int c0) {
+  const int l = threadIdx.x & 63;
+  const int q = l & 15;
+  const int col = c0 + 16 * ((l >> 4) & 1) + 4 * (q & 3);
+  s16x4 lo = lds_tr4(tile + (rowA + (q >> 2)) * stride + col);
+  s16x4 hi = lds_tr4(tile + (rowB + (q >> 2)) * stride + col);
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+TFX_DEV float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+TFX_DEV float gelu_erf_grad(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+TFX_DEV float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }

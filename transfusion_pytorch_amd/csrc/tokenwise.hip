@@ -1,0 +1,791 @@
+// Token-wise (HBM-bound) kernels: one 64-lane wave per token row, 16-byte bf16x8 accesses, wavefront
+// shuffle reductions.  A lane owns chunks c = lane + 64*i (8 contiguous elements each), i < NC.
+#include "tfx_kernels.h"
+
+namespace tfx {
+
+constexpr int WAVES = 4;          // waves per block
+constexpr int MAXB = 1024;        // grid cap for kernels that end in parameter-gradient atomics
+
+template <int NC> struct Row {
+  float v[NC][8];
+};
+
+template <int NC> TFX_DEV void load_row(Row<NC>& r, const bf16* p, int d, int lane) {
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < d) {
+      bf16x8 x = *(const bf16x8*)(p + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; e++) r.v[i][e] = bf2f(x[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) r.v[i][e] = 0.f;
+    }
+  }
+}
+template <int NC> TFX_DEV void store_row(const Row<NC>& r, bf16* p, int d, int lane) {
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < d) {
+      bf16x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = f2bf(r.v[i][e]);
+      *(bf16x8*)(p + c * 8) = x;
+    }
+  }
+}
+template <int NC> TFX_DEV void load_vec(Row<NC>& r, const float* p, int d, int lane) {
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < d) {
+      f32x4 a = *(const f32x4*)(p + c * 8), b = *(const f32x4*)(p + c * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { r.v[i][e] = a[e]; r.v[i][4 + e] = b[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) r.v[i][e] = 0.f;
+    }
+  }
+}
+// block-level reduction of per-lane column partials over the block's waves, then global atomics
+template <int NC> TFX_DEV void flush_col_partials(const Row<NC>& part, float* out, int d, float* smem /* [WAVES][NC*512] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) smem[w * NC * 512 + (lane + 64 * i) * 8 + e] = part.v[i][e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WAVES; ww++) s += smem[ww * NC * 512 + c];
+    if (s != 0.f) atomicAdd(out + c, s);
+  }
+  __syncthreads();
+}
+
+#define DISPATCH_NC(d, CALL)                     \
+  do {                                           \
+    if ((d) % 8 != 0 || (d) > 2048) return -1;   \
+    if ((d) <= 512) { constexpr int NC = 1; CALL; } \
+    else if ((d) <= 1024) { constexpr int NC = 2; CALL; } \
+    else { constexpr int NC = 4; CALL; }         \
+  } while (0)
+
+static inline int grid_tokens(int T) { return (T + WAVES - 1) / WAVES; }
+static inline int grid_capped(int T) { int g = grid_tokens(T); return g < MAXB ? g : MAXB; }
+
+// ------------------------------------------------------------------------------------------------
+// AdaptiveWrapper input side: non-affine LayerNorm + (text gamma | FiLM gamma,beta)        T:747-755
+// ------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void adaln_pre_fwd_k(tfx_adaln_pre_args p) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T) return;
+  const int d = p.d;
+  Row<NC> x; load_row(x, p.x + (size_t)t * d, d, lane);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) s += x.v[i][e];
+  const float mean = wave_sum(s) / d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < d)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { float dv = x.v[i][e] - mean; q += dv * dv; }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / d + 1e-5f);
+  if (lane == 0) { p.mean[t] = mean; p.rstd[t] = rstd; }
+  const int inst = p.tok_inst[t];
+  Row<NC> g, b;
+  if (inst < 0) load_vec(g, p.gamma_text, d, lane);
+  else { load_vec(g, p.table + (size_t)inst * p.ld_table, d, lane); load_vec(b, p.table + (size_t)inst * p.ld_table + d, d, lane); }
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float xh = (x.v[i][e] - mean) * rstd;
+      x.v[i][e] = xh * (1.f + g.v[i][e]) + (inst < 0 ? 0.f : b.v[i][e]);
+    }
+  store_row(x, p.u + (size_t)t * d, d, lane);
+}
+
+template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_k(tfx_adaln_pre_args p) {
+  __shared__ float smem[WAVES * NC * 512];
+  const int lane = threadIdx.x & 63;
+  const int d = p.d;
+  Row<NC> pg;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) pg.v[i][e] = 0.f;
+  for (int t = blockIdx.x * WAVES + (threadIdx.x >> 6); t < p.T; t += gridDim.x * WAVES) {
+    Row<NC> x, du, g;
+    load_row(x, p.x + (size_t)t * d, d, lane);
+    load_row(du, p.du + (size_t)t * d, d, lane);
+    const float mean = p.mean[t], rstd = p.rstd[t];
+    const int inst = p.tok_inst[t];
+    if (inst < 0) load_vec(g, p.gamma_text, d, lane);
+    else load_vec(g, p.table + (size_t)inst * p.ld_table, d, lane);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      int c = lane + 64 * i;
+      if (c * 8 >= d) continue;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float xh = (x.v[i][e] - mean) * rstd;
+        float dg = du.v[i][e] * xh;
+        if (inst < 0) pg.v[i][e] += dg;
+        else {
+          atomicAdd(p.dtable + (size_t)inst * p.ld_table + c * 8 + e, dg);
+          atomicAdd(p.dtable + (size_t)inst * p.ld_table + d + c * 8 + e, du.v[i][e]);
+        }
+        float dxh = du.v[i][e] * (1.f + g.v[i][e]);
+        c1 += dxh; c2 += dxh * xh;
+        x.v[i][e] = xh; du.v[i][e] = dxh;
+      }
+    }
+    c1 = wave_sum(c1) / d; c2 = wave_sum(c2) / d;
+    Row<NC> dx; load_row(dx, p.dx + (size_t)t * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) dx.v[i][e] += rstd * (du.v[i][e] - c1 - x.v[i][e] * c2);
+    store_row(dx, p.dx + (size_t)t * d, d, lane);
+  }
+  flush_col_partials<NC>(pg, p.dgamma_text, d, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdaptiveWrapper output side + residual: out = x + y * (text: layerscale+1 | modality: sigmoid(z))   T:763-769
+// ------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void adaln_post_fwd_k(tfx_adaln_post_args p) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T) return;
+  const int d = p.d;
+  Row<NC> x, y, s;
+  load_row(x, p.x + (size_t)t * d, d, lane);
+  load_row(y, p.y + (size_t)t * d, d, lane);
+  const int inst = p.tok_inst[t];
+  if (inst < 0) load_vec(s, p.layerscale, d, lane);
+  else load_vec(s, p.table + (size_t)inst * p.ld_table + 2 * d, d, lane);
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float sc = inst < 0 ? 1.f + s.v[i][e] : sigmoidf_(s.v[i][e]);
+      x.v[i][e] += y.v[i][e] * sc;
+    }
+  store_row(x, p.out + (size_t)t * d, d, lane);
+}
+
+template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_k(tfx_adaln_post_args p) {
+  __shared__ float smem[WAVES * NC * 512];
+  const int lane = threadIdx.x & 63;
+  const int d = p.d;
+  Row<NC> pl;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) pl.v[i][e] = 0.f;
+  for (int t = blockIdx.x * WAVES + (threadIdx.x >> 6); t < p.T; t += gridDim.x * WAVES) {
+    Row<NC> g, y, s;
+    load_row(g, p.g + (size_t)t * d, d, lane);
+    load_row(y, p.y + (size_t)t * d, d, lane);
+    const int inst = p.tok_inst[t];
+    if (inst < 0) load_vec(s, p.layerscale, d, lane);
+    else load_vec(s, p.table + (size_t)inst * p.ld_table + 2 * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      int c = lane + 64 * i;
+      if (c * 8 >= d) continue;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float gy = g.v[i][e] * y.v[i][e];
+        float sc;
+        if (inst < 0) { sc = 1.f + s.v[i][e]; pl.v[i][e] += gy; }
+        else { sc = sigmoidf_(s.v[i][e]); atomicAdd(p.dtable + (size_t)inst * p.ld_table + 2 * d + c * 8 + e, gy * sc * (1.f - sc)); }
+        g.v[i][e] *= sc;
+      }
+    }
+    store_row(g, p.dy + (size_t)t * d, d, lane);
+  }
+  flush_col_partials<NC>(pl, p.dlayerscale, d, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (final norm): y = x / max(|x|, 1e-12) * sqrt(d) * (gamma + 1)                T:779-786
+// ------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void rmsnorm_fwd_k(tfx_rmsnorm_args p) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T) return;
+  const int d = p.d;
+  Row<NC> x, g;
+  load_row(x, p.x + (size_t)t * d, d, lane);
+  load_vec(g, p.gamma, d, lane);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) q += x.v[i][e] * x.v[i][e];
+  const float r = sqrtf((float)d) / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) x.v[i][e] *= r * (1.f + g.v[i][e]);
+  store_row(x, p.y + (size_t)t * d, d, lane);
+}
+
+template <int NC> __global__ __launch_bounds__(256) void rmsnorm_bwd_k(tfx_rmsnorm_args p) {
+  __shared__ float smem[WAVES * NC * 512];
+  const int lane = threadIdx.x & 63;
+  const int d = p.d;
+  Row<NC> pg, g;
+  load_vec(g, p.gamma, d, lane);
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) pg.v[i][e] = 0.f;
+  for (int t = blockIdx.x * WAVES + (threadIdx.x >> 6); t < p.T; t += gridDim.x * WAVES) {
+    Row<NC> x, dy;
+    load_row(x, p.x + (size_t)t * d, d, lane);
+    load_row(dy, p.dy + (size_t)t * d, d, lane);
+    float q = 0.f, S = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { q += x.v[i][e] * x.v[i][e]; S += (1.f + g.v[i][e]) * dy.v[i][e] * x.v[i][e]; }
+    q = wave_sum(q); S = wave_sum(S);
+    const float r = sqrtf((float)d) / fmaxf(sqrtf(q), 1e-12f);
+    const float k2 = r * r * r / d * S;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        pg.v[i][e] += dy.v[i][e] * x.v[i][e] * r;
+        x.v[i][e] = r * (1.f + g.v[i][e]) * dy.v[i][e] - x.v[i][e] * k2;
+      }
+    store_row(x, p.dx + (size_t)t * d, d, lane);
+  }
+  flush_col_partials<NC>(pg, p.dgamma, d, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// AttentionResidual: out = sum_l softmax_l(<h_l, w> / |h_l|) h_l,  w = (gamma+1) * pseudo_query   T:807-829
+// ------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void attnres_fwd_k(tfx_attnres_args p) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T) return;
+  const int d = p.d;
+  Row<NC> w, pq, o;
+  load_vec(w, p.gamma, d, lane); load_vec(pq, p.pq, d, lane);
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { w.v[i][e] = (1.f + w.v[i][e]) * pq.v[i][e]; o.v[i][e] = 0.f; }
+  float m = -INFINITY, den = 0.f;
+  for (int l = 0; l < p.L; l++) {
+    Row<NC> h; load_row(h, p.hiddens + (size_t)l * p.stride_h + (size_t)t * d, d, lane);
+    float nsq = 0.f, dt = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { nsq += h.v[i][e] * h.v[i][e]; dt += h.v[i][e] * w.v[i][e]; }
+    nsq = wave_sum(nsq); dt = wave_sum(dt);
+    const float s = dt / fmaxf(sqrtf(nsq), 1e-12f);
+    const float mn = fmaxf(m, s);
+    const float al = __expf(m - mn), ex = __expf(s - mn);
+    den = den * al + ex; m = mn;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) o.v[i][e] = o.v[i][e] * al + ex * h.v[i][e];
+  }
+  const float inv = 1.f / den;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) o.v[i][e] *= inv;
+  store_row(o, p.out + (size_t)t * d, d, lane);
+}
+
+template <int NC> __global__ __launch_bounds__(256) void attnres_bwd_k(tfx_attnres_args p) {
+  __shared__ float smem[WAVES * NC * 512];
+  const int lane = threadIdx.x & 63;
+  const int d = p.d;
+  Row<NC> w, pw;     // w = (1+gamma)*pq ; pw = per-lane partial of d(w)
+  {
+    Row<NC> pq; load_vec(w, p.gamma, d, lane); load_vec(pq, p.pq, d, lane);
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { w.v[i][e] = (1.f + w.v[i][e]) * pq.v[i][e]; pw.v[i][e] = 0.f; }
+  }
+  for (int t = blockIdx.x * WAVES + (threadIdx.x >> 6); t < p.T; t += gridDim.x * WAVES) {
+    Row<NC> g; load_row(g, p.g + (size_t)t * d, d, lane);
+    if (p.g2) {
+      Row<NC> g2; load_row(g2, p.g2 + (size_t)t * d, d, lane);
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) g.v[i][e] += g2.v[i][e];
+    }
+    // pass 1: lane l keeps (score, inverse norm, <g,h_l>) of hidden l   (L <= 64)
+    float s_l = -INFINITY, inv_l = 0.f, da_l = 0.f;
+    for (int l = 0; l < p.L; l++) {
+      Row<NC> h; load_row(h, p.hiddens + (size_t)l * p.stride_h + (size_t)t * d, d, lane);
+      float nsq = 0.f, dt = 0.f, da = 0.f;
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { nsq += h.v[i][e] * h.v[i][e]; dt += h.v[i][e] * w.v[i][e]; da += h.v[i][e] * g.v[i][e]; }
+      nsq = wave_sum(nsq); dt = wave_sum(dt); da = wave_sum(da);
+      const float inv = 1.f / fmaxf(sqrtf(nsq), 1e-12f);
+      if (lane == l) { s_l = dt * inv; inv_l = inv; da_l = da; }
+    }
+    const float mx = wave_max(s_l);
+    const float ex = (lane < p.L) ? __expf(s_l - mx) : 0.f;
+    const float a_l = ex / wave_sum(ex);
+    const float dsum = wave_sum(a_l * da_l);
+    const float ds_l = a_l * (da_l - dsum);
+    // pass 2
+    for (int l = 0; l < p.L; l++) {
+      const float a = __shfl(a_l, l, 64), ds = __shfl(ds_l, l, 64), inv = __shfl(inv_l, l, 64), s = __shfl(s_l, l, 64);
+      const bf16* hp = p.hiddens + (size_t)l * p.stride_h + (size_t)t * d;
+      bf16* dp = p.dhiddens + (size_t)l * p.stride_dh + (size_t)t * d;
+      Row<NC> h, dh; load_row(h, hp, d, lane);
+      if (!p.first) load_row(dh, dp, d, lane);
+      const float k1 = ds * inv, k2 = ds * s * inv * inv;
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float v = a * g.v[i][e] + k1 * w.v[i][e] - k2 * h.v[i][e];
+          dh.v[i][e] = p.first ? v : dh.v[i][e] + v;
+          pw.v[i][e] += k1 * h.v[i][e];
+        }
+      store_row(dh, dp, d, lane);
+    }
+  }
+  // d gamma = dw * pq ; d pq = dw * (1 + gamma)
+  Row<NC> gm, pq, tmp; load_vec(gm, p.gamma, d, lane); load_vec(pq, p.pq, d, lane);
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) tmp.v[i][e] = pw.v[i][e] * pq.v[i][e];
+  flush_col_partials<NC>(tmp, p.dgamma, d, smem);
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) tmp.v[i][e] = pw.v[i][e] * (1.f + gm.v[i][e]);
+  flush_col_partials<NC>(tmp, p.dpq, d, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// text embedding gather / scatter-add                                                 T:3173-3184
+// ------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void embed_fwd_k(tfx_embed_args p) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T || p.tok_inst[t] >= 0) return;
+  const int id = max(p.text_ids[t], 0);
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < p.d) *(bf16x8*)(p.x + (size_t)t * p.d + c * 8) = *(const bf16x8*)(p.table + (size_t)id * p.d + c * 8);
+  }
+}
+template <int NC> __global__ __launch_bounds__(256) void embed_bwd_k(tfx_embed_args p) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T || p.tok_inst[t] >= 0) return;
+  const int id = max(p.text_ids[t], 0);
+  Row<NC> g; load_row(g, p.dx + (size_t)t * p.d, p.d, lane);
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < p.d)
+#pragma unroll
+      for (int e = 0; e < 8; e++) atomicAdd(p.dtable + (size_t)id * p.d + c * 8 + e, g.v[i][e]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// qk RMSNorm + RoPE (+ q scale)                                       T:950-952, T:965, T:998
+// 8 threads per 64-wide head vector, 8 contiguous elements (4 rotary pairs) per thread
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args p) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vid = gid >> 3;
+  const int sub = gid & 7;
+  const long long nvec = (long long)p.T * 2 * p.H;
+  if (vid >= nvec) return;
+  const int t = (int)(vid / (2 * p.H)), rem = (int)(vid % (2 * p.H));
+  const int which = rem / p.H;
+  const int col = rem * 64 + sub * 8;          // which*H*64 + h*64 + sub*8
+  bf16x8 x = *(const bf16x8*)(p.qkv + (size_t)t * p.ld_qkv + col);
+  float v[8], q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
+  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+  const float r = 8.f / fmaxf(sqrtf(q), 1e-12f) * (which == 0 ? p.q_scale : 1.f);
+  const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
+  const int pos = p.rot_pos[t];
+  const f32x4 cs = *(const f32x4*)(p.cos_tab + (size_t)pos * 32 + sub * 4);
+  const f32x4 sn = *(const f32x4*)(p.sin_tab + (size_t)pos * 32 + sub * 4);
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float a = v[2 * i] * r * (1.f + gm[2 * i]), b = v[2 * i + 1] * r * (1.f + gm[2 * i + 1]);
+    o[2 * i] = f2bf(a * cs[i] - b * sn[i]);
+    o[2 * i + 1] = f2bf(b * cs[i] + a * sn[i]);
+  }
+  *(bf16x8*)(p.qk + (size_t)t * p.ld_qk + col) = o;
+}
+
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args p) {
+  __shared__ float sg[2][64];
+  if (threadIdx.x < 128) sg[threadIdx.x >> 6][threadIdx.x & 63] = 0.f;
+  __syncthreads();
+  const long long nvec = (long long)p.T * 2 * p.H;
+  const int sub = threadIdx.x & 7;      // constant per thread (grid stride is a multiple of 8 threads)
+  float pq[8], pk[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { pq[e] = 0.f; pk[e] = 0.f; }
+  for (long long vid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; vid < nvec; vid += ((long long)gridDim.x * blockDim.x) >> 3) {
+    const int t = (int)(vid / (2 * p.H)), rem = (int)(vid % (2 * p.H));
+    const int which = rem / p.H;
+    const int col = rem * 64 + sub * 8;
+    bf16x8 x = *(const bf16x8*)(p.qkv + (size_t)t * p.ld_qkv + col);
+    bf16x8 dy8 = *(const bf16x8*)(p.dqk + (size_t)t * p.ld_dqk + col);
+    float v[8], q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+    const float nrm = fmaxf(sqrtf(q), 1e-12f);
+    const float sc = (which == 0 ? p.q_scale : 1.f) * 8.f;
+    const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
+    const int pos = p.rot_pos[t];
+    const f32x4 cs = *(const f32x4*)(p.cos_tab + (size_t)pos * 32 + sub * 4);
+    const f32x4 sn = *(const f32x4*)(p.sin_tab + (size_t)pos * 32 + sub * 4);
+    float dyn[8], S = 0.f;      // dyn = grad wrt (v/nrm), i.e. includes c = sc*(1+gamma)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float da = bf2f(dy8[2 * i]), db = bf2f(dy8[2 * i + 1]);
+      float ga = da * cs[i] + db * sn[i];          // inverse rotation
+      float gb = db * cs[i] - da * sn[i];
+      float ca = sc * (1.f + gm[2 * i]), cb = sc * (1.f + gm[2 * i + 1]);
+      float dga = ga * v[2 * i] / nrm * sc, dgb = gb * v[2 * i + 1] / nrm * sc;
+      pq[2 * i] += which == 0 ? dga : 0.f; pq[2 * i + 1] += which == 0 ? dgb : 0.f;
+      pk[2 * i] += which == 0 ? 0.f : dga; pk[2 * i + 1] += which == 0 ? 0.f : dgb;
+      dyn[2 * i] = ga * ca; dyn[2 * i + 1] = gb * cb;
+      S += dyn[2 * i] * v[2 * i] + dyn[2 * i + 1] * v[2 * i + 1];
+    }
+    S += __shfl_xor(S, 1, 64); S += __shfl_xor(S, 2, 64); S += __shfl_xor(S, 4, 64);
+    const float k = S / (nrm * nrm * nrm);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(dyn[e] / nrm - v[e] * k);
+    *(bf16x8*)(p.dqkv + (size_t)t * p.ld_dqkv + col) = o;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) { atomicAdd(&sg[0][sub * 8 + e], pq[e]); atomicAdd(&sg[1][sub * 8 + e], pk[e]); }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float s = sg[threadIdx.x >> 6][threadIdx.x & 63];
+    if (s != 0.f) atomicAdd((threadIdx.x < 64 ? p.dgamma_q : p.dgamma_k) + (threadIdx.x & 63), s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise / reduction kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void noise_mix_k(tfx_noise_mix_args p) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)p.R * p.ld_xt;
+  if (i >= n) return;
+  const int r = (int)(i / p.ld_xt), c = (int)(i % p.ld_xt);
+  if (c >= p.dl) { p.xt[i] = f2bf(0.f); return; }
+  const float x = p.x[(size_t)r * p.dl + c];
+  if (!p.eps) { p.xt[i] = f2bf(x); return; }
+  const float e = p.eps[(size_t)r * p.dl + c];
+  const float t = p.inst_time[p.row_inst[r]];
+  p.xt[i] = f2bf(x * t + e * (1.f - t));
+  if (p.flow) p.flow[(size_t)r * p.dl + c] = x - e;
+}
+
+__global__ void fourier_k(tfx_fourier_args p) {
+  const int i = blockIdx.x, c = threadIdx.x;
+  const float t = p.times[i];
+  for (int col = c; col < p.ld; col += blockDim.x) {
+    float v = 0.f;
+    if (col == 0) v = t;
+    else if (col <= p.half) v = sinf(t * p.w[col - 1] * 6.283185307179586f);
+    else if (col <= 2 * p.half) v = cosf(t * p.w[col - 1 - p.half] * 6.283185307179586f);
+    p.out[(size_t)i * p.ld + col] = f2bf(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_k(tfx_ce_args p) {
+  __shared__ float sacc[2][WAVES];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = blockIdx.x * WAVES + w;
+  float loss = 0.f, cnt = 0.f;
+  if (t < p.T) {
+    const int lab = p.labels[t];
+    const float* lg = p.logits + (size_t)t * p.ld;
+    bf16* dl = p.dlogits + (size_t)t * p.ld_d;
+    if (lab < 0) {
+      for (int c = lane; c < p.ld_d; c += 64) dl[c] = f2bf(0.f);
+    } else {
+      float mx = -INFINITY;
+      for (int c = lane; c < p.V; c += 64) mx = fmaxf(mx, lg[c]);
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int c = lane; c < p.V; c += 64) se += __expf(lg[c] - mx);
+      se = wave_sum(se);
+      const float lse = mx + __logf(se);
+      for (int c = lane; c < p.ld_d; c += 64) {
+        float g = 0.f;
+        if (c < p.V) g = (__expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * p.grad_scale;
+        dl[c] = f2bf(g);
+      }
+      loss = lse - lg[lab]; cnt = 1.f;
+    }
+  }
+  if (lane == 0) { sacc[0][w] = loss; sacc[1][w] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < WAVES; i++) { a += sacc[0][i]; b += sacc[1][i]; }
+    if (b > 0.f) { atomicAdd(p.acc, a); atomicAdd(p.acc + 1, b); }
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_k(tfx_mse_args p) {
+  __shared__ float sacc[WAVES];
+  const long long n = (long long)p.R * p.ld_d;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / p.ld_d), c = (int)(i % p.ld_d);
+    float g = 0.f;
+    if (c < p.dl) {
+      float df = p.pred[(size_t)r * p.ld_pred + c] - p.flow[(size_t)r * p.dl + c];
+      s += df * df; g = df * p.grad_scale;
+    }
+    p.dpred[i] = f2bf(g);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sacc[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { float a = 0.f; for (int i = 0; i < WAVES; i++) a += sacc[i]; atomicAdd(p.acc, a); }
+}
+
+__global__ void cast_rows_k(tfx_cast_args p) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)p.Rd * p.ld_dst) return;
+  const int r = (int)(i / p.ld_dst), c = (int)(i % p.ld_dst);
+  float v = 0.f;
+  if (c < p.Cs && c < p.Cd) {
+    int rs = p.rowmap ? p.rowmap[r] : r;
+    if (rs >= 0 && rs < p.Rs) v = p.src[(size_t)rs * p.ld_src + c];
+  }
+  p.dst[i] = f2bf(v);
+}
+// dst[c][r] = src[map(r)][c];  dst has Rd (= padded Cs) rows and ld_dst >= Cd (= padded #r) columns
+__global__ void cast_rows_t_k(tfx_cast_args p) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;     // r: dst column index, c: dst row index
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, c = c0 + tx;
+    float v = 0.f;
+    if (r < p.Cd && c < p.Cs) {
+      int rs = p.rowmap ? p.rowmap[r] : r;
+      if (rs >= 0 && rs < p.Rs) v = p.src[(size_t)rs * p.ld_src + c];
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, r = r0 + tx;
+    if (c < p.Rd && r < p.ld_dst) p.dst[(size_t)c * p.ld_dst + r] = f2bf(tile[tx][j]);
+  }
+}
+__global__ void gather_f32_k(const float* src, const int* map, float* dst, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : 0.f;
+}
+__global__ void f32_to_bf16_k(const float* src, bf16* dst, long long n) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    f32x4 v = *(const f32x4*)(src + i);
+    bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+    *(bf16x4*)(dst + i) = o;
+  } else for (; i < n; i++) dst[i] = f2bf(src[i]);
+}
+__global__ void silu_bwd_k(const bf16* dy, const bf16* pre, bf16* dx, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = bf2f(pre[i]), s = sigmoidf_(x);
+  dx[i] = f2bf(bf2f(dy[i]) * s * (1.f + x * (1.f - s)));
+}
+__global__ void add_bf16_k(const bf16* a, const bf16* b, bf16* o, long long n) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 7 < n) {
+    bf16x8 x = *(const bf16x8*)(a + i), y = *(const bf16x8*)(b + i), r;
+#pragma unroll
+    for (int e = 0; e < 8; e++) r[e] = f2bf(bf2f(x[e]) + bf2f(y[e]));
+    *(bf16x8*)(o + i) = r;
+  } else for (; i < n; i++) o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+
+template <typename T> __global__ __launch_bounds__(256) void colsum_k(const T* src, int ld, int R, int C, const int* colmap, float* out, int rows_per_block) {
+  __shared__ float s[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int rbeg = blockIdx.y * rows_per_block, rend = min(R, rbeg + rows_per_block);
+  float a = 0.f;
+  if (c < C) for (int r = rbeg + ry; r < rend; r += 4) a += (float)src[(size_t)r * ld + c];
+  s[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float v = s[0][cx] + s[1][cx] + s[2][cx] + s[3][cx];
+    int co = colmap ? colmap[c] : c;
+    if (co >= 0 && v != 0.f) atomicAdd(out + co, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_k(const float* g, long long n, float* out) {
+  __shared__ float sacc[WAVES];
+  float s = 0.f;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) { f32x4 v = *(const f32x4*)(g + i); s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+    else for (long long j = i; j < n; j++) s += g[j] * g[j];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sacc[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { float a = 0.f; for (int i = 0; i < WAVES; i++) a += sacc[i]; atomicAdd(out, a); }
+}
+
+// clip_grad_norm_(max_norm) + Adam, fused: coef = min(1, max_norm / (norm + 1e-6))   train_toy.py:55-57
+__global__ void adam_k(tfx_adam_args p) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  float coef = p.grad_scale;
+  if (p.max_norm > 0.f) {
+    float norm = sqrtf(p.sumsq[0]) * p.grad_scale;
+    coef *= fminf(1.f, p.max_norm / (norm + 1e-6f));
+  }
+  float g = p.g[i] * coef;
+  float w = p.p[i];
+  if (p.weight_decay != 0.f) g += p.weight_decay * w;
+  float m = p.beta1 * p.m[i] + (1.f - p.beta1) * g;
+  float v = p.beta2 * p.v[i] + (1.f - p.beta2) * g * g;
+  p.m[i] = m; p.v[i] = v;
+  const float bc1 = 1.f - powf(p.beta1, (float)p.step), bc2 = 1.f - powf(p.beta2, (float)p.step);
+  const float denom = sqrtf(v) / sqrtf(bc2) + p.eps;
+  p.p[i] = w - p.lr / bc1 * m / denom;
+}
+
+}  // namespace tfx
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+using namespace tfx;
+#define ST(s) ((hipStream_t)(s))
+#define RET() return (int)hipGetLastError()
+
+extern "C" {
+
+int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_rmsnorm_fwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_rmsnorm_bwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_attnres_fwd(const tfx_attnres_args* a, void* s) { if (a->L > 64) return -2; DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_attnres_bwd(const tfx_attnres_args* a, void* s) { if (a->L > 64) return -2; DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_embed_fwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_embed_bwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_bwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+
+int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* s) {
+  long long nthreads = (long long)a->T * 2 * a->H * 8;
+  hipLaunchKernelGGL(qk_norm_rope_fwd_k, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* s) {
+  long long nthreads = (long long)a->T * 2 * a->H * 8;
+  long long g = (nthreads + 255) / 256; if (g > MAXB) g = MAXB;
+  hipLaunchKernelGGL(qk_norm_rope_bwd_k, dim3((unsigned)g), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_noise_mix(const tfx_noise_mix_args* a, void* s) {
+  long long n = (long long)a->R * a->ld_xt; if (n == 0) return 0;
+  hipLaunchKernelGGL(noise_mix_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_fourier(const tfx_fourier_args* a, void* s) { if (a->I == 0) return 0; hipLaunchKernelGGL(fourier_k, dim3(a->I), dim3(256), 0, ST(s), *a); RET(); }
+int tfx_ce_fwd_bwd(const tfx_ce_args* a, void* s) { hipLaunchKernelGGL(ce_k, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a); RET(); }
+int tfx_mse_fwd_bwd(const tfx_mse_args* a, void* s) {
+  long long n = (long long)a->R * a->ld_d; if (n == 0) return 0;
+  long long g = (n + 255) / 256; if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(mse_k, dim3((unsigned)g), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_cast_rows(const tfx_cast_args* a, void* s) {
+  long long n = (long long)a->Rd * a->ld_dst; if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_rows_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_cast_rows_t(const tfx_cast_args* a, void* s) {
+  hipLaunchKernelGGL(cast_rows_t_k, dim3((a->ld_dst + 31) / 32, (a->Rd + 31) / 32), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_gather_f32(const float* src, const int32_t* map, float* dst, int32_t n, void* s) {
+  if (n == 0) return 0; hipLaunchKernelGGL(gather_f32_k, dim3((n + 255) / 256), dim3(256), 0, ST(s), src, map, dst, n); RET();
+}
+int tfx_f32_to_bf16(const float* src, tfx_bf16* dst, int64_t n, void* s) {
+  if (n == 0) return 0; hipLaunchKernelGGL(f32_to_bf16_k, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, ST(s), src, dst, (long long)n); RET();
+}
+int tfx_silu_bwd(const tfx_bf16* dy, const tfx_bf16* pre, tfx_bf16* dx, int64_t n, void* s) {
+  if (n == 0) return 0; hipLaunchKernelGGL(silu_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(s), dy, pre, dx, (long long)n); RET();
+}
+int tfx_add_bf16(const tfx_bf16* a, const tfx_bf16* b, tfx_bf16* o, int64_t n, void* s) {
+  if (n == 0) return 0; hipLaunchKernelGGL(add_bf16_k, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, ST(s), a, b, o, (long long)n); RET();
+}
+static inline int colsum_rows_per_block(int R) { int rpb = (R + 63) / 64; return rpb < 4 ? 4 : rpb; }
+int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const int32_t* colmap, float* out, void* s) {
+  if (R == 0 || C == 0) return 0;
+  int rpb = colsum_rows_per_block(R);
+  hipLaunchKernelGGL(colsum_k<bf16>, dim3((C + 63) / 64, (R + rpb - 1) / rpb), dim3(256), 0, ST(s), src, ld, R, C, colmap, out, rpb); RET();
+}
+int tfx_colsum_f32(const float* src, int32_t ld, int32_t R, int32_t C, float* out, void* s) {
+  if (R == 0 || C == 0) return 0;
+  int rpb = colsum_rows_per_block(R);
+  hipLaunchKernelGGL(colsum_k<float>, dim3((C + 63) / 64, (R + rpb - 1) / rpb), dim3(256), 0, ST(s), src, ld, R, C, (const int*)nullptr, out, rpb); RET();
+}
+int tfx_sumsq(const float* g, int64_t n, float* out, void* s) {
+  if (n == 0) return 0;
+  long long blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_k, dim3((unsigned)blocks), dim3(256), 0, ST(s), g, (long long)n, out); RET();
+}
+int tfx_adam_step(const tfx_adam_args* a, void* s) {
+  if (a->n == 0) return 0;
+  hipLaunchKernelGGL(adam_k, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* s) { return gemm_nt(*a, ST(s)); }
+int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* s) { return gemm_tn(*a, ST(s)); }
+int tfx_attn_fwd(const tfx_attn_args* a, void* s) { return attn_fwd(*a, ST(s)); }
+int tfx_attn_bwd(const tfx_attn_args* a, void* s) { return attn_bwd(*a, ST(s)); }
+const char* tfx_version(void) { return "tfx-hip gfx950 r1"; }
+
+}  // extern "C"
