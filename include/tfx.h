@@ -71,6 +71,8 @@ typedef struct {
   int32_t splits;
   int32_t accumulate;
   float alpha;
+  const int32_t* a_rowmap;    /* gather rows of A / B (row index = map[m]); NULL = identity */
+  const int32_t* b_rowmap;
 } tfx_gemm_tn_args;
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
 
@@ -220,7 +222,7 @@ int tfx_f32_to_bf16(const float* src, tfx_bf16* dst, int64_t n, void* stream);
 /* dst(bf16) = a(bf16) * silu'(pre(bf16))  (time-MLP backward) */
 int tfx_silu_bwd(const tfx_bf16* dy, const tfx_bf16* pre, tfx_bf16* dx, int64_t n, void* stream);
 /* column sums: out[c] += sum_r src[r][c]  (bias gradients); src bf16 or fp32 */
-int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const int32_t* colmap, float* out, void* stream);
+int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const int32_t* colmap, const int32_t* rowmap, float* out, void* stream);
 int tfx_colsum_f32(const float* src, int32_t ld, int32_t R, int32_t C, float* out, void* stream);
 int tfx_add_bf16(const tfx_bf16* a, const tfx_bf16* b, tfx_bf16* out, int64_t n, void* stream);
 

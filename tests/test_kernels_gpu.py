@@ -449,7 +449,7 @@ def test_param_plumbing():
     check('cast_rows_t', dstT, ref[:, :128].T, 4e-3)
     # colsum
     X = rnd(1000, 136); out = torch.ones(136, device=DEV)
-    capi.check(capi.lib().tfx_colsum_bf16(X.data_ptr(), 136, 1000, 130, None, out.data_ptr(), stream()), 'colsum')
+    capi.check(capi.lib().tfx_colsum_bf16(X.data_ptr(), 136, 1000, 130, None, None, out.data_ptr(), stream()), 'colsum')
     ref = torch.ones(136, device=DEV); ref[:130] += X.float()[:, :130].sum(0)
     check('colsum_bf16', out, ref, 1e-4)
     # adam + clip

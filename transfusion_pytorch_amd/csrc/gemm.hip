@@ -252,8 +252,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
       int m = mrow0 + srow[i];
       int ca = n0 + sch[i] * 8, cb = k0 + sch[i] * 8;
       u32x4 z = {0, 0, 0, 0};
-      ra[i] = (m < mend && ca < p.a_cols) ? *(const u32x4*)(p.A + (size_t)m * p.lda + ca) : z;
-      rb[i] = (m < mend && cb < p.b_cols) ? *(const u32x4*)(p.B + (size_t)m * p.ldb + cb) : z;
+      const bool ok = m < mend;
+      const int ma = (ok && p.a_rowmap) ? p.a_rowmap[m] : m;
+      const int mb = (ok && p.b_rowmap) ? p.b_rowmap[m] : m;
+      ra[i] = (ok && ca < p.a_cols) ? *(const u32x4*)(p.A + (size_t)ma * p.lda + ca) : z;
+      rb[i] = (ok && cb < p.b_cols) ? *(const u32x4*)(p.B + (size_t)mb * p.ldb + cb) : z;
     }
   };
   auto sstore = [&](int buf) {

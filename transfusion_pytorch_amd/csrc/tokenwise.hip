@@ -652,13 +652,13 @@ __global__ void add_bf16_k(const bf16* a, const bf16* b, bf16* o, long long n) {
   } else for (; i < n; i++) o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
 }
 
-template <typename T> __global__ __launch_bounds__(256) void colsum_k(const T* src, int ld, int R, int C, const int* colmap, float* out, int rows_per_block) {
+template <typename T> __global__ __launch_bounds__(256) void colsum_k(const T* src, int ld, int R, int C, const int* colmap, const int* rowmap, float* out, int rows_per_block) {
   __shared__ float s[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   const int rbeg = blockIdx.y * rows_per_block, rend = min(R, rbeg + rows_per_block);
   float a = 0.f;
-  if (c < C) for (int r = rbeg + ry; r < rend; r += 4) a += (float)src[(size_t)r * ld + c];
+  if (c < C) for (int r = rbeg + ry; r < rend; r += 4) a += (float)src[(size_t)(rowmap ? rowmap[r] : r) * ld + c];
   s[ry][cx] = a;
   __syncthreads();
   if (ry == 0 && c < C) {
@@ -763,15 +763,15 @@ int tfx_add_bf16(const tfx_bf16* a, const tfx_bf16* b, tfx_bf16* o, int64_t n, v
   if (n == 0) return 0; hipLaunchKernelGGL(add_bf16_k, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, ST(s), a, b, o, (long long)n); RET();
 }
 static inline int colsum_rows_per_block(int R) { int rpb = (R + 63) / 64; return rpb < 4 ? 4 : rpb; }
-int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const int32_t* colmap, float* out, void* s) {
+int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const int32_t* colmap, const int32_t* rowmap, float* out, void* s) {
   if (R == 0 || C == 0) return 0;
   int rpb = colsum_rows_per_block(R);
-  hipLaunchKernelGGL(colsum_k<bf16>, dim3((C + 63) / 64, (R + rpb - 1) / rpb), dim3(256), 0, ST(s), src, ld, R, C, colmap, out, rpb); RET();
+  hipLaunchKernelGGL(colsum_k<bf16>, dim3((C + 63) / 64, (R + rpb - 1) / rpb), dim3(256), 0, ST(s), src, ld, R, C, colmap, rowmap, out, rpb); RET();
 }
 int tfx_colsum_f32(const float* src, int32_t ld, int32_t R, int32_t C, float* out, void* s) {
   if (R == 0 || C == 0) return 0;
   int rpb = colsum_rows_per_block(R);
-  hipLaunchKernelGGL(colsum_k<float>, dim3((C + 63) / 64, (R + rpb - 1) / rpb), dim3(256), 0, ST(s), src, ld, R, C, (const int*)nullptr, out, rpb); RET();
+  hipLaunchKernelGGL(colsum_k<float>, dim3((C + 63) / 64, (R + rpb - 1) / rpb), dim3(256), 0, ST(s), src, ld, R, C, (const int*)nullptr, (const int*)nullptr, out, rpb); RET();
 }
 int tfx_sumsq(const float* g, int64_t n, float* out, void* s) {
   if (n == 0) return 0;

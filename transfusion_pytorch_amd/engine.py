@@ -1,0 +1,309 @@
+"""Native training engine: a static launch list (forward + hand-written backward) over preallocated HBM
+buffers, executed through the C ABI (libtfx_hip.so) on PyTorch's current HIP stream.
+
+A `Plan` is specialised to one batch geometry (b, n, #instances, latent rows per type): every buffer address
+is fixed, so a step is `for fn, args in plan.fwd: fn(args, stream)` - no allocation, no host sync, and the whole
+list can be captured in a hipGraph.  Math follows SURVEY.md Appendix A (reference T:1100-1266, T:3280-3376).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import capi
+from .params import ModelDims, ParamStore, pad_to
+
+BF16 = torch.bfloat16
+E = capi.ENUMS
+
+
+def _p(t, *idx):
+    """device pointer of t[idx...]"""
+    for i in idx:
+        t = t[i]
+    return t.data_ptr()
+
+
+def skip_sources(md: ModelDims):
+    """simulate the U-Net skip stack (T:1206-1219): for each late layer index with a skip_proj, the index j
+    such that the popped skip is xres[j] (the INPUT of early layer j)."""
+    stack, src = [], {}
+    for i in range(md.depth):
+        layer = i + 1
+        if layer <= md.depth // 2:
+            stack.append(i)
+        elif md.has_skip(i):
+            src[i] = stack.pop()
+    assert not stack
+    return src
+
+
+class Plan:
+    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True):
+        md = ps.md
+        self.ps, self.md, self.b, self.n, self.I, self.R = ps, md, b, n, I, dict(R)
+        self.T = T = b * n
+        dev = ps.device
+        d, hd, D, dip, ldq, nt3 = md.dim, md.hd, md.depth, md.dip, md.ldq, md.nt3
+        z = lambda *s, dtype=BF16: torch.zeros(*s, device=dev, dtype=dtype)
+        e = lambda *s, dtype=BF16: torch.empty(*s, device=dev, dtype=dtype)
+        I1 = max(I, 1)
+        # ---- index arrays (filled per step)
+        self.tok_inst = z(T, dtype=torch.int32); self.kv_end = z(T, dtype=torch.int32); self.q_start = z(T, dtype=torch.int32)
+        self.rot_pos = z(T, dtype=torch.int32); self.text_ids = z(T, dtype=torch.int32); self.labels = z(T, dtype=torch.int32)
+        self.inst_time = z(I1, dtype=torch.float32)
+        self.row_tok = {t: z(r, dtype=torch.int32) for t, r in R.items()}
+        self.row_inst = {t: z(r, dtype=torch.int32) for t, r in R.items()}
+        # ---- forward activations
+        self.hid = e(D + 1, T, d)
+        self.xres = [self.hid[0]] + [e(T, d) for _ in range(D)]
+        self.xa = {i: e(T, d) for i in range(D) if md.has_skip(i)}
+        self.stats = e(4, D, T, dtype=torch.float32)          # mean_a, rstd_a, mean_f, rstd_f
+        self.ua = e(D, T, d); self.uf = e(D, T, d)
+        self.qkvg = z(D, T, ldq); self.qkr = e(D, T, 2 * hd); self.og = e(D, T, hd)
+        self.lse = e(D, b, md.heads, n, dtype=torch.float32)
+        self.ya = e(D, T, d); self.xb = e(D, T, d); self.yf = e(D, T, d)
+        self.ag = e(D, T, 2 * dip); self.hm = e(D, T, dip)
+        self.embed = e(T, d)
+        self.logits = e(T, md.vp, dtype=torch.float32); self.dlogits = e(T, md.vp)
+        self.fe = z(I1, md.kf); self.cond = e(I1, 4 * d); self.pre = e(I1, 4 * d)
+        self.tables = z(I1, nt3, dtype=torch.float32)
+        self.lat = {}
+        for t, r in R.items():
+            dl = md.dim_latents[t]; dlp = pad_to(dl, 64)
+            self.lat[t] = dict(x=e(r, dl, dtype=torch.float32), eps=e(r, dl, dtype=torch.float32), xt=z(r, dlp),
+                               flow=e(r, dl, dtype=torch.float32), pred=e(r, dl, dtype=torch.float32), dpred=z(r, dlp))
+        self.acc = z(8, dtype=torch.float32)
+        self.cos_tab = self.sin_tab = None
+        self.fwd, self.bwd = [], []
+        self.noise_args = {}
+        self._build_forward()
+        if training:
+            self.dH = e(D + 1, T, d)
+            self.gx = e(T, d); self.dy = e(T, d); self.du = e(T, d)
+            self.dskip = {j: e(T, d) for j in set(skip_sources(md).values())}
+            self.dqkvg = z(T, ldq); self.dqk = e(T, 2 * hd); self.dog = e(T, hd); self.do_eff = e(T, hd)
+            self.delta = e(b, md.heads, n, dtype=torch.float32)
+            self.dag = e(T, 2 * dip); self.dembed = e(T, d); self.gfin = e(T, d); self.dx0 = e(T, d)
+            self.dtables = z(I1, nt3, dtype=torch.float32); self.dtab_bf = e(I1, nt3)
+            self.dcond = e(I1, 4 * d); self.dpre = e(I1, 4 * d)
+            self._build_backward()
+
+    # ------------------------------------------------------------------------------------ helpers
+    def _nt(self, lst, **kw):
+        lst.append(('tfx_gemm_nt', capi.make_args('tfx_gemm_nt_args', **kw)))
+
+    def _tn(self, lst, M, N, K, **kw):
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min((M + 511) // 512, 768 // tiles))
+        kw.setdefault('k_valid', K)
+        lst.append(('tfx_gemm_tn', capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, splits=splits, accumulate=1, alpha=1.0, **kw)))
+
+    def _k(self, lst, fn, struct, **kw):
+        lst.append((fn, capi.make_args(struct, **kw)))
+
+    def _raw(self, lst, fn, *args):
+        lst.append((fn, args))
+
+    def _tab(self, i, w):
+        """pointer to (layer i, wrapper w) slice of the AdaLN tables / their grads: gamma | beta | z."""
+        off = ((i * 2 + w) * 3 * self.md.dim) * 4
+        return self.tables.data_ptr() + off, (self.dtables.data_ptr() + off if hasattr(self, 'dtables') else 0)
+
+    # ------------------------------------------------------------------------------------ forward
+    def _build_forward(self):
+        ps, md, T, I = self.ps, self.md, self.T, self.I
+        d, hd, D, dip, ldq, nt3, H = md.dim, md.hd, md.depth, md.dip, md.ldq, md.nt3, md.heads
+        S = ps.shadows
+        L = self.fwd
+        pp = ps.ptr
+        for t, r in self.R.items():
+            dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            self._k(L, 'tfx_noise_mix', 'tfx_noise_mix_args', R=r, dl=dl, x=lt['x'], eps=lt['eps'], row_inst=self.row_inst[t],
+                    inst_time=self.inst_time, xt=lt['xt'], ld_xt=dlp, flow=lt['flow'])
+            self.noise_args[t] = L[-1][1]
+            assert dl != d, 'dim_latent == dim (Identity latent_to_model, T:1478) is not wired in the native path yet'
+            self._nt(L, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
+                     bias=pp(f'latent_to_model_projs.{t}.bias'), rowmap=self.row_tok[t])
+        self._k(L, 'tfx_embed_fwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, table=S['embed'], x=self.hid[0])
+        if I > 0:
+            self._k(L, 'tfx_fourier', 'tfx_fourier_args', I=I, half=d // 2, times=self.inst_time, w=ps.fourier_w, out=self.fe, ld=md.kf)
+            self._nt(L, A=self.fe, lda=md.kf, B=S['time'], ldb=md.kf, M=I, N=4 * d, K=md.kf, epi=E['TFX_EPI_SILU'], C=self.cond, ldc=4 * d,
+                     C2=self.pre, ldc2=4 * d, bias=pp('transformer.to_time_cond.1.bias'))
+            self._nt(L, A=self.cond, lda=4 * d, B=S['ada'], ldb=4 * d, M=I, N=nt3, K=4 * d, epi=E['TFX_EPI_F32'], C=self.tables, ldc=nt3,
+                     bias=pp('transformer.layers.0.1.to_film.bias'))
+        src = skip_sources(md)
+        for i in range(D):
+            p = f'transformer.layers.{i}'
+            x_in = self.xres[i]
+            if md.has_skip(i):
+                self._nt(L, A=x_in, lda=d, A2=self.xres[src[i]], lda2=d, K1=d, B=S[f'skip{i}'], ldb=2 * d, M=T, N=d, K=2 * d,
+                         epi=E['TFX_EPI_RESID'], C=self.xa[i], ldc=d, R=x_in, ldr=d)
+                x_a = self.xa[i]
+            else:
+                x_a = x_in
+            ta, _ = self._tab(i, 0); tf, _ = self._tab(i, 1)
+            self._k(L, 'tfx_adaln_pre_fwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, u=self.ua[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
+                    gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i))
+            self._nt(L, A=self.ua[i], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nq, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[i], ldc=ldq)
+            self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, qk=self.qkr[i], ld_qk=2 * hd,
+                    gamma_q=pp(f'{p}.1.fn.q_norm.gamma'), gamma_k=pp(f'{p}.1.fn.k_norm.gamma'), rot_pos=self.rot_pos,
+                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5)
+            self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
+            self._k(L, 'tfx_attn_fwd', 'tfx_attn_args', **self._attn_kw(i))
+            self._nt(L, A=self.og[i], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[i], ldc=d)
+            self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[i], out=self.xb[i], tok_inst=self.tok_inst,
+                    table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
+            self._k(L, 'tfx_adaln_pre_fwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], u=self.uf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
+                    gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i))
+            self._nt(L, A=self.uf[i], lda=d, B=S[f'ff1{i}'], ldb=d, M=T, N=2 * dip, K=d, epi=E['TFX_EPI_GEGLU'], C=self.ag[i], ldc=2 * dip,
+                     C2=self.hm[i], ldc2=dip, bias=S[f'ff1b{i}'])
+            self._nt(L, A=self.hm[i], lda=dip, B=S[f'ff2{i}'], ldb=dip, M=T, N=d, K=dip, epi=E['TFX_EPI_BF16'], C=self.yf[i], ldc=d,
+                     bias=pp(f'{p}.2.fn.net.3.bias'))
+            self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=self.xb[i], y=self.yf[i], out=self.hid[i + 1], tok_inst=self.tok_inst,
+                    table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
+            self._k(L, 'tfx_attnres_fwd', 'tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
+                    gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1])
+        self._k(L, 'tfx_rmsnorm_fwd', 'tfx_rmsnorm_args', T=T, d=d, x=self.xres[D], y=self.embed, gamma=pp('transformer.norm.gamma'))
+        self.fwd_embed_end = len(L)          # launches up to here produce `embed` (return_embed / decode paths stop here)
+        self._nt(L, A=self.embed, lda=d, B=S['logits'], ldb=d, M=T, N=md.vocab, K=d, epi=E['TFX_EPI_F32'], C=self.logits, ldc=md.vp)
+        self.fwd_logits_end = len(L)
+        self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
+                                       dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
+        L.append(('tfx_ce_fwd_bwd', self._ce_args))
+        self._mse_args = {}
+        for t, r in self.R.items():
+            dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_tok[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
+            self._mse_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['flow'], grad_scale=0.0,
+                                               dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + t))
+            L.append(('tfx_mse_fwd_bwd', self._mse_args[t]))
+
+    def _attn_kw(self, i, bwd=False):
+        md, hd, ldq = self.md, self.md.hd, self.md.ldq
+        kw = dict(q=self.qkr[i], k=_p(self.qkr, i) + 2 * hd, v=_p(self.qkvg, i) + 2 * 2 * hd, ld_q=2 * hd, ld_k=2 * hd, ld_v=ldq,
+                  gate=_p(self.qkvg, i) + 2 * 3 * hd, ld_gate=ldq, kv_end=self.kv_end, q_start=self.q_start, out=self.og[i], ld_out=hd,
+                  lse=self.lse[i], b=self.b, h=md.heads, n=self.n, softcap=50.0)
+        if bwd:
+            kw.update(dout=self.dog, ld_dout=hd, do_eff=self.do_eff, ld_do=hd, delta=self.delta,
+                      dgate=self.dqkvg.data_ptr() + 2 * 3 * hd, ld_dgate=ldq, dq=self.dqk, dk=self.dqk.data_ptr() + 2 * hd,
+                      dv=self.dqkvg.data_ptr() + 2 * 2 * hd, ld_dq=2 * hd, ld_dk=2 * hd, ld_dv=ldq)
+        return kw
+
+    def set_rope_tables(self, cos_tab, sin_tab):
+        self.cos_tab, self.sin_tab = cos_tab, sin_tab
+        for a in getattr(self, '_rope_args', []):
+            a.cos_tab, a.sin_tab = cos_tab.data_ptr(), sin_tab.data_ptr()
+
+    def set_loss_scales(self, ce_scale: float, mse_scales: dict):
+        self._ce_args.grad_scale = ce_scale
+        for t, s in mse_scales.items():
+            self._mse_args[t].grad_scale = s
+
+    # ------------------------------------------------------------------------------------ backward
+    def _build_backward(self):
+        ps, md, T, I = self.ps, self.md, self.T, self.I
+        d, hd, D, di, dip, ldq, nt3, H = md.dim, md.hd, md.depth, md.di, md.dip, md.ldq, md.nt3, md.heads
+        S = ps.shadows
+        L = self.bwd
+        pp, gp = ps.ptr, ps.grad_ptr
+        lib = capi.lib()
+        gmap = ps._maps['geglu']
+        self._nt(L, A=self.dlogits, lda=md.vp, B=S['logits_t'], ldb=md.vp, M=T, N=d, K=md.vp, epi=E['TFX_EPI_BF16'], C=self.dembed, ldc=d)
+        self._tn(L, T, md.vocab, d, A=self.dlogits, lda=md.vp, a_cols=md.vp, B=self.embed, ldb=d, b_cols=d, C=gp('to_text_logits.weight'), ldc=d)
+        for t, r in self.R.items():
+            dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            self._nt(L, A=lt['dpred'], lda=dlp, B=S[f'outp_t{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_RESID'], C=self.dembed, ldc=d,
+                     R=self.dembed, ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
+            self._tn(L, r, dl, d, A=lt['dpred'], lda=dlp, a_cols=dlp, B=self.embed, ldb=d, b_cols=d, b_rowmap=self.row_tok[t],
+                     C=gp(f'model_to_latent_projs.{t}.weight'), ldc=d)
+        self._k(L, 'tfx_rmsnorm_bwd', 'tfx_rmsnorm_args', T=T, d=d, x=self.xres[D], gamma=pp('transformer.norm.gamma'), dy=self.dembed,
+                dx=self.gfin, dgamma=gp('transformer.norm.gamma'))
+        src = skip_sources(md)
+        pushed = set(src.values())
+        g = self.gfin
+        for i in range(D - 1, -1, -1):
+            p = f'transformer.layers.{i}'
+            x_in = self.xres[i]
+            x_a = self.xa[i] if md.has_skip(i) else x_in
+            (ta, dta), (tf, dtf) = self._tab(i, 0), self._tab(i, 1)
+            g2 = self.dskip[i + 1] if (i + 1) in pushed else None
+            self._k(L, 'tfx_attnres_bwd', 'tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
+                    gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), g=g, g2=capi.ptr(g2), dhiddens=self.dH, stride_dh=T * d,
+                    first=1 if i == D - 1 else 0, dgamma=gp(f'{p}.3.norm_keys.gamma'), dpq=gp(f'{p}.3.pseudo_queries'))
+            G = self.dH[i + 1]
+            # ---- feedforward wrapper
+            self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.yf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
+                    layerscale=pp(f'{p}.2.layerscale'), g=G, dy=self.dy, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'))
+            self._raw(L, lib.tfx_colsum_bf16, self.dy.data_ptr(), d, T, d, None, None, gp(f'{p}.2.fn.net.3.bias'))
+            self._tn(L, T, d, di, A=self.dy, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
+            self._nt(L, A=self.dy, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=self.dag, ldc=2 * dip,
+                     aux=self.ag[i], ldaux=2 * dip)
+            self._raw(L, lib.tfx_colsum_bf16, self.dag.data_ptr(), 2 * dip, T, 2 * dip, gmap.data_ptr(), None, gp(f'{p}.2.fn.net.0.bias'))
+            self._tn(L, T, 2 * dip, d, A=self.dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
+                     C=gp(f'{p}.2.fn.net.0.weight'), ldc=d)
+            self._nt(L, A=self.dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
+            self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
+                    gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
+                    dtable=dtf, dgamma_text=gp(f'{p}.2.layernorm_gamma'))
+            # ---- attention wrapper
+            self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.ya[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
+                    layerscale=pp(f'{p}.1.layerscale'), g=G, dy=self.dy, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'))
+            self._tn(L, T, d, hd, A=self.dy, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=hd)
+            self._nt(L, A=self.dy, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
+            self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
+            self._k(L, 'tfx_qk_norm_rope_bwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, gamma_q=pp(f'{p}.1.fn.q_norm.gamma'),
+                    gamma_k=pp(f'{p}.1.fn.k_norm.gamma'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5,
+                    dqk=self.dqk, ld_dqk=2 * hd, dqkv=self.dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
+            self._rope_args.append(L[-1][1])
+            self._tn(L, T, md.nq, d, A=self.dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d)
+            self._nt(L, A=self.dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
+            self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, tok_inst=self.tok_inst, table=ta, ld_table=nt3,
+                    gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i), du=self.du, dx=G,
+                    dtable=dta, dgamma_text=gp(f'{p}.1.layernorm_gamma'))
+            if md.has_skip(i):
+                sk = self.xres[src[i]]
+                self._tn(L, T, d, d, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
+                self._tn(L, T, d, d, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
+                st = S[f'skip_t{i}']
+                self._nt(L, A=G, lda=d, B=st, ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.gx, ldc=d, R=G, ldr=d)
+                self._nt(L, A=G, lda=d, B=st[d:], ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_BF16'], C=self.dskip[src[i]], ldc=d)
+                g = self.gx
+            else:
+                g = G
+        # ---- gradient wrt the transformer input x0 = hid[0] = xres[0]
+        self._raw(L, lib.tfx_add_bf16, g.data_ptr(), self.dH[0].data_ptr(), self.dx0.data_ptr(), T * d)
+        if 0 in pushed:
+            self._raw(L, lib.tfx_add_bf16, self.dx0.data_ptr(), self.dskip[0].data_ptr(), self.dx0.data_ptr(), T * d)
+        self._k(L, 'tfx_embed_bwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, dx=self.dx0, dtable=gp('text_embed.weight'))
+        for t, r in self.R.items():
+            dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            self._tn(L, r, d, dl, A=self.dx0, lda=d, a_cols=d, a_rowmap=self.row_tok[t], B=lt['xt'], ldb=dlp, b_cols=dlp,
+                     C=gp(f'latent_to_model_projs.{t}.weight'), ldc=dl)
+            self._raw(L, lib.tfx_colsum_bf16, self.dx0.data_ptr(), d, r, d, None, self.row_tok[t].data_ptr(), gp(f'latent_to_model_projs.{t}.bias'))
+        if I > 0:
+            self._raw(L, lib.tfx_f32_to_bf16, self.dtables.data_ptr(), self.dtab_bf.data_ptr(), I * nt3)
+            self._tn(L, I, nt3, 4 * d, A=self.dtab_bf, lda=nt3, a_cols=nt3, B=self.cond, ldb=4 * d, b_cols=4 * d,
+                     C=gp('transformer.layers.0.1.to_film.weight'), ldc=4 * d)
+            self._raw(L, lib.tfx_colsum_f32, self.dtables.data_ptr(), nt3, I, nt3, gp('transformer.layers.0.1.to_film.bias'))
+            self._nt(L, A=self.dtab_bf, lda=nt3, B=S['ada_t'], ldb=nt3, M=I, N=4 * d, K=nt3, epi=E['TFX_EPI_BF16'], C=self.dcond, ldc=4 * d)
+            self._raw(L, lib.tfx_silu_bwd, self.dcond.data_ptr(), self.pre.data_ptr(), self.dpre.data_ptr(), I * 4 * d)
+            self._tn(L, I, 4 * d, d + 1, A=self.dpre, lda=4 * d, a_cols=4 * d, B=self.fe, ldb=md.kf, b_cols=md.kf,
+                     C=gp('transformer.to_time_cond.1.weight'), ldc=d + 1)
+            self._raw(L, lib.tfx_colsum_bf16, self.dpre.data_ptr(), 4 * d, I, 4 * d, None, None, gp('transformer.to_time_cond.1.bias'))
+
+    # ------------------------------------------------------------------------------------ run
+    @staticmethod
+    def run(launches, stream, lo=0, hi=None):
+        lib = capi.lib()
+        sp = ctypes.c_void_p(stream)
+        for item in launches[lo:hi]:
+            fn, a = item
+            if isinstance(fn, str):
+                rc = getattr(lib, fn)(ctypes.byref(a), sp)
+            else:
+                rc = fn(*a, sp)
+            if rc != 0:
+                raise capi.TfxError(f'{fn if isinstance(fn, str) else fn.__name__} failed with code {rc}')

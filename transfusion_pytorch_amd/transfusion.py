@@ -1,0 +1,348 @@
+"""`Transfusion` - the reference's Python surface (transfusion_pytorch/__init__.py:1-6, constructor T:1292-1322,
+forward T:2926-2948) in front of the native MI355X engine.
+
+What is native: everything between the packed batch and the scalar loss, forward AND backward (engine.py).
+What stays Python: the structure scan of the ragged input (pure bookkeeping, MP:206-263) and API glue.
+Unsupported reference options raise NotImplementedError - there is no silent PyTorch fallback.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import capi
+from .engine import Plan
+from .packing import PackedBatch, is_int_tensor, scan_batch, token_maps
+from .params import ModelDims, ParamStore
+
+
+class LossBreakdown(NamedTuple):            # T:105-110
+    total: torch.Tensor
+    text: torch.Tensor
+    flow: list
+    velocity: list | None = None
+    recon: list | None = None
+
+
+PROCESSING_STRATEGIES = ('naive', 'grouped', 'flat', 'hybrid', 'auto')    # MP:1050-1058: every name maps to the native packer
+
+
+def default_to_modality_shape_fn(maybe_shape_str):       # T:176-177
+    return tuple([*map(int, maybe_shape_str.split(','))])
+
+
+def cast_tuple(t, length=1):
+    return t if isinstance(t, tuple) else ((t,) * length)
+
+
+class Transformer:
+    """config holder with the reference's constructor signature (T:1043-1059); the layers live in `Transfusion`."""
+
+    def __init__(self, dim, *, depth, dim_head=64, heads=8, dropout=0., ff_expansion_factor=4, attn_kwargs: dict = dict(),
+                 ff_kwargs: dict = dict(), attn_laser=False, unet_skips=True, use_flex_attn=False, qk_rmsnorm=True, use_value_residual=False):
+        unsupported = dict(dropout=dropout != 0., attn_kwargs=bool(attn_kwargs), ff_kwargs=bool(ff_kwargs), attn_laser=attn_laser,
+                           unet_skips=not unet_skips, use_flex_attn=use_flex_attn, qk_rmsnorm=not qk_rmsnorm, use_value_residual=use_value_residual)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f'Transformer options not supported by the native MI355X path: {bad}')
+        if dim_head != 64:
+            raise NotImplementedError('the native attention kernels are specialised to dim_head = 64')
+        if dim % 64 != 0:
+            raise NotImplementedError('the native kernels need dim to be a multiple of 64')
+        self.dim, self.depth, self.dim_head, self.heads, self.ff_expansion_factor = dim, depth, dim_head, heads, ff_expansion_factor
+
+
+class _NativeLoss(torch.autograd.Function):
+    """connects the engine's hand-written backward to `loss.backward()`."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss):
+        ctx.model = model
+        ctx.step_id = model._step_id
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._native_backward(grad_out, ctx.step_id)
+        return None, None, None
+
+
+class Transfusion(nn.Module):
+    def __init__(
+        self, *, num_text_tokens, transformer, model_output_clean=False, dim_latent=None, channel_first_latent=False, add_pos_emb=False,
+        modality_encoder=None, modality_decoder=None, pre_post_transformer_enc_dec=None, modality_default_shape=None,
+        fallback_to_default_shape_if_invalid=False, modality_num_dim=None, to_modality_shape_fn=default_to_modality_shape_fn,
+        ignore_index=-1, flow_loss_weight=1., text_loss_weight=1., velocity_consistency_loss_weight=0.1, reconstruction_loss_weight=0.,
+        modality_encoder_decoder_requires_batch_dim=True, odeint_kwargs: dict = dict(atol=1e-5, rtol=1e-5, method='midpoint'),
+        eps=1e-2, prob_uncond=0.1, modality_processing: str = 'auto',
+    ):
+        super().__init__()
+        assert modality_processing in PROCESSING_STRATEGIES, \
+            f'unknown modality processing strategy `{modality_processing}`, available: {list(PROCESSING_STRATEGIES)}'      # MP:1254-1256
+        self.modality_processing = modality_processing
+        unsupported = dict(model_output_clean=model_output_clean, channel_first_latent=any(cast_tuple(channel_first_latent)),
+                           add_pos_emb=any(cast_tuple(add_pos_emb)), modality_encoder=modality_encoder is not None,
+                           modality_decoder=modality_decoder is not None, pre_post_transformer_enc_dec=pre_post_transformer_enc_dec is not None,
+                           reconstruction_loss_weight=reconstruction_loss_weight > 0.)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f'Transfusion options outside the native hot path (SURVEY.md section 8): {bad}')
+        if odeint_kwargs.get('method', 'midpoint') != 'midpoint':
+            raise NotImplementedError('only the fixed-grid midpoint solver is implemented')
+        if isinstance(transformer, dict):
+            transformer = Transformer(**transformer)
+        self.transformer_config = transformer
+        self.dim = dim = transformer.dim
+        dim_latent = dim if dim_latent is None else dim_latent
+        self.dim_latents = cast_tuple(dim_latent)
+        self.num_modalities = len(self.dim_latents)
+        if modality_default_shape is None or (isinstance(modality_default_shape, tuple) and all(isinstance(i, int) for i in modality_default_shape)):
+            modality_default_shape = (modality_default_shape,) * self.num_modalities           # T:1362-1363
+        self.modality_default_shape = modality_default_shape
+        assert len(self.modality_default_shape) == self.num_modalities
+        self.fallback_to_default_shape_if_invalid = fallback_to_default_shape_if_invalid
+        if modality_num_dim is None:
+            modality_num_dim = tuple(len(s) if s is not None else None for s in self.modality_default_shape)
+        self.modality_num_dim = cast_tuple(modality_num_dim, self.num_modalities)
+        self.to_modality_shape_fn = cast_tuple(to_modality_shape_fn, self.num_modalities)
+        # vocabulary layout  T:1420-1449
+        self.num_text_tokens = num_text_tokens
+        self.sos_id, self.eos_id, self.null_text_id = num_text_tokens, num_text_tokens + 1, num_text_tokens + 2
+        M = self.num_modalities
+        self.som_ids = [num_text_tokens + 3 + i for i in range(M)]
+        self.eom_ids = [num_text_tokens + 3 + M + i for i in range(M)]
+        self.meta_id = num_text_tokens + 3 + 2 * M
+        self.ignore_index = ignore_index
+        self.flow_loss_weight, self.text_loss_weight = flow_loss_weight, text_loss_weight
+        self.velocity_consistency_loss_weight = velocity_consistency_loss_weight
+        self.eps, self.prob_uncond = eps, prob_uncond
+        self.odeint_kwargs = dict(odeint_kwargs)
+
+        self.md = ModelDims(num_text_tokens=num_text_tokens, dim=dim, depth=transformer.depth, heads=transformer.heads,
+                            dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor)
+        self.store = ParamStore(self.md, self)
+        self._plans = {}
+        self._step_id = 0
+        self._live = None
+        self._anchor = None
+        self._rope = None
+        self._noise_override = None          # test hook: type -> (R, dl) noise (parity runs inject the oracle's noise)
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    @property
+    def device(self):
+        return self.store.flat.device
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn)
+        dev = next(iter(self.store.params.values())).device
+        self.store.fourier_w = self.transformer.to_time_cond[0].weights
+        self.store.reflatten(dev)
+        self._plans.clear()
+        self._rope = None
+        return out
+
+    def vocab_size(self):
+        return self.md.vocab
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _require_gpu(self):
+        if self.device.type != 'cuda':
+            raise capi.TfxError('the Transfusion hot path only runs on an MI355X (model.cuda()); there is no CPU fallback')
+        capi.lib()
+
+    def _rope_tables(self, max_pos: int):
+        if self._rope is None or self._rope[0].shape[0] <= max_pos:
+            P = max(2048, 1 << (max_pos + 1).bit_length())
+            freqs = self.store.rot_param.detach().float().cpu()
+            ang = torch.arange(P, dtype=torch.float32)[:, None] * freqs[None, :]      # rotary_embedding_torch: pos * freq, fp32
+            self._rope = (ang.cos().to(self.device).contiguous(), ang.sin().to(self.device).contiguous())
+        return self._rope
+
+    def _plan(self, b, n, I, R, training):
+        key = (b, n, I, tuple(sorted(R.items())), training)
+        if key not in self._plans:
+            if len(self._plans) > 8:
+                self._plans.clear()
+            self._plans[key] = Plan(self.store, b, n, I, R, training=training)
+        return self._plans[key]
+
+    def _scan(self, modalities, add_sos_eos):
+        return scan_batch(modalities, num_modalities=self.num_modalities, dim_latents=self.dim_latents, sos_id=self.sos_id, eos_id=self.eos_id,
+                          meta_id=self.meta_id, som_ids=self.som_ids, eom_ids=self.eom_ids, add_sos_eos=add_sos_eos)
+
+    def _default_times(self, num_modalities_host: np.ndarray):
+        """default_modality_length_to_time_fn, T:186-200 (device RNG)."""
+        b, m = len(num_modalities_host), int(num_modalities_host.max()) if len(num_modalities_host) else 0
+        if m == 0:
+            return torch.empty((b, 0), device=self.device)
+        nm = torch.from_numpy(num_modalities_host.astype(np.float32)).to(self.device)
+        rand_num = torch.floor(torch.rand(b, device=self.device) * nm)
+        seq = torch.arange(m, device=self.device)
+        prev = seq[None, :] < rand_num[:, None]
+        cur = torch.rand(b, device=self.device)
+        return torch.where(prev, torch.full((), 0.5, device=self.device), cur[:, None].expand(b, m))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, modalities, times=None, num_modalities_to_times_fn=None, modality_type=None, cache=None, decode_length=None,
+                decoding_text_or_modality=None, velocity_consistency_ema_model=None, velocity_consistency_delta_time=1e-3,
+                return_only_pred_flows=False, return_loss=True, return_breakdown=False, return_embed=False, return_hiddens=False,
+                return_kv_cache=False, return_times=False, prob_uncond=None):
+        self._require_gpu()
+        if torch.is_tensor(modalities):
+            raise NotImplementedError('forward_text / forward_modality (pure text / pure modality tensors) are "next" rows of SURVEY.md 8(f)')
+        if cache is not None or decoding_text_or_modality is not None or return_kv_cache or velocity_consistency_ema_model is not None \
+                or return_hiddens or return_only_pred_flows:
+            raise NotImplementedError('kv-cache decoding / EMA velocity consistency / hiddens through forward() are not wired in the native path yet')
+        return_loss = return_loss and not return_embed
+        dev = self.device
+        stream = self._stream()
+        ps, md = self.store, self.md
+
+        P = self._scan(modalities, add_sos_eos=return_loss)
+        b = P.b
+        n = P.n_full - 1 if return_loss else P.n_full
+        tm = token_maps(P, n, self.num_modalities)
+        I = len(P.inst_b)
+        R = {t: int(len(v)) for t, v in P.row_inst.items()}
+
+        # ---- times (T:3075-3082)
+        num_mod = np.bincount(P.inst_b, minlength=b)
+        if times is None:
+            fn = num_modalities_to_times_fn
+            times = fn(torch.from_numpy(num_mod).to(dev)) if fn is not None else self._default_times(num_mod)
+        times = times.to(dev, torch.float32)
+
+        ps.refresh_shadows(stream)
+        plan = self._plan(b, n, I, R, training=return_loss)
+        plan.set_rope_tables(*self._rope_tables(int(tm.rot_pos.max()) if tm.rot_pos.size else 0))
+
+        # ---- token ids on device (values never visit the host)
+        text_full = torch.from_numpy(P.text_host).to(dev, non_blocking=True)
+        if P.user_text:
+            vals = torch.cat([t.reshape(-1) for t in P.user_text]).to(dev, torch.int32)
+            text_full.view(-1).index_copy_(0, torch.from_numpy(P.text_dest).to(dev), vals)
+        prob_uncond = self.prob_uncond if prob_uncond is None else prob_uncond
+        if self.training and prob_uncond > 0:                                              # CFG text drop, T:3027-3043
+            drop_rows = torch.rand(b, device=dev) < prob_uncond
+            mask = torch.from_numpy(P.cfg_droppable).to(dev) & drop_rows[:, None]
+            text_full = text_full.masked_fill(mask, self.null_text_id)
+        tok_inst = torch.from_numpy(tm.tok_inst).to(dev, non_blocking=True)
+        plan.tok_inst.copy_(tok_inst.view(-1))
+        plan.kv_end.copy_(torch.from_numpy(tm.kv_end).view(-1), non_blocking=True)
+        plan.q_start.copy_(torch.from_numpy(tm.q_start).view(-1), non_blocking=True)
+        plan.rot_pos.copy_(torch.from_numpy(tm.rot_pos).view(-1), non_blocking=True)
+        plan.text_ids.copy_(text_full[:, :n].reshape(-1))
+        if return_loss:
+            lab = text_full[:, 1:]                                                          # T:3144
+            lab = torch.where((tok_inst >= 0) | (lab == self.null_text_id), torch.full_like(lab, -1), lab)   # T:3320-3323
+            plan.labels.copy_(lab.reshape(-1))
+        if I > 0:
+            it = times[torch.from_numpy(P.inst_b).to(dev), torch.from_numpy(P.inst_m).to(dev)]
+            plan.inst_time.copy_(it)
+        for t in R:
+            rp = P.row_pos[t].astype(np.int64)
+            rb, rl = rp // P.n_full, rp % P.n_full
+            row_tok = np.where(rl < n, rb * n + rl, -1).astype(np.int32)
+            plan.row_tok[t].copy_(torch.from_numpy(row_tok), non_blocking=True)
+            plan.row_inst[t].copy_(torch.from_numpy(P.row_inst[t]), non_blocking=True)
+            lt = plan.lat[t]
+            lt['x'].copy_(torch.cat(P.latents[t]), non_blocking=True)        # one cat on the source device, one transfer
+            if return_loss:
+                if self._noise_override is not None:
+                    lt['eps'].copy_(self._noise_override[t])
+                else:
+                    lt['eps'].normal_()                                                     # MP:654
+            # without a loss there is no noising (MP:658-660): noise_mix with eps = NULL copies x
+            plan.noise_args[t].eps = lt['eps'].data_ptr() if return_loss else None
+
+        if not return_loss:
+            end = plan.fwd_embed_end if return_embed else plan.fwd_logits_end
+            Plan.run(plan.fwd, stream, 0, end)
+            if return_embed:
+                out = plan.embed.view(b, n, md.dim).float()
+                return (out, P) if not return_times else ((out, P), times)
+            logits = plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
+            return (logits, times) if return_times else logits
+
+        # ---- loss seeds (the token-count normalisers cancel: d loss / d logit = w / total_tokens, T:3331)
+        total = float(P.total_tokens)
+        mse_scales = {}
+        for t, r in R.items():
+            w_t = float(tm.is_type[t]) / total                                              # T:3343
+            mse_scales[t] = 2.0 * self.flow_loss_weight * w_t / (r * md.dim_latents[t])
+        plan.set_loss_scales(self.text_loss_weight / total, mse_scales)
+        plan.acc.zero_()
+        Plan.run(plan.fwd, stream)
+
+        acc = plan.acc
+        text_loss = acc[0] / acc[1].clamp(min=1.)
+        loss = self.text_loss_weight * acc[0] / total
+        flow_losses = []
+        for t, r in sorted(R.items()):
+            fl = acc[2 + t] / (r * md.dim_latents[t])
+            flow_losses.append(fl)
+            loss = loss + self.flow_loss_weight * fl * (float(tm.is_type[t]) / total)
+
+        self._step_id += 1
+        self._live = (plan, self._step_id)
+        if torch.is_grad_enabled():
+            if self._anchor is None or self._anchor.device != dev:
+                self._anchor = torch.zeros((), device=dev, requires_grad=True)
+            loss = _NativeLoss.apply(self._anchor, self, loss)
+        if not return_breakdown and not return_times:
+            return loss
+        ret = (loss,)
+        if return_breakdown:
+            ret = (*ret, LossBreakdown(loss, text_loss, flow_losses, None, None))
+        if return_times:
+            ret = (*ret, times)
+        return ret
+
+    def _native_backward(self, grad_out, step_id):
+        plan, live_id = self._live
+        if live_id != step_id:
+            raise RuntimeError('backward() of a stale loss: the native engine keeps the activations of the latest forward only')
+        ps = self.store
+        ps.ensure_grad_views()
+        go = grad_out.reshape(()).to(torch.bfloat16)          # d(total)/d(loss): scales the loss seeds (everything downstream is linear)
+        plan.dlogits.mul_(go)
+        for lt in plan.lat.values():
+            lt['dpred'].mul_(go)
+        plan.dtables.zero_()
+        Plan.run(plan.bwd, self._stream())
+
+    # ------------------------------------------------------------------ sampling surface (not wired yet)
+    def sample(self, *a, **k):
+        raise NotImplementedError('sample / sample_one / sample_many: native decode kernels are the next milestone')
+
+    sample_one = sample
+    sample_many = sample
+
+
+def print_modality_sample(modality_sample):           # T:224-239
+    output = []
+    for sample in modality_sample:
+        if isinstance(sample, tuple):
+            modality_type, sample = sample
+            output.append((f'modality:{modality_type}', sample.shape))
+        elif is_int_tensor(sample):
+            output.append(('text', sample.shape))
+        else:
+            output.append(('modality', sample.shape))
+    print(output)
+
+
+def collate_fn(data):                                  # T:305-306
+    return [*map(list, data)]
+
+
+def create_dataloader(dataset, **kwargs):              # T:308-310
+    from torch.utils.data import DataLoader
+    return DataLoader(dataset, collate_fn=collate_fn, **kwargs)
