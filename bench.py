@@ -1,0 +1,215 @@
+"""bench.py - training-step throughput of the native Transfusion hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): Transfusion(num_text_tokens=256, dim_latent=384, dim=512, depth=8), per-GPU batch
+64 x packed length 1024 of interleaved text + (4,384) latents (the canonical synthetic sample of SURVEY.md section 8(d)),
+bf16 compute / fp32 master.  A step = model(batch) [packing + forward] + loss.backward() [native backward] + one RCCL
+all-reduce of the flat gradient (N > 1) + fused clip(0.5)+Adam(3e-4) (train_toy.py:50-57).  Inputs are resident in HBM.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel family timed with HIP events on the launch stream inside the
+timed region) and, at N == 1, `cpu_baseline` (the oracle restatement timed on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def canonical_batch(b, device, gen, num_text_tokens=256, dim_latent=384, n_inst=32, latent_len=4, text_len=24, last_text_len=23):
+    """per sample 64 parts alternating randint text(24) / randn latent (4,384); packs to 1025 tokens."""
+    batch = []
+    for _ in range(b):
+        parts = []
+        for i in range(n_inst):
+            tl = text_len if i < n_inst - 1 else last_text_len
+            parts.append(torch.randint(0, num_text_tokens, (tl,), device=device, generator=gen))
+            parts.append(torch.randn(latent_len, dim_latent, device=device, generator=gen))
+        batch.append(parts)
+    return batch
+
+
+def f_core_per_sample(d=512, D=8, h=8, dh=64, n=1024, n_inst=32, L=4):
+    """F_core = 6 n D (P_attn + P_ff + SDPA) flop / sample, mask-aware SDPA pairs."""
+    hd, di = h * dh, int(d * 8 / 3)
+    p_attn = d * 2 * hd + d * hd + d * h + hd * d
+    p_ff = d * 2 * di + di * d
+    pairs = n * (n + 1) / 2 + n_inst * L * (L - 1) / 2
+    sdpa = 2 * dh * h * (pairs / n)
+    return 6 * n * D * (p_attn + p_ff + sdpa)
+
+
+def timed_run(plan_cls, launches, stream, family, events):
+    """Plan.run with HIP events (torch events on the launch stream) around every launch of `family`."""
+    from transfusion_pytorch_amd import capi
+    lib = capi.lib()
+    sp = ctypes.c_void_p(stream)
+    for fn, a in launches:
+        if isinstance(fn, str):
+            if fn == family:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = getattr(lib, fn)(ctypes.byref(a), sp)
+                e1.record()
+                events.append((e0, e1, getattr(a, '_algo_flops', 0.0)))
+            else:
+                rc = getattr(lib, fn)(ctypes.byref(a), sp)
+        else:
+            rc = fn(*a, sp)
+        if rc != 0:
+            raise RuntimeError(f'{fn} failed with code {rc}')
+
+
+def cpu_baseline(budget_s=25.0):
+    """the oracle restatement ("port") on the host cores: 1 train step (fwd+bwd+clip+Adam) on a bounded sample."""
+    from oracle import detdata as D
+    from oracle.transfusion_oracle import OracleConfig, train_step
+    torch.set_num_threads(os.cpu_count())
+    cfg = OracleConfig(num_text_tokens=256, dim=512, depth=8, dim_latents=(384,))
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag='bench')
+    sd = {k: (v.clone().requires_grad_(True) if k not in ('rotary_emb.freqs', 'transformer.to_time_cond.0.weights') else v) for k, v in sd.items()}
+    bs = 2
+    batch = D.canonical_batch(bs, key='bench')
+    times = D.det_times('bench/t', batch)
+    noise = D.det_noise('bench/n', batch, 1)
+    state = {}
+    t0 = time.time(); train_step(sd, cfg, batch, times, noise, state); t1 = time.time() - t0
+    steps, tsum = 0, 0.0
+    while tsum + t1 < budget_s and steps < 3:
+        t0 = time.time(); train_step(sd, cfg, batch, times, noise, state); dt = time.time() - t0
+        tsum += dt; steps += 1
+    per_step = (tsum / steps) if steps else t1
+    return {'value': bs / per_step, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'oracle restatement (torch fp32 CPU), dim512/depth8, batch {bs} x 1024 canonical samples, '
+                      f'{"1 warm-up + " + str(steps) + " timed" if steps else "1 timed (cold)"} step(s) of fwd+bwd+clip+Adam'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--dim', type=int, default=512)
+    ap.add_argument('--depth', type=int, default=8)
+    ap.add_argument('--roofline-kernel', default='tfx_gemm_nt')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-profile', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.engine import Plan
+    from transfusion_pytorch_amd.optim import FusedAdam
+
+    torch.manual_seed(0)                                      # identical init on every rank (replicas)
+    model = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,),
+                        transformer=dict(dim=args.dim, depth=args.depth)).to(dev).train()
+    opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    torch.manual_seed(7 + rank)                               # per-rank noise / times / CFG streams
+    batch = canonical_batch(args.batch, dev, gen)
+
+    def step():
+        loss = model(batch)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    # instrument the dominant kernel family with HIP events inside the timed region
+    events = []
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    orig_run = Plan.run
+    def run(launches, stream_, lo=0, hi=None):
+        timed_run(Plan, launches[lo:hi], stream_, args.roofline_kernel, events)
+    Plan.run = staticmethod(run)
+    host_t = 0.0
+    prof = None
+    if args.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h0 = time.perf_counter()
+        loss = step()
+        host_t += time.perf_counter() - h0
+    if prof is not None:
+        prof.disable()
+        import pstats
+        pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(18)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    Plan.run = orig_run
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+
+    if rank == 0:
+        kt = sum(e0.elapsed_time(e1) for e0, e1, _ in events) * 1e-3
+        kf = sum(f for _, _, f in events)
+        achieved = kf / kt / 1e12 if kt > 0 else 0.0
+        n_launch = len(events)
+        fcore = f_core_per_sample(d=args.dim, D=args.depth)
+        out = {
+            'metric': 'train samples/sec, dim512 d8 seq1024 text+latent', 'value': value, 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'Transfusion dim={args.dim} depth={args.depth} heads=8 dim_head=64 num_text_tokens=256 dim_latent=384; '
+                                   f'per-GPU batch {args.batch} x seq 1024 (32 x [24 text tokens + (4,384) latent] per sample); '
+                                   'step = pack + fwd + bwd + grad all-reduce + clip(0.5) + Adam(3e-4)',
+                       'global_batch': world * args.batch, 'seq_len': 1024, 'parallelism': f'dp{world}'},
+            'loss': float(loss),
+            'model_flops_utilization': value / world * fcore / (PEAK_BF16_TFLOPS * 1e12),
+            'f_core_gflop_per_sample': fcore / 1e9,
+            'host_ms_per_step': host_t / args.steps * 1e3,
+            'roofline': {'bound': 'mfma', 'kernel': args.roofline_kernel, 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': None, 'launches_per_step': n_launch / max(args.steps, 1),
+                         'avg_launch_us': kt / max(n_launch, 1) * 1e6, 'algorithmic_gflop_per_step': kf / max(args.steps, 1) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -59,7 +59,8 @@ typedef struct {
 } tfx_gemm_nt_args;
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
 
-/* C[rowmap[n]][k] (+)= alpha * sum_m A[m][n] * B[m][k]   (fp32 C; split-M with fp32 atomics).
+/* C[rowmap[n]][k] += alpha * sum_m A[m][n] * B[m][k]   (fp32 C, ALWAYS accumulates: split-M partial sums are
+ * added with fp32 atomics, the caller zeroes C when it wants a plain product; `accumulate` is ignored).
  * a_cols/b_cols: number of readable columns of A/B (multiples of 8); k_valid: columns of C written. */
 typedef struct {
   const tfx_bf16* A; int32_t lda; int32_t a_cols;
@@ -111,6 +112,9 @@ typedef struct {
   const tfx_bf16* du; tfx_bf16* dx;           /* dx += LN backward (in place accumulate) */
   float* dtable;                              /* fp32 [I, ld] (atomic accumulate) */
   float* dgamma_text;                         /* [d] (atomic accumulate) */
+  /* optional segment mode (backward): runs of consecutive tokens sharing one tok_inst value; one wave owns a
+   * segment, so an instance's FiLM gradients are reduced in registers and STORED (no atomics).  NULL = per-token atomics */
+  const int32_t* seg_start; const int32_t* seg_len; int32_t n_seg;
 } tfx_adaln_pre_args;
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* stream);
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* stream);
@@ -124,6 +128,7 @@ typedef struct {
   /* backward: g = grad wrt out (also the residual grad, passed through untouched) */
   const tfx_bf16* g; tfx_bf16* dy;
   float* dtable; float* dlayerscale;
+  const int32_t* seg_start; const int32_t* seg_len; int32_t n_seg;   /* optional segment mode, see tfx_adaln_pre_args */
 } tfx_adaln_post_args;
 int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* stream);
 int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* stream);
@@ -218,6 +223,8 @@ int tfx_cast_rows(const tfx_cast_args* a, void* stream);
 int tfx_cast_rows_t(const tfx_cast_args* a, void* stream);
 /* out_f32[i] = gather of fp32 vector through a map (bias shadows): dst[i] = map[i] >= 0 ? src[map[i]] : 0 */
 int tfx_gather_f32(const float* src, const int32_t* map, float* dst, int32_t n, void* stream);
+/* out[t][c] (bf16, ld % 8 == 0) = 1 if token t is text and max(ids[t],0) == c else 0  (embedding-gradient GEMM operand) */
+int tfx_onehot_bf16(const int32_t* ids, const int32_t* tok_inst, tfx_bf16* out, int32_t T, int32_t ld, void* stream);
 int tfx_f32_to_bf16(const float* src, tfx_bf16* dst, int64_t n, void* stream);
 /* dst(bf16) = a(bf16) * silu'(pre(bf16))  (time-MLP backward) */
 int tfx_silu_bwd(const tfx_bf16* dy, const tfx_bf16* pre, tfx_bf16* dx, int64_t n, void* stream);

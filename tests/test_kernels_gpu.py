@@ -466,3 +466,47 @@ def test_param_plumbing():
         capi.call('tfx_adam_step', a, stream())
         pr.grad = g.clone(); torch.nn.utils.clip_grad_norm_([pr], 0.5); opt.step()
     check('adam+clip', p, pr.detach(), 1e-6)
+
+
+@pytest.mark.parametrize('T,d', [(1000, 512), (300, 1024)])
+def test_adaln_bwd_segment_mode(T, d):
+    """segment mode (one wave owns an instance: register reduction + plain stores) == per-token atomics mode."""
+    import numpy as np
+    from transfusion_pytorch_amd.packing import token_segments
+    torch.manual_seed(0)
+    I = 23
+    # contiguous instances of random lengths inside 2 sample rows
+    tok = np.full((2, T // 2), -1, dtype=np.int32)
+    g = 0
+    for bi in range(2):
+        pos = 2
+        while pos < T // 2 - 12 and g < I:
+            L = int(np.random.RandomState(g).randint(1, 12))
+            tok[bi, pos:pos + L] = g; g += 1
+            pos += L + int(np.random.RandomState(100 + g).randint(0, 20))
+    seg_start, seg_len = token_segments(tok)
+    assert seg_len.sum() == tok.size
+    tok_inst = torch.from_numpy(tok.reshape(-1)).to(DEV)
+    T = tok.size
+    ld = 3 * d + 8
+    table = torch.randn(I, ld, device=DEV) * 0.5
+    x = rnd(T, d, scale=2.0); gt = torch.randn(d, device=DEV) * 0.3; du = rnd(T, d)
+    u = torch.zeros(T, d, device=DEV, dtype=BF); mean = torch.zeros(T, device=DEV); rstd = torch.zeros(T, device=DEV)
+    ss, sl = torch.from_numpy(seg_start).to(DEV), torch.from_numpy(seg_len).to(DEV)
+    outs = []
+    for seg in (False, True):
+        dx = torch.zeros(T, d, device=DEV, dtype=BF); dtable = torch.zeros_like(table); dgt = torch.zeros(d, device=DEV)
+        kw = dict(seg_start=ss, seg_len=sl, n_seg=len(seg_start)) if seg else {}
+        a = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x, u=u, tok_inst=tok_inst, table=table, ld_table=ld, gamma_text=gt,
+                           mean=mean, rstd=rstd, du=du, dx=dx, dtable=dtable, dgamma_text=dgt, **kw)
+        capi.call('tfx_adaln_pre_fwd', a, stream()); capi.call('tfx_adaln_pre_bwd', a, stream())
+        y = rnd(T, d, scale=1.0) if not outs else y_keep
+        y_keep = y
+        ls = gt; gg = du; dy = torch.zeros(T, d, device=DEV, dtype=BF); dt2 = torch.zeros_like(table); dls = torch.zeros(d, device=DEV)
+        a2 = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x, y=y, out=u, tok_inst=tok_inst, table=table, ld_table=ld,
+                            layerscale=ls, g=gg, dy=dy, dtable=dt2, dlayerscale=dls, **kw)
+        capi.call('tfx_adaln_post_bwd', a2, stream())
+        outs.append((dx.float(), dtable[:, :2 * d].clone(), dgt.clone(), dy.float(), dt2[:, 2 * d:3 * d].clone(), dls.clone()))
+    names = ['pre dx', 'pre dtable', 'pre dgamma_text', 'post dy', 'post dtable', 'post dlayerscale']
+    for nm, a_, b_ in zip(names, outs[1], outs[0]):
+        check(f'segment-mode {nm}', a_, b_, 2e-3 if 'dx' in nm or 'dy' in nm else 1e-5)

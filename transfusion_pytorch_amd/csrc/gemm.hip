@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 // gemm_tn: C[rowmap[n]][k] += sum_m A[m][n] * B[m][k]
 // ------------------------------------------------------------------------------------------------
 constexpr int TN_BMK = 64;      // contraction rows per LDS tile
-constexpr int TN_LD = 160;      // padded LDS row stride (elements): conflict-free ds_read_b64_tr_b16
+constexpr int TN_LD = 136;      // padded LDS row stride (elements); 136 keeps 2 blocks/CU resident (69.6 KB LDS each)
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -233,8 +233,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wn = w >> 1, wk = w & 1, hi = l >> 5;
   const int ntn = (p.N + 127) / 128, ntk = (p.K + 127) / 128;
-  int bid = blockIdx.x;
-  const int split = bid / (ntn * ntk); bid -= split * ntn * ntk;
+  // XCD-aware order (block b runs on XCD b % 8, private L2): an XCD owns whole row-chunks ("splits") and walks
+  // all output tiles of a chunk concurrently, so every 64-row slab of A and B is fetched from HBM once per
+  // chunk and re-read by the other tiles from that XCD's L2.  splits is a multiple of 8 (launcher).
+  const int ntile = ntn * ntk;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int split = xcd + 8 * (local / ntile);
+  const int bid = local % ntile;
   const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
   const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
   const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
@@ -317,9 +322,236 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
         const int k = k0 + wk * 64 + j * 32 + (l & 31);
         if (k < p.k_valid) {
           float v = acc[i][j][r] * p.alpha;
-          if (p.splits == 1 && !p.accumulate) p.C[(size_t)no * p.ldc + k] = v;
-          else atomicAdd(p.C + (size_t)no * p.ldc + k, v);
+          atomicAdd(p.C + (size_t)no * p.ldc + k, v);
         }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variants (global_load_lds, 16 B per lane): the register -> ds_write_b128 staging pass is what
+// bounds the register-staged kernels above (ds_write_b128 ~13 LDS cycles per wave-instruction: ~415 cycles
+// per 128x128x64 tile-step against 512 MFMA cycles).  The DMA writes lane-linear 1 KiB pieces, so the bank
+// swizzle is applied to the SOURCE address (each lane fetches the chunk its LDS slot must hold) and to the
+// read address - same involution on both sides (cdna_hip_programming.md rule 21).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+TFX_DEV void glds16(const bf16* g, bf16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* As = (bf16*)smem_raw;                 // [2][128*64], row r chunk c' holds global chunk c' ^ (r & 7)
+  bf16* Bs = As + 2 * BM * BK;
+
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int nk = p.K / BK;
+
+  // wave w stages rows [32w, 32w+32) of both tiles: 4 DMA pieces of 8 rows x 128 B each
+  const bf16 *ga[4], *ga2[4], *gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int row = w * 32 + j * 8 + (l >> 3);
+    const int c = (l & 7) ^ (row & 7);
+    int rm = min(m0 + row, p.M - 1);
+    if (p.a_rowmap) rm = p.a_rowmap[rm];
+    const int rn = min(n0 + row, p.N - 1);
+    ga[j] = p.A + (size_t)rm * p.lda + c * 8;
+    ga2[j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
+    gb[j] = p.B + (size_t)rn * p.ldb + c * 8;
+  }
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    const bool second = p.A2 && k0 >= p.K1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      glds16(second ? ga2[j] + (k0 - p.K1) : ga[j] + k0, As + buf * BM * BK + (w * 32 + j * 8) * BK);
+      glds16(gb[j] + k0, Bs + buf * BN * BK + (w * 32 + j * 8) * BK);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  issue(0, 0);
+  const int arow0 = wm * 64 + (l & 31), brow0 = wn * 64 + (l & 31);
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      issue(kt + 1, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 8 pieces of tile kt have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                            // ... and every other wave's
+    const bf16* as = As + cur * BM * BK;
+    const bf16* bs = Bs + cur * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        int ar = arow0 + i * 32, br = brow0 + i * 32;
+        af[i] = *(const bf16x8*)(as + ar * BK + (((ks * 2 + hi) ^ (ar & 7)) << 3));
+        bfr[i] = *(const bf16x8*)(bs + br * BK + (((ks * 2 + hi) ^ (br & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // buffer `cur` is free for tile kt + 2
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int m = m0 + wm * 64 + i * 32 + (l & 31);
+    if (m >= p.M) continue;
+    const int mo = p.rowmap ? p.rowmap[m] : m;
+    if (mo < 0) continue;
+    if constexpr (EPI == EPI_GEGLU) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int n_a = n0 + wn * 64 + 8 * g + 4 * hi;
+        if (n_a >= p.N) continue;
+        f32x4 a, gt;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e]; gt[e] = acc[i][1][4 * g + e]; }
+        GegluFwd::apply(p, mo, n_a, a, gt);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e];
+          Epilogue<EPI>::apply(p, m, mo, n, v);
+        }
+    }
+  }
+}
+
+// TN with LDS-DMA: unpadded [64][128] tiles, 16-byte chunk index XOR ((row & 3) << 2) keeps the four rows of a
+// ds_read_b64_tr_b16 group on distinct banks.  Needs M % 64 == 0 and no row maps (rows are never zero-filled).
+TFX_DEV bf16x8 lds_tr8_swz(const bf16* tile, int rowA, int rowB, int c0) {
+  const int l = threadIdx.x & 63;
+  const int q = l & 15;
+  const int col = c0 + 16 * ((l >> 4) & 1) + 4 * (q & 3);
+  const int ra = rowA + (q >> 2), rb = rowB + (q >> 2);
+  s16x4 lo = lds_tr4(tile + ra * 128 + ((((col >> 3) ^ ((ra & 3) << 2))) << 3) + (col & 7));
+  s16x4 hi = lds_tr4(tile + rb * 128 + ((((col >> 3) ^ ((rb & 3) << 2))) << 3) + (col & 7));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTN p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* As = (bf16*)smem_raw;                         // [2][64*128]
+  bf16* Bs = As + 2 * TN_BMK * 128;                   // [2][64*128]
+
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = w >> 1, wk = w & 1;
+  const int ntn = (p.N + 127) / 128, ntk = (p.K + 127) / 128;
+  const int ntile = ntn * ntk;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int split = xcd + 8 * (local / ntile);
+  const int bid = local % ntile;
+  const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
+  const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
+  const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
+  if (mbeg >= mend) return;
+  const int nsteps = (mend - mbeg) / TN_BMK;
+
+  // wave w stages rows [16w, 16w+16) of both tiles: 4 DMA pieces of 4 rows x 256 B each
+  const bf16 *ga[4], *gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int row = w * 16 + j * 4 + (l >> 4);
+    const int c = (l & 15) ^ ((row & 3) << 2);
+    const int ca = min(n0 + c * 8, p.a_cols - 8), cb = min(k0 + c * 8, p.b_cols - 8);   // clamped columns only feed unstored outputs
+    ga[j] = p.A + (size_t)(mbeg + row) * p.lda + ca;
+    gb[j] = p.B + (size_t)(mbeg + row) * p.ldb + cb;
+  }
+  auto issue = [&](int st, int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      glds16(ga[j] + (size_t)st * TN_BMK * p.lda, As + buf * TN_BMK * 128 + (w * 16 + j * 4) * 128);
+      glds16(gb[j] + (size_t)st * TN_BMK * p.ldb, Bs + buf * TN_BMK * 128 + (w * 16 + j * 4) * 128);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  issue(0, 0);
+  for (int st = 0; st < nsteps; st++) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) {
+      issue(st + 1, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const bf16* as = As + cur * TN_BMK * 128;
+    const bf16* bs = Bs + cur * TN_BMK * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const int r0 = ks * 16 + 8 * hi;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        af[i] = lds_tr8_swz(as, r0, r0 + 4, wn * 64 + i * 32);
+        bfr[i] = lds_tr8_swz(bs, r0, r0 + 4, wk * 64 + i * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (n >= p.N) continue;
+      const int no = p.rowmap ? p.rowmap[n] : n;
+      if (no < 0) continue;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int k = k0 + wk * 64 + j * 32 + (l & 31);
+        if (k < p.k_valid) atomicAdd(p.C + (size_t)no * p.ldc + k, acc[i][j][r] * p.alpha);
       }
     }
 }
@@ -327,10 +559,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+static bool use_glds() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TFX_GEMM_GLDS"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int smem = 2 * (BM * BK + BN * BK) * 2;
   int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
+  if (use_glds()) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
+  else hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }
 
@@ -357,8 +596,13 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
     hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  int grid = ((p.N + 127) / 128) * ((p.K + 127) / 128) * p.splits;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), smem, s, p);
+  GemmTN q = p;
+  q.splits = (p.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernel's block order)
+  int grid = ((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
+  if (use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8)
+    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(grid), dim3(256), 2 * 2 * TN_BMK * 128 * 2, s, q);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), smem, s, q);
   return (int)hipGetLastError();
 }
 

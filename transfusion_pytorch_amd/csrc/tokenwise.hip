@@ -224,6 +224,132 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_k(tfx_ad
 }
 
 // ------------------------------------------------------------------------------------------------
+// segment-mode backward of the two AdaLN kernels: a wave owns a run of consecutive tokens with one tok_inst
+// value (a whole modality instance, or a short chunk of text), so the per-instance FiLM / ada-ln-zero
+// gradients are reduced in registers and written with plain stores - no atomics on the table gradients.
+// ------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_seg_k(tfx_adaln_pre_args p) {
+  __shared__ float smem[WAVES * NC * 512];
+  const int lane = threadIdx.x & 63;
+  const int d = p.d;
+  Row<NC> pg;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) pg.v[i][e] = 0.f;
+  for (int s = blockIdx.x * WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * WAVES) {
+    const int t0 = p.seg_start[s], len = p.seg_len[s];
+    const int inst = p.tok_inst[t0];
+    Row<NC> g, ag, ab;
+    if (inst < 0) load_vec(g, p.gamma_text, d, lane);
+    else load_vec(g, p.table + (size_t)inst * p.ld_table, d, lane);
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { ag.v[i][e] = 0.f; ab.v[i][e] = 0.f; }
+    for (int t = t0; t < t0 + len; t++) {
+      Row<NC> x, du;
+      load_row(x, p.x + (size_t)t * d, d, lane);
+      load_row(du, p.du + (size_t)t * d, d, lane);
+      const float mean = p.mean[t], rstd = p.rstd[t];
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NC; i++) {
+        int c = lane + 64 * i;
+        if (c * 8 >= d) continue;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float xh = (x.v[i][e] - mean) * rstd;
+          ag.v[i][e] += du.v[i][e] * xh; ab.v[i][e] += du.v[i][e];
+          float dxh = du.v[i][e] * (1.f + g.v[i][e]);
+          c1 += dxh; c2 += dxh * xh;
+          x.v[i][e] = xh; du.v[i][e] = dxh;
+        }
+      }
+      c1 = wave_sum(c1) / d; c2 = wave_sum(c2) / d;
+      Row<NC> dx; load_row(dx, p.dx + (size_t)t * d, d, lane);
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) dx.v[i][e] += rstd * (du.v[i][e] - c1 - x.v[i][e] * c2);
+      store_row(dx, p.dx + (size_t)t * d, d, lane);
+    }
+    if (inst < 0) {
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) pg.v[i][e] += ag.v[i][e];
+    } else {
+      float* dt = p.dtable + (size_t)inst * p.ld_table;
+#pragma unroll
+      for (int i = 0; i < NC; i++) {
+        int c = lane + 64 * i;
+        if (c * 8 >= d) continue;
+        f32x4 a0, a1, b0, b1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a0[e] = ag.v[i][e]; a1[e] = ag.v[i][4 + e]; b0[e] = ab.v[i][e]; b1[e] = ab.v[i][4 + e]; }
+        *(f32x4*)(dt + c * 8) = a0; *(f32x4*)(dt + c * 8 + 4) = a1;
+        *(f32x4*)(dt + d + c * 8) = b0; *(f32x4*)(dt + d + c * 8 + 4) = b1;
+      }
+    }
+  }
+  flush_col_partials<NC>(pg, p.dgamma_text, d, smem);
+}
+
+template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_seg_k(tfx_adaln_post_args p) {
+  __shared__ float smem[WAVES * NC * 512];
+  const int lane = threadIdx.x & 63;
+  const int d = p.d;
+  Row<NC> pl;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) pl.v[i][e] = 0.f;
+  for (int s = blockIdx.x * WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * WAVES) {
+    const int t0 = p.seg_start[s], len = p.seg_len[s];
+    const int inst = p.tok_inst[t0];
+    Row<NC> sc, az;
+    if (inst < 0) load_vec(sc, p.layerscale, d, lane);
+    else load_vec(sc, p.table + (size_t)inst * p.ld_table + 2 * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { sc.v[i][e] = inst < 0 ? 1.f + sc.v[i][e] : sigmoidf_(sc.v[i][e]); az.v[i][e] = 0.f; }
+    for (int t = t0; t < t0 + len; t++) {
+      Row<NC> g, y;
+      load_row(g, p.g + (size_t)t * d, d, lane);
+      load_row(y, p.y + (size_t)t * d, d, lane);
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { az.v[i][e] += g.v[i][e] * y.v[i][e]; g.v[i][e] *= sc.v[i][e]; }
+      store_row(g, p.dy + (size_t)t * d, d, lane);
+    }
+    if (inst < 0) {
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) pl.v[i][e] += az.v[i][e];
+    } else {
+      float* dt = p.dtable + (size_t)inst * p.ld_table + 2 * d;
+#pragma unroll
+      for (int i = 0; i < NC; i++) {
+        int c = lane + 64 * i;
+        if (c * 8 >= d) continue;
+        f32x4 a0, a1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          a0[e] = az.v[i][e] * sc.v[i][e] * (1.f - sc.v[i][e]);
+          a1[e] = az.v[i][4 + e] * sc.v[i][4 + e] * (1.f - sc.v[i][4 + e]);
+        }
+        *(f32x4*)(dt + c * 8) = a0; *(f32x4*)(dt + c * 8 + 4) = a1;
+      }
+    }
+  }
+  flush_col_partials<NC>(pl, p.dlayerscale, d, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
 // RMSNorm (final norm): y = x / max(|x|, 1e-12) * sqrt(d) * (gamma + 1)                T:779-786
 // ------------------------------------------------------------------------------------------------
 template <int NC> __global__ __launch_bounds__(256) void rmsnorm_fwd_k(tfx_rmsnorm_args p) {
@@ -624,6 +750,17 @@ __global__ void cast_rows_t_k(tfx_cast_args p) {
     if (c < p.Rd && r < p.ld_dst) p.dst[(size_t)c * p.ld_dst + r] = f2bf(tile[tx][j]);
   }
 }
+// one-hot rows of the text tokens (zero rows for modality tokens): the embedding gradient becomes a TN GEMM
+__global__ void onehot_k(const int* ids, const int* tok_inst, bf16* out, int T, int ld) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= (long long)T * ld) return;
+  const int t = (int)(i / ld), c = (int)(i % ld);
+  const int id = tok_inst[t] < 0 ? max(ids[t], 0) : -1;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; e++) o[e] = f2bf(c + e == id ? 1.f : 0.f);
+  *(bf16x8*)(out + i) = o;
+}
 __global__ void gather_f32_k(const float* src, const int* map, float* dst, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : 0.f;
@@ -713,9 +850,18 @@ using namespace tfx;
 extern "C" {
 
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
-int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+static inline int grid_segs(int n_seg) { int g = (n_seg + WAVES - 1) / WAVES; return g < 512 ? (g < 1 ? 1 : g) : 512; }
+int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) {
+  if (a->seg_start) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
+  else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
+  RET();
+}
 int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
-int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) {
+  if (a->seg_start) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
+  else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
+  RET();
+}
 int tfx_rmsnorm_fwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_rmsnorm_bwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_attnres_fwd(const tfx_attnres_args* a, void* s) { if (a->L > 64) return -2; DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
@@ -749,6 +895,11 @@ int tfx_cast_rows(const tfx_cast_args* a, void* s) {
 }
 int tfx_cast_rows_t(const tfx_cast_args* a, void* s) {
   hipLaunchKernelGGL(cast_rows_t_k, dim3((a->ld_dst + 31) / 32, (a->Rd + 31) / 32), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_onehot_bf16(const int32_t* ids, const int32_t* tok_inst, tfx_bf16* out, int32_t T, int32_t ld, void* s) {
+  if (T == 0) return 0; if (ld % 8) return -1;
+  long long n = (long long)T * ld / 8;
+  hipLaunchKernelGGL(onehot_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(s), ids, tok_inst, out, T, ld); RET();
 }
 int tfx_gather_f32(const float* src, const int32_t* map, float* dst, int32_t n, void* s) {
   if (n == 0) return 0; hipLaunchKernelGGL(gather_f32_k, dim3((n + 255) / 256), dim3(256), 0, ST(s), src, map, dst, n); RET();

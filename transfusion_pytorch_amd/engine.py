@@ -17,6 +17,7 @@ from .params import ModelDims, ParamStore, pad_to
 
 BF16 = torch.bfloat16
 E = capi.ENUMS
+TN_BLOCKS_PER_XCD = int(__import__('os').environ.get('TFX_TN_BLOCKS_PER_XCD', '128'))
 
 
 def _p(t, *idx):
@@ -79,6 +80,9 @@ class Plan:
         self.cos_tab = self.sin_tab = None
         self.fwd, self.bwd = [], []
         self.noise_args = {}
+        self.loaded_structure = None
+        self._seg_args = []
+        self.seg_start = z(max(T, 1), dtype=torch.int32); self.seg_len = z(max(T, 1), dtype=torch.int32)
         self._build_forward()
         if training:
             self.dH = e(D + 1, T, d)
@@ -89,17 +93,32 @@ class Plan:
             self.dag = e(T, 2 * dip); self.dembed = e(T, d); self.gfin = e(T, d); self.dx0 = e(T, d)
             self.dtables = z(I1, nt3, dtype=torch.float32); self.dtab_bf = e(I1, nt3)
             self.dcond = e(I1, 4 * d); self.dpre = e(I1, 4 * d)
+            self.onehot = e(T, md.vp)
             self._build_backward()
 
     # ------------------------------------------------------------------------------------ helpers
-    def _nt(self, lst, **kw):
-        lst.append(('tfx_gemm_nt', capi.make_args('tfx_gemm_nt_args', **kw)))
+    def _nt(self, lst, algo_n=None, algo_k=None, **kw):
+        a = capi.make_args('tfx_gemm_nt_args', **kw)
+        a._algo_flops = 2.0 * kw['M'] * (algo_n or kw['N']) * (algo_k or kw['K'])      # algorithmic (unpadded) work of this launch
+        lst.append(('tfx_gemm_nt', a))
 
     def _tn(self, lst, M, N, K, **kw):
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splits = max(1, min((M + 511) // 512, 768 // tiles))
+        # each XCD owns whole row-chunks (gemm.hip); 64 blocks are resident per XCD (2 per CU).  Pick the split count
+        # that minimises (block waves per XCD) x (rows per block) plus a small price for the fp32 atomics per split
+        # (measured on MI355X with tools/bench_gemm.py).
+        best, splits = None, 8
+        for s in (8, 16, 24, 32, 48, 64):
+            if s > 8 and M // s < 256:
+                break
+            cost = -(-(tiles * s // 8) // 64) * (8.0 / s) + 0.004 * s
+            if best is None or cost < best - 1e-9:
+                best, splits = cost, s
         kw.setdefault('k_valid', K)
-        lst.append(('tfx_gemm_tn', capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, splits=splits, accumulate=1, alpha=1.0, **kw)))
+        algo_n = kw.pop('algo_n', None)
+        a = capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, splits=splits, accumulate=1, alpha=1.0, **kw)
+        a._algo_flops = 2.0 * M * (algo_n or N) * kw['k_valid']
+        lst.append(('tfx_gemm_tn', a))
 
     def _k(self, lst, fn, struct, **kw):
         lst.append((fn, capi.make_args(struct, **kw)))
@@ -125,12 +144,12 @@ class Plan:
                     inst_time=self.inst_time, xt=lt['xt'], ld_xt=dlp, flow=lt['flow'])
             self.noise_args[t] = L[-1][1]
             assert dl != d, 'dim_latent == dim (Identity latent_to_model, T:1478) is not wired in the native path yet'
-            self._nt(L, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
+            self._nt(L, algo_k=dl, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
                      bias=pp(f'latent_to_model_projs.{t}.bias'), rowmap=self.row_tok[t])
         self._k(L, 'tfx_embed_fwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, table=S['embed'], x=self.hid[0])
         if I > 0:
             self._k(L, 'tfx_fourier', 'tfx_fourier_args', I=I, half=d // 2, times=self.inst_time, w=ps.fourier_w, out=self.fe, ld=md.kf)
-            self._nt(L, A=self.fe, lda=md.kf, B=S['time'], ldb=md.kf, M=I, N=4 * d, K=md.kf, epi=E['TFX_EPI_SILU'], C=self.cond, ldc=4 * d,
+            self._nt(L, algo_k=d + 1, A=self.fe, lda=md.kf, B=S['time'], ldb=md.kf, M=I, N=4 * d, K=md.kf, epi=E['TFX_EPI_SILU'], C=self.cond, ldc=4 * d,
                      C2=self.pre, ldc2=4 * d, bias=pp('transformer.to_time_cond.1.bias'))
             self._nt(L, A=self.cond, lda=4 * d, B=S['ada'], ldb=4 * d, M=I, N=nt3, K=4 * d, epi=E['TFX_EPI_F32'], C=self.tables, ldc=nt3,
                      bias=pp('transformer.layers.0.1.to_film.bias'))
@@ -158,9 +177,9 @@ class Plan:
                     table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
             self._k(L, 'tfx_adaln_pre_fwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], u=self.uf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                     gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i))
-            self._nt(L, A=self.uf[i], lda=d, B=S[f'ff1{i}'], ldb=d, M=T, N=2 * dip, K=d, epi=E['TFX_EPI_GEGLU'], C=self.ag[i], ldc=2 * dip,
+            self._nt(L, algo_n=2 * md.di, A=self.uf[i], lda=d, B=S[f'ff1{i}'], ldb=d, M=T, N=2 * dip, K=d, epi=E['TFX_EPI_GEGLU'], C=self.ag[i], ldc=2 * dip,
                      C2=self.hm[i], ldc2=dip, bias=S[f'ff1b{i}'])
-            self._nt(L, A=self.hm[i], lda=dip, B=S[f'ff2{i}'], ldb=dip, M=T, N=d, K=dip, epi=E['TFX_EPI_BF16'], C=self.yf[i], ldc=d,
+            self._nt(L, algo_k=md.di, A=self.hm[i], lda=dip, B=S[f'ff2{i}'], ldb=dip, M=T, N=d, K=dip, epi=E['TFX_EPI_BF16'], C=self.yf[i], ldc=d,
                      bias=pp(f'{p}.2.fn.net.3.bias'))
             self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=self.xb[i], y=self.yf[i], out=self.hid[i + 1], tok_inst=self.tok_inst,
                     table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
@@ -197,6 +216,12 @@ class Plan:
         for a in getattr(self, '_rope_args', []):
             a.cos_tab, a.sin_tab = cos_tab.data_ptr(), sin_tab.data_ptr()
 
+    def set_segments(self, seg_start, seg_len):
+        n_seg = int(seg_start.numel())
+        self.seg_start[:n_seg].copy_(seg_start); self.seg_len[:n_seg].copy_(seg_len)
+        for a in self._seg_args:
+            a.n_seg = n_seg
+
     def set_loss_scales(self, ce_scale: float, mse_scales: dict):
         self._ce_args.grad_scale = ce_scale
         for t, s in mse_scales.items():
@@ -211,11 +236,11 @@ class Plan:
         pp, gp = ps.ptr, ps.grad_ptr
         lib = capi.lib()
         gmap = ps._maps['geglu']
-        self._nt(L, A=self.dlogits, lda=md.vp, B=S['logits_t'], ldb=md.vp, M=T, N=d, K=md.vp, epi=E['TFX_EPI_BF16'], C=self.dembed, ldc=d)
+        self._nt(L, algo_k=md.vocab, A=self.dlogits, lda=md.vp, B=S['logits_t'], ldb=md.vp, M=T, N=d, K=md.vp, epi=E['TFX_EPI_BF16'], C=self.dembed, ldc=d)
         self._tn(L, T, md.vocab, d, A=self.dlogits, lda=md.vp, a_cols=md.vp, B=self.embed, ldb=d, b_cols=d, C=gp('to_text_logits.weight'), ldc=d)
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
-            self._nt(L, A=lt['dpred'], lda=dlp, B=S[f'outp_t{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_RESID'], C=self.dembed, ldc=d,
+            self._nt(L, algo_k=dl, A=lt['dpred'], lda=dlp, B=S[f'outp_t{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_RESID'], C=self.dembed, ldc=d,
                      R=self.dembed, ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
             self._tn(L, r, dl, d, A=lt['dpred'], lda=dlp, a_cols=dlp, B=self.embed, ldb=d, b_cols=d, b_rowmap=self.row_tok[t],
                      C=gp(f'model_to_latent_projs.{t}.weight'), ldc=d)
@@ -236,21 +261,26 @@ class Plan:
             G = self.dH[i + 1]
             # ---- feedforward wrapper
             self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.yf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
-                    layerscale=pp(f'{p}.2.layerscale'), g=G, dy=self.dy, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'))
+                    layerscale=pp(f'{p}.2.layerscale'), g=G, dy=self.dy, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'),
+                    seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+            self._seg_args.append(L[-1][1])
             self._raw(L, lib.tfx_colsum_bf16, self.dy.data_ptr(), d, T, d, None, None, gp(f'{p}.2.fn.net.3.bias'))
             self._tn(L, T, d, di, A=self.dy, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
-            self._nt(L, A=self.dy, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=self.dag, ldc=2 * dip,
+            self._nt(L, algo_n=di, A=self.dy, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=self.dag, ldc=2 * dip,
                      aux=self.ag[i], ldaux=2 * dip)
             self._raw(L, lib.tfx_colsum_bf16, self.dag.data_ptr(), 2 * dip, T, 2 * dip, gmap.data_ptr(), None, gp(f'{p}.2.fn.net.0.bias'))
-            self._tn(L, T, 2 * dip, d, A=self.dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
+            self._tn(L, T, 2 * dip, d, algo_n=2 * di, A=self.dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
                      C=gp(f'{p}.2.fn.net.0.weight'), ldc=d)
-            self._nt(L, A=self.dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
+            self._nt(L, algo_k=2 * di, A=self.dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                     gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
-                    dtable=dtf, dgamma_text=gp(f'{p}.2.layernorm_gamma'))
+                    dtable=dtf, dgamma_text=gp(f'{p}.2.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+            self._seg_args.append(L[-1][1])
             # ---- attention wrapper
             self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.ya[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
-                    layerscale=pp(f'{p}.1.layerscale'), g=G, dy=self.dy, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'))
+                    layerscale=pp(f'{p}.1.layerscale'), g=G, dy=self.dy, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'),
+                    seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+            self._seg_args.append(L[-1][1])
             self._tn(L, T, d, hd, A=self.dy, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=hd)
             self._nt(L, A=self.dy, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
             self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
@@ -259,10 +289,11 @@ class Plan:
                     dqk=self.dqk, ld_dqk=2 * hd, dqkv=self.dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
             self._rope_args.append(L[-1][1])
             self._tn(L, T, md.nq, d, A=self.dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d)
-            self._nt(L, A=self.dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
+            self._nt(L, algo_k=md.nq, A=self.dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, tok_inst=self.tok_inst, table=ta, ld_table=nt3,
                     gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i), du=self.du, dx=G,
-                    dtable=dta, dgamma_text=gp(f'{p}.1.layernorm_gamma'))
+                    dtable=dta, dgamma_text=gp(f'{p}.1.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+            self._seg_args.append(L[-1][1])
             if md.has_skip(i):
                 sk = self.xres[src[i]]
                 self._tn(L, T, d, d, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
@@ -277,7 +308,8 @@ class Plan:
         self._raw(L, lib.tfx_add_bf16, g.data_ptr(), self.dH[0].data_ptr(), self.dx0.data_ptr(), T * d)
         if 0 in pushed:
             self._raw(L, lib.tfx_add_bf16, self.dx0.data_ptr(), self.dskip[0].data_ptr(), self.dx0.data_ptr(), T * d)
-        self._k(L, 'tfx_embed_bwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, dx=self.dx0, dtable=gp('text_embed.weight'))
+        self._raw(L, lib.tfx_onehot_bf16, self.text_ids.data_ptr(), self.tok_inst.data_ptr(), self.onehot.data_ptr(), T, md.vp)
+        self._tn(L, T, md.vocab, d, A=self.onehot, lda=md.vp, a_cols=md.vp, B=self.dx0, ldb=d, b_cols=d, C=gp('text_embed.weight'), ldc=d)
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
             self._tn(L, r, d, dl, A=self.dx0, lda=d, a_cols=d, a_rowmap=self.row_tok[t], B=lt['xt'], ldb=dlp, b_cols=dlp,

@@ -147,3 +147,43 @@ def token_maps(P: PackedBatch, n: int, num_modalities: int, rot_offset: int = 0)
     rot = ar[None, :] - np.cumsum(extra, axis=1, dtype=np.int32) + rot_offset
     return TokenMaps(n=n, tok_inst=tok_inst, kv_end=kv_end.astype(np.int32), q_start=q_start.astype(np.int32),
                      rot_pos=rot.astype(np.int32), is_type=counts)
+
+
+def fast_signature(modalities):
+    """one cheap pass over the ragged input: (hashable structure signature, user text tensors in scan order,
+    latent tensors per type in scan order).  The signature keys the structure cache: batches with the same
+    part kinds / lengths / shapes reuse every index array (already resident on the device)."""
+    sig, texts, lats = [], [], {}
+    for sample in modalities:
+        ss = []
+        for part in sample:
+            if type(part) is tuple:
+                ty, x = part[0], part[1]
+                ss.append((ty, *x.shape))
+                lats.setdefault(ty, []).append(x if x.ndim == 2 else x.reshape(-1, x.shape[-1]))
+            elif part.dtype.is_floating_point:
+                ss.append((0, *part.shape))
+                lats.setdefault(0, []).append(part if part.ndim == 2 else part.reshape(-1, part.shape[-1]))
+            else:
+                ss.append(part.numel())
+                texts.append(part if part.ndim == 1 else part.reshape(-1))
+        sig.append(tuple(ss))
+    return tuple(sig), texts, lats
+
+
+def token_segments(tok_inst: np.ndarray, max_text_run: int = 8):
+    """runs of consecutive tokens (within a sample row) sharing one tok_inst value; text runs are chopped to
+    <= max_text_run tokens so the waves that own them stay balanced.  Returns flat (start, length) arrays."""
+    b, n = tok_inst.shape
+    starts, lens = [], []
+    for bi in range(b):
+        row = tok_inst[bi]
+        cut = np.flatnonzero(np.diff(row)) + 1
+        bounds = np.concatenate(([0], cut, [n]))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            if row[lo] >= 0:
+                starts.append(bi * n + lo); lens.append(hi - lo)
+            else:
+                for s in range(lo, hi, max_text_run):
+                    starts.append(bi * n + s); lens.append(min(max_text_run, hi - s))
+    return np.asarray(starts, dtype=np.int32), np.asarray(lens, dtype=np.int32)

@@ -15,7 +15,7 @@ from torch import nn
 
 from . import capi
 from .engine import Plan
-from .packing import PackedBatch, is_int_tensor, scan_batch, token_maps
+from .packing import PackedBatch, fast_signature, is_int_tensor, scan_batch, token_maps, token_segments
 from .params import ModelDims, ParamStore
 
 
@@ -125,6 +125,7 @@ class Transfusion(nn.Module):
                             dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor)
         self.store = ParamStore(self.md, self)
         self._plans = {}
+        self._struct_cache = {}
         self._step_id = 0
         self._live = None
         self._anchor = None
@@ -142,6 +143,7 @@ class Transfusion(nn.Module):
         self.store.fourier_w = self.transformer.to_time_cond[0].weights
         self.store.reflatten(dev)
         self._plans.clear()
+        self._struct_cache.clear()
         self._rope = None
         return out
 
@@ -173,16 +175,44 @@ class Transfusion(nn.Module):
             self._plans[key] = Plan(self.store, b, n, I, R, training=training)
         return self._plans[key]
 
+    def _build_structure(self, modalities, return_loss):
+        """full structure scan (host) + upload of every derived index array; cached per structure signature."""
+        dev = self.device
+        P = self._scan(modalities, add_sos_eos=return_loss)
+        b = P.b
+        n = P.n_full - 1 if return_loss else P.n_full
+        tm = token_maps(P, n, self.num_modalities)
+        seg_start, seg_len = token_segments(tm.tok_inst)
+        D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        R = {t: int(len(v)) for t, v in P.row_inst.items()}
+        row_tok = {}
+        for t in R:
+            rp = P.row_pos[t].astype(np.int64)
+            rb, rl = rp // P.n_full, rp % P.n_full
+            row_tok[t] = D(np.where(rl < n, rb * n + rl, -1).astype(np.int32))
+        tok_inst = D(tm.tok_inst)
+        S = dict(P=P, tm=tm, b=b, n=n, I=len(P.inst_b), R=R, num_mod=np.bincount(P.inst_b, minlength=b),
+                 text_host=D(P.text_host), text_dest=D(P.text_dest), cfg_droppable=D(P.cfg_droppable), tok_inst=tok_inst,
+                 kv_end=D(tm.kv_end.reshape(-1)), q_start=D(tm.q_start.reshape(-1)), rot_pos=D(tm.rot_pos.reshape(-1)),
+                 is_mod=tok_inst >= 0, minus1=torch.full((b, n), -1, dtype=torch.int32, device=dev),
+                 inst_b=D(P.inst_b), inst_m=D(P.inst_m), row_tok=row_tok, row_inst={t: D(P.row_inst[t]) for t in R},
+                 seg_start=D(seg_start), seg_len=D(seg_len))
+        S['num_mod_dev'] = D(S['num_mod'].astype(np.float32))
+        P.user_text, P.latents = None, None          # the cache keeps structure only, never the caller's tensors
+        return S
+
     def _scan(self, modalities, add_sos_eos):
         return scan_batch(modalities, num_modalities=self.num_modalities, dim_latents=self.dim_latents, sos_id=self.sos_id, eos_id=self.eos_id,
                           meta_id=self.meta_id, som_ids=self.som_ids, eom_ids=self.eom_ids, add_sos_eos=add_sos_eos)
 
-    def _default_times(self, num_modalities_host: np.ndarray):
-        """default_modality_length_to_time_fn, T:186-200 (device RNG)."""
+    def _default_times(self, num_modalities_host: np.ndarray, nm=None):
+        """default_modality_length_to_time_fn, T:186-200 (device RNG).  `nm`: cached device copy of the counts
+        (a pageable host->device copy here would serialise the host with the GPU queue every step)."""
         b, m = len(num_modalities_host), int(num_modalities_host.max()) if len(num_modalities_host) else 0
         if m == 0:
             return torch.empty((b, 0), device=self.device)
-        nm = torch.from_numpy(num_modalities_host.astype(np.float32)).to(self.device)
+        if nm is None:
+            nm = torch.from_numpy(num_modalities_host.astype(np.float32)).to(self.device)
         rand_num = torch.floor(torch.rand(b, device=self.device) * nm)
         seq = torch.arange(m, device=self.device)
         prev = seq[None, :] < rand_num[:, None]
@@ -205,55 +235,50 @@ class Transfusion(nn.Module):
         stream = self._stream()
         ps, md = self.store, self.md
 
-        P = self._scan(modalities, add_sos_eos=return_loss)
-        b = P.b
-        n = P.n_full - 1 if return_loss else P.n_full
-        tm = token_maps(P, n, self.num_modalities)
-        I = len(P.inst_b)
-        R = {t: int(len(v)) for t, v in P.row_inst.items()}
+        # ---- structure: one cheap signature pass; everything derived from it is cached ON THE DEVICE per signature
+        sig, user_text, latents = fast_signature(modalities)
+        S = self._struct_cache.get((sig, return_loss))
+        if S is None:
+            if len(self._struct_cache) > 16:
+                self._struct_cache.clear()
+            S = self._struct_cache[(sig, return_loss)] = self._build_structure(modalities, return_loss)
+        P, tm, b, n, I, R = S['P'], S['tm'], S['b'], S['n'], S['I'], S['R']
 
         # ---- times (T:3075-3082)
-        num_mod = np.bincount(P.inst_b, minlength=b)
         if times is None:
             fn = num_modalities_to_times_fn
-            times = fn(torch.from_numpy(num_mod).to(dev)) if fn is not None else self._default_times(num_mod)
+            times = fn(S['num_mod_dev'].long()) if fn is not None else self._default_times(S['num_mod'], S['num_mod_dev'])
         times = times.to(dev, torch.float32)
 
         ps.refresh_shadows(stream)
         plan = self._plan(b, n, I, R, training=return_loss)
-        plan.set_rope_tables(*self._rope_tables(int(tm.rot_pos.max()) if tm.rot_pos.size else 0))
+        if plan.loaded_structure is not S:
+            plan.set_rope_tables(*self._rope_tables(int(tm.rot_pos.max()) if tm.rot_pos.size else 0))
+            plan.tok_inst.copy_(S['tok_inst'].view(-1)); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['q_start']); plan.rot_pos.copy_(S['rot_pos'])
+            plan.set_segments(S['seg_start'], S['seg_len'])
+            for t in R:
+                plan.row_tok[t].copy_(S['row_tok'][t]); plan.row_inst[t].copy_(S['row_inst'][t])
+            plan.loaded_structure = S
 
         # ---- token ids on device (values never visit the host)
-        text_full = torch.from_numpy(P.text_host).to(dev, non_blocking=True)
-        if P.user_text:
-            vals = torch.cat([t.reshape(-1) for t in P.user_text]).to(dev, torch.int32)
-            text_full.view(-1).index_copy_(0, torch.from_numpy(P.text_dest).to(dev), vals)
+        text_full = S['text_host'].clone()
+        if user_text:
+            vals = torch.cat(user_text).to(dev, torch.int32)
+            text_full.view(-1).index_copy_(0, S['text_dest'], vals)
         prob_uncond = self.prob_uncond if prob_uncond is None else prob_uncond
         if self.training and prob_uncond > 0:                                              # CFG text drop, T:3027-3043
             drop_rows = torch.rand(b, device=dev) < prob_uncond
-            mask = torch.from_numpy(P.cfg_droppable).to(dev) & drop_rows[:, None]
-            text_full = text_full.masked_fill(mask, self.null_text_id)
-        tok_inst = torch.from_numpy(tm.tok_inst).to(dev, non_blocking=True)
-        plan.tok_inst.copy_(tok_inst.view(-1))
-        plan.kv_end.copy_(torch.from_numpy(tm.kv_end).view(-1), non_blocking=True)
-        plan.q_start.copy_(torch.from_numpy(tm.q_start).view(-1), non_blocking=True)
-        plan.rot_pos.copy_(torch.from_numpy(tm.rot_pos).view(-1), non_blocking=True)
+            text_full = text_full.masked_fill(S['cfg_droppable'] & drop_rows[:, None], self.null_text_id)
         plan.text_ids.copy_(text_full[:, :n].reshape(-1))
         if return_loss:
             lab = text_full[:, 1:]                                                          # T:3144
-            lab = torch.where((tok_inst >= 0) | (lab == self.null_text_id), torch.full_like(lab, -1), lab)   # T:3320-3323
+            lab = torch.where(S['is_mod'] | (lab == self.null_text_id), S['minus1'], lab)    # T:3320-3323
             plan.labels.copy_(lab.reshape(-1))
         if I > 0:
-            it = times[torch.from_numpy(P.inst_b).to(dev), torch.from_numpy(P.inst_m).to(dev)]
-            plan.inst_time.copy_(it)
+            plan.inst_time.copy_(times[S['inst_b'], S['inst_m']])
         for t in R:
-            rp = P.row_pos[t].astype(np.int64)
-            rb, rl = rp // P.n_full, rp % P.n_full
-            row_tok = np.where(rl < n, rb * n + rl, -1).astype(np.int32)
-            plan.row_tok[t].copy_(torch.from_numpy(row_tok), non_blocking=True)
-            plan.row_inst[t].copy_(torch.from_numpy(P.row_inst[t]), non_blocking=True)
             lt = plan.lat[t]
-            lt['x'].copy_(torch.cat(P.latents[t]), non_blocking=True)        # one cat on the source device, one transfer
+            lt['x'].copy_(torch.cat(latents[t]), non_blocking=True)          # one cat on the source device, one transfer
             if return_loss:
                 if self._noise_override is not None:
                     lt['eps'].copy_(self._noise_override[t])
