@@ -76,11 +76,14 @@ def cpu_baseline(budget_s=25.0):
     """the oracle restatement ("port") on the host cores: 1 train step (fwd+bwd+clip+Adam) on a bounded sample."""
     from oracle import detdata as D
     from oracle.transfusion_oracle import OracleConfig, train_step
-    torch.set_num_threads(os.cpu_count())
+    # 256 torch threads on the GPU box's host oversubscribe badly on these small ops (measured: 469 s / step);
+    # 32 threads is the sweet spot of the oracle's einsum-heavy graph - `cores` reports the threads actually used
+    threads = min(32, os.cpu_count())
+    torch.set_num_threads(threads)
     cfg = OracleConfig(num_text_tokens=256, dim=512, depth=8, dim_latents=(384,))
     sd = D.det_state_dict(cfg.state_dict_shapes(), tag='bench')
     sd = {k: (v.clone().requires_grad_(True) if k not in ('rotary_emb.freqs', 'transformer.to_time_cond.0.weights') else v) for k, v in sd.items()}
-    bs = 2
+    bs = 1
     batch = D.canonical_batch(bs, key='bench')
     times = D.det_times('bench/t', batch)
     noise = D.det_noise('bench/n', batch, 1)
@@ -91,7 +94,7 @@ def cpu_baseline(budget_s=25.0):
         t0 = time.time(); train_step(sd, cfg, batch, times, noise, state); dt = time.time() - t0
         tsum += dt; steps += 1
     per_step = (tsum / steps) if steps else t1
-    return {'value': bs / per_step, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
+    return {'value': bs / per_step, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
             'sample': f'oracle restatement (torch fp32 CPU), dim512/depth8, batch {bs} x 1024 canonical samples, '
                       f'{"1 warm-up + " + str(steps) + " timed" if steps else "1 timed (cold)"} step(s) of fwd+bwd+clip+Adam'}
 

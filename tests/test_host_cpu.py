@@ -1,0 +1,88 @@
+"""CPU-only checks (-m "not gpu"): the C-ABI library loads and exports every symbol include/tfx.h declares, the
+host packer reproduces the reference's packed layout (via the oracle's restatement), and the product path refuses
+to run without the HIP device."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.cases import build_case
+from oracle.transfusion_oracle import kv_end_from_positions, pack_batch, rotary_positions
+from transfusion_pytorch_amd import Transfusion, capi
+from transfusion_pytorch_amd.packing import fast_signature, scan_batch, token_maps, token_segments
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    assert os.path.exists(capi.LIB_PATH), 'run `python -m transfusion_pytorch_amd.build` (hipcc cross-compiles gfx950 without a GPU)'
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    assert len(capi.FUNCTIONS) >= 30
+    for name in capi.FUNCTIONS:
+        assert hasattr(lib, name), f'{name} declared in include/tfx.h but not exported by libtfx_hip.so'
+    assert capi.lib().tfx_version().startswith(b'tfx-hip gfx950')
+    # every struct of the header became a ctypes Structure with pointer-aligned layout
+    for name, S in capi.STRUCTS.items():
+        assert ctypes.sizeof(S) % 8 == 0 or all(t is not ctypes.c_void_p for _, t in S._fields_), name
+
+
+def _native(cfg):
+    dl = cfg.dim_latents if len(cfg.dim_latents) > 1 else cfg.dim_latents[0]
+    return Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=dl,
+                       transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+
+
+@pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'canon512'])
+def test_packer_matches_reference_layout(name):
+    cfg, sd, batch, times, noise = build_case(name)
+    m = _native(cfg)
+    assert set(m.state_dict()) == set(cfg.state_dict_shapes())
+    for k, shp in cfg.state_dict_shapes().items():
+        assert tuple(m.state_dict()[k].shape) == tuple(shp), k
+    P = m._scan(batch, add_sos_eos=True)
+    O = pack_batch(cfg, batch)                                  # oracle restatement of MP:206-377 (pinned to the reference)
+    assert P.positions == O.positions and P.total_tokens == O.total_tokens and P.n_full == O.text.shape[1]
+    text = P.text_host.copy().reshape(-1)
+    text[P.text_dest] = torch.cat([t.reshape(-1) for t in P.user_text]).numpy()
+    assert np.array_equal(text.reshape(O.text.shape), O.text.numpy())
+    n = P.n_full - 1
+    tm = token_maps(P, n, cfg.num_modalities)
+    assert np.array_equal(tm.kv_end, kv_end_from_positions(O.positions, P.b, n).numpy())
+    assert np.array_equal(tm.rot_pos, rotary_positions(O.positions, P.b, n).numpy())
+    # q_start is the inverse view of kv_end: key j is visible to query i  <=>  i >= q_start[j]
+    i = np.arange(n)
+    for bi in range(P.b):
+        vis_q = i[None, :] < tm.kv_end[bi][:, None]            # [query, key]
+        vis_k = i[:, None] >= tm.q_start[bi][None, :]
+        assert np.array_equal(vis_q, vis_k)
+    ss, sl = token_segments(tm.tok_inst)
+    assert sl.sum() == P.b * n and (sl > 0).all()
+    flat = tm.tok_inst.reshape(-1)
+    for s0, l0 in zip(ss[:200], sl[:200]):
+        assert (flat[s0:s0 + l0] == flat[s0]).all()
+    sig, texts, lats = fast_signature(batch)
+    assert len(texts) == len(P.user_text) and {t: len(v) for t, v in lats.items()} == {t: len(v) for t, v in P.latents.items()}
+
+
+def test_state_dict_roundtrip_and_flat_views():
+    cfg, sd, batch, times, noise = build_case('tiny1')
+    m = _native(cfg)
+    m.load_state_dict(sd, strict=True)
+    for k, v in sd.items():
+        assert torch.equal(m.state_dict()[k], v), k
+    # parameters are views into ONE flat buffer
+    k = 'transformer.layers.1.2.fn.net.0.weight'
+    m.store.view(k).add_(1.0)
+    assert torch.equal(m.state_dict()[k], sd[k] + 1.0)
+
+
+def test_unsupported_options_raise_and_no_cpu_fallback():
+    with pytest.raises(AssertionError):
+        Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1), modality_processing='nope')
+    with pytest.raises(NotImplementedError):
+        Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1, dim_head=8))
+    with pytest.raises(NotImplementedError):
+        Transfusion(num_text_tokens=8, dim_latent=16, add_pos_emb=True, transformer=dict(dim=64, depth=1, heads=1))
+    m = Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1))
+    with pytest.raises(capi.TfxError):
+        m([[torch.randint(0, 8, (4,)), torch.randn(2, 16)]])

@@ -238,8 +238,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   // chunk and re-read by the other tiles from that XCD's L2.  splits is a multiple of 8 (launcher).
   const int ntile = ntn * ntk;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int split = xcd + 8 * (local / ntile);
-  const int bid = local % ntile;
+  // splits == 1 (many tiles, few rows: e.g. the AdaLN weight gradient): one block per tile over all rows
+  const int split = p.splits == 1 ? 0 : xcd + 8 * (local / ntile);
+  const int bid = p.splits == 1 ? xcd_remap(blockIdx.x, gridDim.x) : local % ntile;
   const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
   const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
   const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
@@ -475,8 +476,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTN p) {
   const int ntn = (p.N + 127) / 128, ntk = (p.K + 127) / 128;
   const int ntile = ntn * ntk;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int split = xcd + 8 * (local / ntile);
-  const int bid = local % ntile;
+  // splits == 1 (many tiles, few rows: e.g. the AdaLN weight gradient): one block per tile over all rows
+  const int split = p.splits == 1 ? 0 : xcd + 8 * (local / ntile);
+  const int bid = p.splits == 1 ? xcd_remap(blockIdx.x, gridDim.x) : local % ntile;
   const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
   const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
   const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
@@ -597,7 +599,7 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
     attr_set = true;
   }
   GemmTN q = p;
-  q.splits = (p.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernel's block order)
+  q.splits = p.splits == 1 ? 1 : (p.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernel's block order)
   int grid = ((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
   if (use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8)
     hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(grid), dim3(256), 2 * 2 * TN_BMK * 128 * 2, s, q);

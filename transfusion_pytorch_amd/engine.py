@@ -108,12 +108,14 @@ class Plan:
         # that minimises (block waves per XCD) x (rows per block) plus a small price for the fp32 atomics per split
         # (measured on MI355X with tools/bench_gemm.py).
         best, splits = None, 8
-        for s in (8, 16, 24, 32, 48, 64):
+        for s in (() if tiles >= 512 else (8, 16, 24, 32, 48, 64)):
             if s > 8 and M // s < 256:
                 break
             cost = -(-(tiles * s // 8) // 64) * (8.0 / s) + 0.004 * s
             if best is None or cost < best - 1e-9:
                 best, splits = cost, s
+        if tiles >= 512:
+            splits = 1            # enough tiles to fill the chip: no split, no extra atomics
         kw.setdefault('k_valid', K)
         algo_n = kw.pop('algo_n', None)
         a = capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, splits=splits, accumulate=1, alpha=1.0, **kw)
