@@ -44,7 +44,20 @@ TFX_DEV bf16x8 g_rowfrag(const bf16* base, int ld, int row, int nrows, int ks) {
   row = min(row, nrows - 1);
   return *(const bf16x8*)(base + (size_t)row * ld + 16 * ks + 8 * (l >> 5));
 }
-TFX_DEV float fast_tanh(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+// tanh for the soft-cap.  Scores are q~.k~ with |q~|,|k~| bounded by the QK-RMSNorm gains, so x = s/cap is small:
+// the odd Taylor polynomial to x^9 is exact to 1.3e-6 for |x| <= 0.45 and costs 6 plain VALU ops; if ANY lane of the
+// wave exceeds the bound the whole wave takes the exact exp2/rcp form (wave-uniform branch, no divergence).
+TFX_DEV float tanh_poly(float x) {
+  const float x2 = x * x;
+  return x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+}
+TFX_DEV float tanh_exact(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (2.f * LOG2E))); }
+TFX_DEV float wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
 TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
   bf16x8 o;
 #pragma unroll
@@ -81,8 +94,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) o[i][r] = 0.f;
-  float m = -INFINITY, lsum = 0.f;
-  const float cap = p.softcap, icap = 1.f / p.softcap;
+  float m = -INFINITY, lsum = 0.f;             // running max / sum in the log2 domain
+  const float icap = 1.f / p.softcap, cap2 = p.softcap * LOG2E;
+  const int kve_min = wave_min_i(kve);
 
   TileRegs kr, vr;
   tile_gload(kr, kb_, p.ld_k, 0, n);
@@ -101,24 +115,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) s[kb] = MFMA(lds_rowfrag(Ks, kb * 32, ks), qf[ks], s[kb]);   // S^T[key][q]
     }
+    // soft-cap in the log2 domain: s2 = cap*log2e * tanh(s/cap)
+    float amax = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[kb][r]));
+    const bool exact = __any(amax * icap > 0.45f);
+    const bool need_mask = (j + 1) * 64 > kve_min;            // wave-uniform: interior tiles skip the compare/select
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float v = cap * fast_tanh(s[kb][r] * icap);
-        v = key < kve ? v : -INFINITY;
+        const float x = s[kb][r] * icap;
+        float v = cap2 * (exact ? tanh_exact(x) : tanh_poly(x));
+        if (need_mask) {
+          const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          v = key < kve ? v : -INFINITY;
+        }
         s[kb][r] = v; mx = fmaxf(mx, v);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);             // finite after tile 0 (key 0 is visible to every query)
-    const float alpha = __expf(m - mn);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
     float ps = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) { float e = __expf(s[kb][r] - mn); s[kb][r] = e; ps += e; }
+      for (int r = 0; r < 16; r++) { float e = __builtin_amdgcn_exp2f(s[kb][r] - mn); s[kb][r] = e; ps += e; }
     ps += __shfl_xor(ps, 32, 64);
     lsum = lsum * alpha + ps; m = mn;
 #pragma unroll
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   }
   if (qrow < n) {
     const float g = sigmoidf_(bf2f(p.gate[(tok0 + qrow) * p.ld_gate + h]));
-    const float sc = g / lsum;
+    const float sc = g * __builtin_amdgcn_rcpf(lsum);
     bf16* op = p.out + (tok0 + qrow) * p.ld_out + h * DH;
 #pragma unroll
     for (int db = 0; db < 2; db++)
@@ -148,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
         for (int e = 0; e < 4; e++) v[e] = f2bf(o[db][rg * 4 + e] * sc);
         *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
       }
-    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = m + __logf(lsum);
+    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = (m + __log2f(lsum)) * LN2;
   }
 }
 
@@ -196,8 +221,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
   const int kve = p.kv_end[tok0 + qc];
   const int kv_limit = p.kv_end[tok0 + min(q0 + 127, n - 1)];
   const int nt = (kv_limit + 63) / 64;
-  const float lse = p.lse[((size_t)b * p.h + h) * n + qc];
+  const float lse2 = p.lse[((size_t)b * p.h + h) * n + qc] * LOG2E;
   const float dlt = p.delta[((size_t)b * p.h + h) * n + qc];
+  const int kve_min = wave_min_i(kve);
 
   bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
-  const float cap = p.softcap, icap = 1.f / p.softcap;
+  const float icap = 1.f / p.softcap, cap2 = p.softcap * LOG2E;
 
   TileRegs kr, vr;
   tile_gload(kr, kb_, p.ld_k, 0, n);
@@ -217,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
     tile_sstore(kr, Ks); tile_sstore(vr, Vs);
     __syncthreads();
     if (j + 1 < nt) { tile_gload(kr, kb_, p.ld_k, (j + 1) * 64, n); tile_gload(vr, vb, p.ld_v, (j + 1) * 64, n); }
+    const bool need_mask = (j + 1) * 64 > kve_min;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
       f32x16 s, dp;
@@ -227,11 +254,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
         s = MFMA(lds_rowfrag(Ks, kb * 32, ks), qf[ks], s);         // S^T[key][q]
         dp = MFMA(lds_rowfrag(Vs, kb * 32, ks), dof[ks], dp);      // dP^T[key][q]
       }
+      float amax = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[r]));
+      const bool exact = __any(amax * icap > 0.45f);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float th = fast_tanh(s[r] * icap);
-        const float pr = key < kve ? __expf(cap * th - lse) : 0.f;
+        const float x = s[r] * icap;
+        const float th = exact ? tanh_exact(x) : tanh_poly(x);
+        float pr = __builtin_amdgcn_exp2f(cap2 * th - lse2);
+        if (need_mask) {
+          const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          pr = key < kve ? pr : 0.f;
+        }
         s[r] = pr * (dp[r] - dlt) * (1.f - th * th);               // dS_raw^T
       }
 #pragma unroll
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
 // ------------------------------------------------------------------------------------------------
 // backward dK/dV: block = 128 keys (4 waves x 32), loop over 64-query tiles that can see them
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(tfx_attn_args p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(16))) bf16 Qs[64 * LDT];
   __shared__ __attribute__((aligned(16))) bf16 Ds[64 * LDT];
   __shared__ __attribute__((aligned(16))) float s_lse[64], s_dlt[64];
@@ -287,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-  const float cap = p.softcap, icap = 1.f / p.softcap;
+  const float icap = 1.f / p.softcap, cap2 = p.softcap * LOG2E;
 
   TileRegs qr, dr;
   tile_gload(qr, qb, p.ld_q, qt0 * 64, n);
@@ -298,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(tfx_attn_args p) {
     if (threadIdx.x < 64) {
       const int qi = jt * 64 + threadIdx.x;
       const int qcl = min(qi, n - 1);
-      s_lse[threadIdx.x] = lseb[qcl];
+      s_lse[threadIdx.x] = lseb[qcl] * LOG2E;
       s_dlt[threadIdx.x] = dltb[qcl];
       s_kve[threadIdx.x] = qi < n ? p.kv_end[tok0 + qcl] : 0;       // rows past the end see nothing
     }
@@ -314,6 +349,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(tfx_attn_args p) {
         s = MFMA(lds_rowfrag(Qs, qb2 * 32, ks), kf[ks], s);       // S[q][key]
         dp = MFMA(lds_rowfrag(Ds, qb2 * 32, ks), vf[ks], dp);     // dP[q][key]
       }
+      float amax = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[r]));
+      const bool exact = __any(amax * icap > 0.45f);
       f32x16 pr;
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
@@ -323,8 +362,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(tfx_attn_args p) {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int r = rg * 4 + e;
-          const float th = fast_tanh(s[r] * icap);
-          const float pv = krow < kv4[e] ? __expf(cap * th - ls4[e]) : 0.f;
+          const float x = s[r] * icap;
+          const float th = exact ? tanh_exact(x) : tanh_poly(x);
+          const float pv = krow < kv4[e] ? __builtin_amdgcn_exp2f(cap2 * th - ls4[e]) : 0.f;
           pr[r] = pv;
           s[r] = pv * (dp[r] - dl4[e]) * (1.f - th * th);          // dS_raw[q][key]
         }
