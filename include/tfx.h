@@ -90,6 +90,7 @@ typedef struct {
   float* lse;                 /* [b, h, n] */
   int32_t b, h, n;
   float softcap;
+  int32_t n_kv;               /* forward only: keys/values have n_kv rows per sample (KV-cache decode); 0 = n */
   /* backward */
   const tfx_bf16* dout; int32_t ld_dout;     /* grad wrt gated output */
   tfx_bf16* do_eff; int32_t ld_do;           /* scratch: dout * sigmoid(gate) */
@@ -225,6 +226,8 @@ int tfx_cast_rows_t(const tfx_cast_args* a, void* stream);
 int tfx_gather_f32(const float* src, const int32_t* map, float* dst, int32_t n, void* stream);
 /* out[t][c] (bf16, ld % 8 == 0) = 1 if token t is text and max(ids[t],0) == c else 0  (embedding-gradient GEMM operand) */
 int tfx_onehot_bf16(const int32_t* ids, const int32_t* tok_inst, tfx_bf16* out, int32_t T, int32_t ld, void* stream);
+/* dst[rowmap[r]][0:cols] = src[r][0:cols] for rowmap[r] >= 0   (KV-cache append; bf16, cols % 8 == 0) */
+int tfx_scatter_rows_bf16(const tfx_bf16* src, int32_t ld_src, int32_t cols, tfx_bf16* dst, int32_t ld_dst, const int32_t* rowmap, int32_t R, void* stream);
 int tfx_f32_to_bf16(const float* src, tfx_bf16* dst, int64_t n, void* stream);
 /* dst(bf16) = a(bf16) * silu'(pre(bf16))  (time-MLP backward) */
 int tfx_silu_bwd(const tfx_bf16* dy, const tfx_bf16* pre, tfx_bf16* dx, int64_t n, void* stream);

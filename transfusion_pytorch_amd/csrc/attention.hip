@@ -74,11 +74,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(16))) bf16 Vs[64 * LDT];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
   const int n = p.n, h = blockIdx.y, b = blockIdx.z;
+  const int nkv = p.n_kv > 0 ? p.n_kv : n;                       // KV-cache decode: keys live in a longer per-sample buffer
   const int q0 = blockIdx.x * 128;
-  const size_t tok0 = (size_t)b * n;
+  const size_t tok0 = (size_t)b * n, tokk = (size_t)b * nkv;
   const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
-  const bf16* kb_ = p.k + tok0 * p.ld_k + h * DH;
-  const bf16* vb = p.v + tok0 * p.ld_v + h * DH;
+  const bf16* kb_ = p.k + tokk * p.ld_k + h * DH;
+  const bf16* vb = p.v + tokk * p.ld_v + h * DH;
   const int qrow = q0 + w * 32 + (l & 31);
   const int qc = min(qrow, n - 1);
   const int kve = p.kv_end[tok0 + qc];
@@ -99,13 +100,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   const int kve_min = wave_min_i(kve);
 
   TileRegs kr, vr;
-  tile_gload(kr, kb_, p.ld_k, 0, n);
-  tile_gload(vr, vb, p.ld_v, 0, n);
+  tile_gload(kr, kb_, p.ld_k, 0, nkv);
+  tile_gload(vr, vb, p.ld_v, 0, nkv);
   for (int j = 0; j < nt; j++) {
     __syncthreads();
     tile_sstore(kr, Ks); tile_sstore(vr, Vs);
     __syncthreads();
-    if (j + 1 < nt) { tile_gload(kr, kb_, p.ld_k, (j + 1) * 64, n); tile_gload(vr, vb, p.ld_v, (j + 1) * 64, n); }
+    if (j + 1 < nt) { tile_gload(kr, kb_, p.ld_k, (j + 1) * 64, nkv); tile_gload(vr, vb, p.ld_v, (j + 1) * 64, nkv); }
 
     f32x16 s[2];
 #pragma unroll

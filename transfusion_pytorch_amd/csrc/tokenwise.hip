@@ -761,6 +761,14 @@ __global__ void onehot_k(const int* ids, const int* tok_inst, bf16* out, int T, 
   for (int e = 0; e < 8; e++) o[e] = f2bf(c + e == id ? 1.f : 0.f);
   *(bf16x8*)(out + i) = o;
 }
+__global__ void scatter_rows_k(const bf16* src, int ld_src, int cols, bf16* dst, int ld_dst, const int* rowmap, int R) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = cols / 8;
+  if (i >= (long long)R * cpr) return;
+  const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+  const int ro = rowmap[r];
+  if (ro >= 0) *(bf16x8*)(dst + (size_t)ro * ld_dst + c) = *(const bf16x8*)(src + (size_t)r * ld_src + c);
+}
 __global__ void gather_f32_k(const float* src, const int* map, float* dst, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : 0.f;
@@ -928,6 +936,11 @@ int tfx_onehot_bf16(const int32_t* ids, const int32_t* tok_inst, tfx_bf16* out, 
   if (T == 0) return 0; if (ld % 8) return -1;
   long long n = (long long)T * ld / 8;
   hipLaunchKernelGGL(onehot_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(s), ids, tok_inst, out, T, ld); RET();
+}
+int tfx_scatter_rows_bf16(const tfx_bf16* src, int32_t ld_src, int32_t cols, tfx_bf16* dst, int32_t ld_dst, const int32_t* rowmap, int32_t R, void* s) {
+  if (R == 0) return 0; if (cols % 8 || ld_src % 8 || ld_dst % 8) return -1;
+  long long n = (long long)R * (cols / 8);
+  hipLaunchKernelGGL(scatter_rows_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(s), src, ld_src, cols, dst, ld_dst, rowmap, R); RET();
 }
 int tfx_gather_f32(const float* src, const int32_t* map, float* dst, int32_t n, void* s) {
   if (n == 0) return 0; hipLaunchKernelGGL(gather_f32_k, dim3((n + 255) / 256), dim3(256), 0, ST(s), src, map, dst, n); RET();

@@ -42,8 +42,13 @@ def skip_sources(md: ModelDims):
 
 
 class Plan:
-    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True):
+    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None):
+        """cache: None, or a KV cache tensor [depth, b, maxlen, 2*heads*64] (k~ | v per token).  With a cache the plan is a
+        DECODE step: each layer appends this step's k~ / v rows at `cache_pos` (flat row b*maxlen + position, -1 = skip) and
+        attention reads keys / values from the cache (per-token visible length in `kv_end`)."""
         md = ps.md
+        self.cache = cache
+        assert cache is None or not training
         self.ps, self.md, self.b, self.n, self.I, self.R = ps, md, b, n, I, dict(R)
         self.T = T = b * n
         dev = ps.device
@@ -83,6 +88,7 @@ class Plan:
         self.loaded_structure = None
         self._seg_args = []
         self.seg_start = z(max(T, 1), dtype=torch.int32); self.seg_len = z(max(T, 1), dtype=torch.int32)
+        self.cache_pos = z(max(T, 1), dtype=torch.int32)
         self._build_forward()
         if training:
             self.dH = e(D + 1, T, d)
@@ -173,6 +179,11 @@ class Plan:
                     gamma_q=pp(f'{p}.1.fn.q_norm.gamma'), gamma_k=pp(f'{p}.1.fn.k_norm.gamma'), rot_pos=self.rot_pos,
                     cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5)
             self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
+            if self.cache is not None:
+                lib = capi.lib()
+                ck = self.cache[i]                                   # [b, maxlen, 2*hd]
+                self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkr, i) + 2 * hd, 2 * hd, hd, ck.data_ptr(), 2 * hd, self.cache_pos.data_ptr(), T)
+                self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkvg, i) + 2 * 2 * hd, ldq, hd, ck.data_ptr() + 2 * hd, 2 * hd, self.cache_pos.data_ptr(), T)
             self._k(L, 'tfx_attn_fwd', 'tfx_attn_args', **self._attn_kw(i))
             self._nt(L, A=self.og[i], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[i], ldc=d)
             self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[i], out=self.xb[i], tok_inst=self.tok_inst,
@@ -191,6 +202,15 @@ class Plan:
         self.fwd_embed_end = len(L)          # launches up to here produce `embed` (return_embed / decode paths stop here)
         self._nt(L, A=self.embed, lda=d, B=S['logits'], ldb=d, M=T, N=md.vocab, K=d, epi=E['TFX_EPI_F32'], C=self.logits, ldc=md.vp)
         self.fwd_logits_end = len(L)
+        if self.cache is not None:
+            # decode plans: flow prediction only (model_to_latent on the modality rows), no losses.  `row_src` = row_tok with
+            # the dropped rows (-1) clamped to 0, so the gather never reads out of bounds (those rows are ignored by the caller)
+            self.row_src = {t: torch.zeros(r, device=self.ps.device, dtype=torch.int32) for t, r in self.R.items()}
+            for t, r in self.R.items():
+                dl = md.dim_latents[t]; lt = self.lat[t]
+                self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_src[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
+            self.fwd_pred_end = len(L)
+            return
         self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
                                        dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
         L.append(('tfx_ce_fwd_bwd', self._ce_args))
@@ -207,6 +227,9 @@ class Plan:
         kw = dict(q=self.qkr[i], k=_p(self.qkr, i) + 2 * hd, v=_p(self.qkvg, i) + 2 * 2 * hd, ld_q=2 * hd, ld_k=2 * hd, ld_v=ldq,
                   gate=_p(self.qkvg, i) + 2 * 3 * hd, ld_gate=ldq, kv_end=self.kv_end, q_start=self.q_start, out=self.og[i], ld_out=hd,
                   lse=self.lse[i], b=self.b, h=md.heads, n=self.n, softcap=50.0)
+        if self.cache is not None:
+            ck = self.cache[i]
+            kw.update(k=ck.data_ptr(), v=ck.data_ptr() + 2 * hd, ld_k=2 * hd, ld_v=2 * hd, n_kv=int(ck.shape[1]))
         if bwd:
             kw.update(dout=self.dog, ld_dout=hd, do_eff=self.do_eff, ld_do=hd, delta=self.delta,
                       dgate=self.dqkvg.data_ptr() + 2 * 3 * hd, ld_dgate=ldq, dq=self.dqk, dk=self.dqk.data_ptr() + 2 * hd,

@@ -1,0 +1,347 @@
+"""KV-cached batched decoding: the reference's `sample_many` state machine (T:2082-2583) over the native engine.
+
+The per-sample state machine (phases text / modality / done, prompt normalisation, [som] transitions, shape parsing,
+length budget) is host bookkeeping and follows the reference line by line; every tensor operation of a decoding step
+runs in the HIP kernels through a *decode plan* (engine.Plan with a KV cache):
+
+  * text step (T:2279-2349)   one new token per active sample: embed -> transformer against the cache -> fp32 logits
+  * modality step (T:2354-2556) joint fixed-grid midpoint ODE (torchdiffeq semantics) over all samples
+    in the modality phase; every evaluation = latent_to_model -> transformer (FiLM path, t = step time) against the
+    conditional cache, again against the null-text cache for classifier-free guidance, -> model_to_latent.
+
+Cache semantics reproduced exactly: the new [som] token is NOT in the conditional cache when its modality is decoded
+(the modality block takes the rotary position the [som] would have had, T:2411); the K/V committed for a decoded
+modality are those of the LAST conditional ODE evaluation (T:2531-2533); past modalities are conditioned at t = 1.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import capi
+from .engine import Plan
+
+
+@dataclass
+class _State:                                   # _SamplingState, T:1270-1287 (token values mirrored on the host)
+    parts: list                                 # host view of `sample`: lists of ints (text) and (type, tensor) tuples
+    curr_seq: list                              # the text part currently being built (alias of parts[-1] when it is text)
+    last_token: int | None
+    phase: str = 'text'
+    cache_len: int = 0
+    uncond_len: int = 0
+    tokens_seen: int = 0
+    num_past_modalities: int = 0
+    curr_modality_id: int | None = None
+    modality_shape: tuple | None = None
+    modality_length: int | None = None
+    num_tokens: int = 0
+    forced: tuple = (None, None)
+
+
+def _min_p_filter(logits, min_p):                # T:591-595
+    probs = logits.softmax(dim=-1)
+    limit = min_p * probs.amax(dim=-1, keepdim=True)
+    return torch.where(probs < limit, torch.full_like(logits, float('-inf')), logits)
+
+
+def _sample_text_token(logits, temperature, min_p):   # T:597-605
+    if temperature == 0.:
+        return logits.argmax(dim=-1)
+    logits = _min_p_filter(logits / temperature, min_p)
+    return torch.multinomial(logits.softmax(dim=-1), 1).squeeze(-1)
+
+
+class Sampler:
+    def __init__(self, model):
+        self.m = model
+        self.dev = model.device
+        self.md = model.md
+
+    # ------------------------------------------------------------------ prompt handling (T:1701-1800)
+    def _meta_tokens(self, shape, ty):
+        m = self.m
+        s = ','.join(map(str, shape))
+        return [m.meta_id] + [ord(c) + m.meta_id + 1 for c in s] + [m.som_ids[ty]]
+
+    def _prepare(self, prompt, force_modality_at_start):
+        m = self.m
+        if torch.is_tensor(prompt) and prompt.is_floating_point():
+            prompt = (0, prompt)
+        if torch.is_tensor(prompt):                                   # text only prompt
+            prompt = [prompt]
+        elif isinstance(prompt, tuple):
+            ty, mod = prompt
+            shape = tuple(mod.shape[:-1])
+            prompt = [self._meta_tokens(shape, ty), (ty, mod), [m.eom_ids[ty]]]
+        elif prompt is None:
+            prompt = []
+        prompt = [p for p in prompt if p is not None]
+        if prompt and isinstance(prompt[-1], tuple):                  # a raw modality ending the prompt is closed with its [eom]
+            prompt.append([m.eom_ids[prompt[-1][0]]])
+        parts = [[m.sos_id]]
+        for p in prompt:
+            if isinstance(p, tuple):
+                parts.append((p[0], p[1].to(self.dev, torch.float32)))
+                continue
+            ids = p if isinstance(p, list) else [int(v) for v in torch.atleast_1d(p).reshape(-1).tolist()]
+            if isinstance(parts[-1], list):                           # concat_contiguous_text, T:204-222
+                parts[-1] = parts[-1] + ids
+            else:
+                parts.append(list(ids))
+        forced_id, forced_shape = force_modality_at_start if isinstance(force_modality_at_start, tuple) else (force_modality_at_start, None)
+        if forced_id is not None:                                     # maybe_force_modality_at_start, T:1701-1731
+            toks = self._meta_tokens(forced_shape, forced_id) if forced_shape is not None else [m.som_ids[forced_id]]
+            if isinstance(parts[-1], list):
+                parts[-1] = parts[-1] + toks
+            else:
+                parts.append(toks)
+        return parts, forced_id, forced_shape
+
+    def _shape_from_seq(self, seq, ty, fixed_shape, forced_shape):    # get_modality_shape_from_seq, T:1607-1648
+        m = self.m
+        shape = forced_shape if forced_shape is not None else fixed_shape
+        default_shape = m.modality_default_shape[ty]
+        if m.meta_id in seq and forced_shape is None:
+            after = seq[len(seq) - 1 - seq[::-1].index(m.meta_id) + 1:]
+            meta = after[:-1]
+            meta_str = ''.join(chr(min(max(t - (m.meta_id + 1), 0), 127)) for t in meta)
+            if len(after) > 0:
+                if not meta_str.isdigit() or int(meta_str) <= 0:
+                    assert default_shape is not None, 'invalid modality meta information detected, please set `modality_default_shape` in order to properly fallback'
+                    shape = default_shape
+                else:
+                    shape = m.to_modality_shape_fn[ty](meta_str)
+        shape = shape if shape is not None else default_shape
+        ndim = m.modality_num_dim[ty]
+        if m.fallback_to_default_shape_if_invalid and ndim is not None and len(shape) != ndim:
+            shape = default_shape
+        assert shape is not None, f'language model did not produce a proper modality shape for modality type {ty} - please set a fallback shape with `modality_default_shape`'
+        assert ndim is None or ndim == len(shape), f'expected modality type {ty} to have {ndim} dimensions but language model produced a shape of {shape}'
+        return tuple(shape)
+
+    def _maybe_transition(self, st, fixed_shape):                     # T:2203-2224 / get_modality_transition T:1802-1825
+        m = self.m
+        tok = st.curr_seq[-1]
+        if tok not in m.som_ids:
+            return False
+        ty = m.som_ids.index(tok)
+        forced_id, forced_shape = st.forced
+        shape = self._shape_from_seq(st.curr_seq, ty, fixed_shape, forced_shape if ty == forced_id else None)
+        st.curr_modality_id, st.modality_shape, st.modality_length, st.phase = ty, shape, math.prod(shape), 'modality'
+        return True
+
+    def _as_batch(self, parts_list, null_text=False):
+        """host parts -> the list-of-tensors batch format the packer takes."""
+        out = []
+        for parts in parts_list:
+            s = []
+            for p in parts:
+                if isinstance(p, tuple):
+                    s.append(p)
+                else:
+                    ids = [self.m.null_text_id] * len(p) if null_text else p
+                    s.append(torch.tensor(ids, dtype=torch.long, device=self.dev))
+            out.append(s)
+        return out
+
+    # ------------------------------------------------------------------ caches
+    def _alloc_cache(self, B, maxlen):
+        return torch.zeros(self.md.depth, B, maxlen, 2 * self.md.hd, device=self.dev, dtype=torch.bfloat16)
+
+    def _fill_cache(self, cache, plan, B, n):
+        D, hd, ldq = self.md.depth, self.md.hd, self.md.ldq
+        cache[:, :, :n, :hd].copy_(plan.qkr.view(D, B, n, 2 * hd)[..., hd:])
+        cache[:, :, :n, hd:].copy_(plan.qkvg.view(D, B, n, ldq)[..., 2 * hd:3 * hd])
+
+    def _decode_plan(self, key, B, Lq, cache, with_latents):
+        plans = self.m._decode_plans
+        if key not in plans:
+            R = {t: B * Lq for t in range(self.m.num_modalities)} if with_latents else {}
+            self.m.store.refresh_shadows(self.m._stream())
+            p = Plan(self.m.store, B, Lq, B if with_latents else 0, R, training=False, cache=cache)
+            p.q_start.zero_()
+            plans[key] = p
+        return plans[key]
+
+    # ------------------------------------------------------------------ main
+    def sample_many(self, prompts, max_length, text_temperature, text_min_p, fixed_modality_shape, force_modality_at_start,
+                    init_modality_noise, modality_steps, cfg_scale):
+        m, md, dev = self.m, self.md, self.dev
+        m._require_gpu()
+        if prompts is None:
+            prompts = [None]
+        elif not isinstance(prompts, list):
+            prompts = [prompts]
+        states = []
+        for prompt in prompts:
+            parts, forced_id, forced_shape = self._prepare(prompt, force_modality_at_start)
+            seq_len = collapse = past = 0
+            for p in parts:
+                if isinstance(p, tuple):
+                    L = math.prod(p[1].shape[:-1]); seq_len += L; collapse += L - 1; past += 1
+                else:
+                    seq_len += len(p)
+            last = parts[-1]
+            st = _State(parts=parts, curr_seq=last if isinstance(last, list) else [m.sos_id],
+                        last_token=last[-1] if isinstance(last, list) else None, forced=(forced_id, forced_shape))
+            st.tokens_seen, st.num_past_modalities, st.cache_len = seq_len - collapse, past, seq_len
+            states.append(st)
+        B = len(states)
+
+        # ---- batched prefill (T:2194-2201): prompted modalities conditioned at t = 1, no meta tokens re-added
+        max_past = max((s.num_past_modalities for s in states), default=0)
+        times = torch.ones(B, max(max_past, 1), device=dev)
+        plan, S = m._forward_plain(self._as_batch([s.parts for s in states]), times, add_meta=False)
+        n0 = S['n']
+        Lcap = max([math.prod(sh) for sh in m.modality_default_shape if sh is not None] + [math.prod(fixed_modality_shape or (1,)), 16])
+        maxlen = (max(s.cache_len for s in states) + max_length + 2 * Lcap + 80) // 64 * 64
+        m._decode_plans = {}
+        cache = self._alloc_cache(B, max(maxlen, n0))
+        self._fill_cache(cache, plan, B, n0)
+        ucache = None
+        logits0 = plan.logits.view(B, n0, md.vp)[..., :md.vocab]
+        for st in states:
+            self._maybe_transition(st, fixed_modality_shape)
+        first = _sample_text_token(torch.stack([logits0[i, s.cache_len - 1] for i, s in enumerate(states)]), text_temperature, text_min_p).tolist()
+        for st, tok in zip(states, first):
+            if st.phase == 'text':
+                st.curr_seq.append(tok); st.last_token = tok; st.num_tokens += 1
+                if isinstance(st.parts[-1], list) and st.parts[-1] is not st.curr_seq:
+                    st.parts[-1] = st.curr_seq
+                if tok == m.eos_id:
+                    st.phase = 'done'; continue
+                self._maybe_transition(st, fixed_modality_shape)
+            if st.num_tokens > max_length:
+                st.phase = 'done'
+
+        stream = m._stream()
+        while not all(s.phase == 'done' for s in states):
+            # ------------------------------------------------ text phase
+            while any(s.phase == 'text' for s in states):
+                cache = self._ensure_capacity(cache, states, 1)
+                p = self._decode_plan(('text', cache.data_ptr()), B, 1, cache, False)
+                ids = np.zeros(B, np.int32); pos = np.full(B, -1, np.int32); kve = np.ones(B, np.int32); rot = np.zeros(B, np.int32)
+                for i, st in enumerate(states):
+                    kve[i] = max(st.cache_len, 1)
+                    if st.phase == 'text':
+                        ids[i], pos[i], kve[i], rot[i] = st.last_token, i * cache.shape[2] + st.cache_len, st.cache_len + 1, st.tokens_seen
+                self._load(p, ids=ids, pos=pos, kve=kve, rot=rot, tok_inst=np.full(B, -1, np.int32))
+                Plan.run(p.fwd, stream, 0, p.fwd_logits_end)
+                toks = _sample_text_token(p.logits[:, :md.vocab], text_temperature, text_min_p).tolist()
+                for st, tok in zip(states, toks):
+                    if st.phase != 'text':
+                        continue
+                    st.cache_len += 1
+                    st.curr_seq.append(tok); st.last_token = tok; st.tokens_seen += 1; st.num_tokens += 1
+                    if tok == m.eos_id or st.num_tokens > max_length:
+                        st.phase = 'done'; continue
+                    self._maybe_transition(st, fixed_modality_shape)
+            # ------------------------------------------------ modality phase
+            group = [i for i, s in enumerate(states) if s.phase == 'modality']
+            if not group:
+                continue
+            Lmax = max(states[i].modality_length for i in group)
+            cache = self._ensure_capacity(cache, states, Lmax)
+            use_cfg = cfg_scale != 1.
+            if use_cfg:                                               # null-text history prefill, T:2386-2406
+                hist = [states[i].parts if i in group else [[m.null_text_id]] for i in range(B)]
+                past = max(max(states[i].num_past_modalities for i in group), 1)
+                uplan, US = m._forward_plain(self._as_batch(hist, null_text=True), torch.ones(B, past, device=dev), add_meta=False)
+                un = US['n']
+                if ucache is None or ucache.shape[2] < un + Lmax + 8 or ucache.shape[2] != cache.shape[2]:
+                    ucache = self._alloc_cache(B, max(cache.shape[2], (un + Lmax + 8 + 63) // 64 * 64))
+                self._fill_cache(ucache, uplan, B, un)
+                for i in group:
+                    states[i].uncond_len = sum(math.prod(p[1].shape[:-1]) if isinstance(p, tuple) else len(p) for p in states[i].parts)
+            y = torch.zeros(B, Lmax, max(md.dim_latents), device=dev)
+            for i in group:
+                st = states[i]; L, dl = st.modality_length, md.dim_latents[st.curr_modality_id]
+                y[i, :L, :dl] = init_modality_noise[:L, :dl].to(dev) if init_modality_noise is not None else torch.randn(L, dl, device=dev)
+            cp = self._decode_plan(('mod', Lmax, cache.data_ptr()), B, Lmax, cache, True)
+            up = self._decode_plan(('umod', Lmax, ucache.data_ptr()), B, Lmax, ucache, True) if use_cfg else None
+            self._load_modality(cp, states, group, Lmax, cache.shape[2], uncond=False)
+            if use_cfg:
+                self._load_modality(up, states, group, Lmax, ucache.shape[2], uncond=True)
+
+            def velocity(t, yy):
+                f = self._eval(cp, states, group, Lmax, t, yy, stream)
+                if not use_cfg:
+                    return f
+                fu = self._eval(up, states, group, Lmax, t, yy, stream)
+                return fu + cfg_scale * (f - fu)
+
+            ts = torch.linspace(0, 1, modality_steps)                  # fixed grid = the linspace itself (odeint midpoint)
+            for k in range(modality_steps - 1):
+                t0, dt = ts[k], ts[k + 1] - ts[k]
+                f0 = velocity(float(t0), y)
+                y_mid = y + f0 * float(dt * 0.5)
+                y = y + float(dt) * velocity(float(t0 + dt * 0.5), y_mid)
+            for i in group:                                            # commit, T:2531-2556
+                st = states[i]; L, dl, ty = st.modality_length, md.dim_latents[st.curr_modality_id], st.curr_modality_id
+                st.cache_len += L
+                st.parts.append((ty, y[i, :L, :dl].reshape(*st.modality_shape, dl).clone()))
+                st.curr_seq = [m.eom_ids[ty]]; st.parts.append(st.curr_seq); st.last_token = m.eom_ids[ty]
+                st.tokens_seen += 1; st.num_tokens += L; st.num_past_modalities += 1
+                st.phase = 'done' if st.num_tokens > max_length else 'text'
+        m._decode_plans = {}
+        return [[(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in st.parts] for st in states]
+
+    # ------------------------------------------------------------------ helpers
+    def _ensure_capacity(self, cache, states, extra):
+        need = max(s.cache_len for s in states) + extra + 1
+        if need <= cache.shape[2]:
+            return cache
+        new = self._alloc_cache(cache.shape[1], (need + 256) // 64 * 64)
+        new[:, :, :cache.shape[2]].copy_(cache)
+        self.m._decode_plans = {}
+        return new
+
+    def _load(self, p, ids, pos, kve, rot, tok_inst):
+        dev = self.dev
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        p.text_ids.copy_(up(ids)); p.cache_pos.copy_(up(pos)); p.kv_end.copy_(up(kve)); p.rot_pos.copy_(up(rot)); p.tok_inst.copy_(up(tok_inst))
+        p.set_rope_tables(*self.m._rope_tables(int(rot.max()) + 1))
+
+    def _load_modality(self, p, states, group, Lmax, maxlen, uncond):
+        B, md = len(states), self.md
+        T = B * Lmax
+        ids = np.zeros(T, np.int32); pos = np.full(T, -1, np.int32); kve = np.ones(T, np.int32); rot = np.zeros(T, np.int32)
+        tok_inst = np.full(T, -1, np.int32)
+        row_tok = {t: np.full(T, -1, np.int32) for t in range(self.m.num_modalities)}
+        for i in range(B):
+            st = states[i]
+            base = st.uncond_len if uncond else st.cache_len
+            kve[i * Lmax:(i + 1) * Lmax] = max(base, 1)
+            if i not in group:
+                continue
+            L, ty = st.modality_length, st.curr_modality_id
+            sl = slice(i * Lmax, i * Lmax + L)
+            kve[i * Lmax:(i + 1) * Lmax] = base + L                    # own prefix + own (bidirectional) modality block, T:2415-2419
+            pos[sl] = i * maxlen + base + np.arange(L)
+            rot[i * Lmax:(i + 1) * Lmax] = st.tokens_seen              # every token of the instance shares one position, T:2411
+            tok_inst[sl] = i
+            row_tok[ty][sl] = np.arange(i * Lmax, i * Lmax + L)
+        self._load(p, ids, pos, kve, rot, tok_inst)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        for t in row_tok:
+            p.row_tok[t].copy_(up(row_tok[t])); p.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
+            p.row_inst[t].copy_(up(np.repeat(np.arange(B, dtype=np.int32), Lmax)))
+            p.noise_args[t].eps = None
+
+    def _eval(self, p, states, group, Lmax, t, y, stream):
+        """one model evaluation of the joint ODE state y (B, Lmax, dmax) at time t -> predicted flow, same layout (T:2468-2521)."""
+        md, B = self.md, len(states)
+        p.inst_time.fill_(t)
+        for ty in range(self.m.num_modalities):
+            p.lat[ty]['x'].copy_(y[:, :, :md.dim_latents[ty]].reshape(B * Lmax, md.dim_latents[ty]))
+        Plan.run(p.fwd, stream, 0, p.fwd_embed_end)
+        Plan.run(p.fwd, stream, p.fwd_logits_end, p.fwd_pred_end)
+        out = torch.zeros_like(y)
+        for i in group:
+            st = states[i]; L, ty = st.modality_length, st.curr_modality_id; dl = md.dim_latents[ty]
+            out[i, :L, :dl] = p.lat[ty]['pred'].view(B, Lmax, dl)[i, :L]
+        return out

@@ -175,12 +175,24 @@ class Transfusion(nn.Module):
             self._plans[key] = Plan(self.store, b, n, I, R, training=training)
         return self._plans[key]
 
-    def _build_structure(self, modalities, return_loss):
-        """full structure scan (host) + upload of every derived index array; cached per structure signature."""
+    def _build_structure(self, modalities, return_loss, add_meta=True, pad_n=1):
+        """full structure scan (host) + upload of every derived index array; cached per structure signature.
+        `add_meta=False`: the decode-time layout (`return_embed` in the reference, MP:330): no [meta][shape][som][eom]
+        tokens are added around modalities.  `pad_n`: round the packed length up (keeps the number of distinct plans small)."""
         dev = self.device
-        P = self._scan(modalities, add_sos_eos=return_loss)
+        P = self._scan(modalities, add_sos_eos=return_loss, add_meta=add_meta)
         b = P.b
         n = P.n_full - 1 if return_loss else P.n_full
+        if pad_n > 1 and n % pad_n:
+            n_new = (n + pad_n - 1) // pad_n * pad_n
+            old = P.n_full
+            th = np.full((b, n_new), -1, dtype=np.int32); th[:, :old] = P.text_host; P.text_host = th
+            cd = np.zeros((b, n_new), dtype=bool); cd[:, :old] = P.cfg_droppable; P.cfg_droppable = cd
+            P.text_dest = (P.text_dest // old) * n_new + (P.text_dest % old)
+            for t in P.row_pos:
+                rp = P.row_pos[t].astype(np.int64)
+                P.row_pos[t] = ((rp // old) * n_new + (rp % old)).astype(np.int32)
+            P.n_full = n = n_new
         tm = token_maps(P, n, self.num_modalities)
         seg_start, seg_len = token_segments(tm.tok_inst)
         D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -201,9 +213,40 @@ class Transfusion(nn.Module):
         P.user_text, P.latents = None, None          # the cache keeps structure only, never the caller's tensors
         return S
 
-    def _scan(self, modalities, add_sos_eos):
+    def _scan(self, modalities, add_sos_eos, add_meta=True):
         return scan_batch(modalities, num_modalities=self.num_modalities, dim_latents=self.dim_latents, sos_id=self.sos_id, eos_id=self.eos_id,
-                          meta_id=self.meta_id, som_ids=self.som_ids, eom_ids=self.eom_ids, add_sos_eos=add_sos_eos)
+                          meta_id=self.meta_id, som_ids=self.som_ids, eom_ids=self.eom_ids, add_sos_eos=add_sos_eos, add_meta=add_meta)
+
+    def _forward_plain(self, samples, times, add_meta=False, pad_n=64):
+        """inference forward over explicit samples (nothing added, no noising): fills and runs a non-training plan up to the
+        fp32 logits.  Returns (plan, structure).  Used by the sampler's prefills (T:2194-2201, T:2389-2406)."""
+        self._require_gpu()
+        dev, stream = self.device, self._stream()
+        sig, user_text, latents = fast_signature(samples)
+        key = (sig, 'plain', add_meta, pad_n)
+        S = self._struct_cache.get(key)
+        if S is None:
+            if len(self._struct_cache) > 16:
+                self._struct_cache.clear()
+            S = self._struct_cache[key] = self._build_structure(samples, False, add_meta=add_meta, pad_n=pad_n)
+        tm, b, n, I, R = S['tm'], S['b'], S['n'], S['I'], S['R']
+        self.store.refresh_shadows(stream)
+        plan = self._plan(b, n, I, R, training=False)
+        plan.set_rope_tables(*self._rope_tables(int(tm.rot_pos.max()) if tm.rot_pos.size else 0))
+        plan.tok_inst.copy_(S['tok_inst'].view(-1)); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['q_start']); plan.rot_pos.copy_(S['rot_pos'])
+        plan.loaded_structure = S
+        text_full = S['text_host'].clone()
+        if user_text:
+            text_full.view(-1).index_copy_(0, S['text_dest'], torch.cat(user_text).to(dev, torch.int32))
+        plan.text_ids.copy_(text_full[:, :n].reshape(-1))
+        if I > 0:
+            plan.inst_time.copy_(times.to(dev, torch.float32)[S['inst_b'], S['inst_m']])
+        for t in R:
+            plan.row_tok[t].copy_(S['row_tok'][t]); plan.row_inst[t].copy_(S['row_inst'][t])
+            plan.lat[t]['x'].copy_(torch.cat(latents[t]).to(dev, torch.float32))
+            plan.noise_args[t].eps = None
+        Plan.run(plan.fwd, stream, 0, plan.fwd_logits_end)
+        return plan, S
 
     def _default_times(self, num_modalities_host: np.ndarray, nm=None):
         """default_modality_length_to_time_fn, T:186-200 (device RNG).  `nm`: cached device copy of the counts
@@ -343,12 +386,32 @@ class Transfusion(nn.Module):
         plan.dtables.zero_()
         Plan.run(plan.bwd, self._stream())
 
-    # ------------------------------------------------------------------ sampling surface (not wired yet)
-    def sample(self, *a, **k):
-        raise NotImplementedError('sample / sample_one / sample_many: native decode kernels are the next milestone')
+    # ------------------------------------------------------------------ sampling surface (T:1842-2583)
+    @torch.no_grad()
+    def sample_many(self, prompts=None, max_length=2048, text_temperature=1., text_min_p=0.1, fixed_modality_shape=None,
+                    force_modality_at_start=None, init_modality_noise=None, modality_steps=16, return_unprocessed_modalities=False,
+                    cfg_scale=3.):
+        from .sampling import Sampler
+        was_training = self.training
+        self.eval()                                              # @temp_eval in the reference
+        try:
+            return Sampler(self).sample_many(prompts, max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
+                                             fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
+                                             init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale)
+        finally:
+            self.train(was_training)
 
-    sample_one = sample
-    sample_many = sample
+    @torch.no_grad()
+    def sample_one(self, prompt=None, max_length=2048, text_temperature=1., text_min_p=0.1, cache_kv=False, fixed_modality_shape=None,
+                   force_modality_at_start=None, init_modality_noise=None, modality_steps=16, return_unprocessed_modalities=False, cfg_scale=3.):
+        """T:1845-1858.  The reference asserts sample_many == per-prompt sample_one (tests/test_transfusion.py:758-808); here
+        sample_one IS the batch-of-one case of the KV-cached decoder (`cache_kv` is accepted for signature parity)."""
+        return self.sample_many([prompt], max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
+                                fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
+                                init_modality_noise=init_modality_noise, modality_steps=modality_steps,
+                                return_unprocessed_modalities=return_unprocessed_modalities, cfg_scale=cfg_scale)[0]
+
+    sample = sample_one
 
 
 def print_modality_sample(modality_sample):           # T:224-239
