@@ -20,6 +20,9 @@ constexpr int BM = 128, BN = 128, BK = 64;
 template <int EPI> struct Epilogue;
 
 TFX_DEV void store_bf16x4(bf16* dst, f32x4 v) {
+#ifdef TFX_DEBUG_NOSTORE
+  if (v[0] != 123456.75f) return;      // experiment: time the kernel without its epilogue stores
+#endif
   bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
   *(bf16x4*)dst = o;
 }
@@ -91,9 +94,10 @@ template <> struct Epilogue<EPI_GEGLU_BWD> {
     bf16x4 a4 = *(const bf16x4*)ag, g4 = *(const bf16x4*)(ag + 32);
     f32x4 da, dg;
     for (int e = 0; e < 4; e++) {
-      float a = bf2f(a4[e]), g = bf2f(g4[e]);
-      da[e] = dh[e] * gelu_erf(g);
-      dg[e] = dh[e] * a * gelu_erf_grad(g);
+      const float a = bf2f(a4[e]), g = bf2f(g4[e]);
+      const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752440f));        // one erf serves gelu and its derivative
+      da[e] = dh[e] * g * cdf;
+      dg[e] = dh[e] * a * (cdf + g * 0.39894228040143267794f * __expf(-0.5f * g * g));
     }
     bf16* c = (bf16*)p.C + (size_t)mo * p.ldc + col;
     store_bf16x4(c, da); store_bf16x4(c + 32, dg);
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      int off = srow[i] * BK + ((skc[i] ^ (srow[i] & 7)) << 3);
+      int off = srow[i] * BK + ((skc[i] ^ ((srow[i] >> 1) & 7)) << 3);
       *(u32x4*)(As + buf * BM * BK + off) = ra[i];
       *(u32x4*)(Bs + buf * BN * BK + off) = rb[i];
     }
@@ -173,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         int ar = arow0 + i * 32, br = brow0 + i * 32;
-        af[i] = *(const bf16x8*)(as + ar * BK + (((ks * 2 + hi) ^ (ar & 7)) << 3));
-        bfr[i] = *(const bf16x8*)(bs + br * BK + (((ks * 2 + hi) ^ (br & 7)) << 3));
+        af[i] = *(const bf16x8*)(as + ar * BK + (((ks * 2 + hi) ^ ((ar >> 1) & 7)) << 3));
+        bfr[i] = *(const bf16x8*)(bs + br * BK + (((ks * 2 + hi) ^ ((br >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < 2; i++)
@@ -345,7 +349,7 @@ TFX_DEV void glds16(const bf16* g, bf16* lds_wave_base) {
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16* As = (bf16*)smem_raw;                 // [2][128*64], row r chunk c' holds global chunk c' ^ (r & 7)
+  bf16* As = (bf16*)smem_raw;                 // [2][128*64], row r chunk c' holds global chunk c' ^ ((r >> 1) & 7): conflict-free for the ds_read_b128 lane groups
   bf16* Bs = As + 2 * BM * BK;
 
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int row = w * 32 + j * 8 + (l >> 3);
-    const int c = (l & 7) ^ (row & 7);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
     int rm = min(m0 + row, p.M - 1);
     if (p.a_rowmap) rm = p.a_rowmap[rm];
     const int rn = min(n0 + row, p.N - 1);
@@ -389,34 +393,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
 
   issue(0, 0);
   const int arow0 = wm * 64 + (l & 31), brow0 = wn * 64 + (l & 31);
+  // fragment addresses (bytes folded by the compiler): row r, k-step ks -> chunk (2*ks + hi) ^ ((r >> 1) & 7)
+  auto ldfrag = [&](const bf16* base, int r, int ks) { return *(const bf16x8*)(base + r * BK + (((ks * 2 + hi) ^ ((r >> 1) & 7)) << 3)); };
   for (int kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      issue(kt + 1, cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 8 pieces of tile kt have landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                            // ... and every other wave's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                            // ... everyone's have, and everyone finished reading the other buffer
+    if (kt + 1 < nk) issue(kt + 1, cur ^ 1);                 // DMA of tile kt+1 overlaps the MFMAs of tile kt
     const bf16* as = As + cur * BM * BK;
     const bf16* bs = Bs + cur * BN * BK;
+    bf16x8 af[2][2], bfr[2][2];                              // register double-buffered fragments: reads of k-step ks+1 fly under the MFMAs of ks
+#pragma unroll
+    for (int i = 0; i < 2; i++) { af[0][i] = ldfrag(as, arow0 + i * 32, 0); bfr[0][i] = ldfrag(bs, brow0 + i * 32, 0); }
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      bf16x8 af[2], bfr[2];
+      const int c = ks & 1;
+      if (ks + 1 < 4) {
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        int ar = arow0 + i * 32, br = brow0 + i * 32;
-        af[i] = *(const bf16x8*)(as + ar * BK + (((ks * 2 + hi) ^ (ar & 7)) << 3));
-        bfr[i] = *(const bf16x8*)(bs + br * BK + (((ks * 2 + hi) ^ (br & 7)) << 3));
+        for (int i = 0; i < 2; i++) { af[c ^ 1][i] = ldfrag(as, arow0 + i * 32, ks + 1); bfr[c ^ 1][i] = ldfrag(bs, brow0 + i * 32, ks + 1); }
       }
+      __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of this k-step's MFMAs (distinct registers)
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[c][j], af[c][i], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                            // buffer `cur` is free for tile kt + 2
   }
 
 #pragma unroll
@@ -447,6 +449,133 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
           for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e];
           Epilogue<EPI>::apply(p, m, mo, n, v);
         }
+    }
+  }
+}
+
+// 256x256x64 tile, 8 waves (2 x 4, wave tile 128x64 = 4x2 MFMA blocks), 2-stage LDS-DMA ring (128 KiB, one block per CU).
+// One staged K-tile feeds 2048 MFMA-cycles per SIMD - about the loaded-memory latency - so a single tile in flight
+// covers it, and the L2->LDS traffic per flop is half that of the 128x128 tile.
+constexpr int BM2 = 256, BN2 = 256;
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* As = (bf16*)smem_raw;                 // [2][256*64]
+  bf16* Bs = As + 2 * BM2 * BK;               // [2][256*64]
+
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int ntn = (p.N + BN2 - 1) / BN2;
+  const int ntiles = ((p.M + BM2 - 1) / BM2) * ntn;
+  const int nk = p.K / BK;
+  const int G = gridDim.x;                    // PERSISTENT: block b walks virtual tiles b, b+G, ... (G is a multiple of 8 or == ntiles)
+
+  // per-lane staging pointers of the tile being ISSUED (wave w stages rows [32w, 32w+32) of A and of B: 4 pieces of 8 rows each)
+  const bf16 *ga[4], *ga2[4], *gb[4];
+  auto setup = [&](int vt) {
+    const int bid = xcd_remap(vt, ntiles);
+    const int m0 = (bid / ntn) * BM2, n0 = (bid % ntn) * BN2;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int row = w * 32 + j * 8 + (l >> 3);
+      const int c = (l & 7) ^ ((row >> 1) & 7);
+      int rm = min(m0 + row, p.M - 1);
+      if (p.a_rowmap) rm = p.a_rowmap[rm];
+      const int rn = min(n0 + row, p.N - 1);
+      ga[j] = p.A + (size_t)rm * p.lda + c * 8;
+      ga2[j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
+      gb[j] = p.B + (size_t)rn * p.ldb + c * 8;
+    }
+  };
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    const bool second = p.A2 && k0 >= p.K1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      glds16(second ? ga2[j] + (k0 - p.K1) : ga[j] + k0, As + buf * BM2 * BK + (w * 32 + j * 8) * BK);
+      glds16(gb[j] + k0, Bs + buf * BN2 * BK + (w * 32 + j * 8) * BK);
+    }
+  };
+  const int arow0 = wm * 128 + (l & 31), brow0 = wn * 64 + (l & 31);
+  auto ldfrag = [&](const bf16* base, int r, int ks) { return *(const bf16x8*)(base + r * BK + (((ks * 2 + hi) ^ ((r >> 1) & 7)) << 3)); };
+
+  int buf = 0;
+  int vt = blockIdx.x;
+  if (vt >= ntiles) return;
+  setup(vt);
+  issue(0, 0);
+  for (; vt < ntiles; vt += G) {
+    const int bid = xcd_remap(vt, ntiles);
+    const int m0 = (bid / ntn) * BM2, n0 = (bid % ntn) * BN2;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; kt++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the current K-tile have landed
+      __builtin_amdgcn_s_barrier();                           // ... everyone's have, and the other buffer is free
+      if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+      else if (vt + G < ntiles) { setup(vt + G); issue(0, buf ^ 1); }   // cross-tile prefetch: flies under the epilogue
+      const bf16* as = As + buf * BM2 * BK;
+      const bf16* bs = Bs + buf * BN2 * BK;
+      bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) af[0][i] = ldfrag(as, arow0 + i * 32, 0);
+#pragma unroll
+      for (int j = 0; j < 2; j++) bfr[0][j] = ldfrag(bs, brow0 + j * 32, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const int c = ks & 1;
+        if (ks + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) af[c ^ 1][i] = ldfrag(as, arow0 + i * 32, ks + 1);
+#pragma unroll
+          for (int j = 0; j < 2; j++) bfr[c ^ 1][j] = ldfrag(bs, brow0 + j * 32, ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[c][j], af[c][i], acc[i][j], 0, 0, 0);
+      }
+      buf ^= 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int m = m0 + wm * 128 + i * 32 + (l & 31);
+      if (m >= p.M) continue;
+      const int mo = p.rowmap ? p.rowmap[m] : m;
+      if (mo < 0) continue;
+      if constexpr (EPI == EPI_GEGLU) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n_a = n0 + wn * 64 + 8 * g + 4 * hi;
+          if (n_a >= p.N) continue;
+          f32x4 a, gt;
+#pragma unroll
+          for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e]; gt[e] = acc[i][1][4 * g + e]; }
+          GegluFwd::apply(p, mo, n_a, a, gt);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+            if (n >= p.N) continue;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e];
+            Epilogue<EPI>::apply(p, m, mo, n, v);
+          }
+      }
     }
   }
 }
@@ -514,32 +643,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTN p) {
   issue(0, 0);
   for (int st = 0; st < nsteps; st++) {
     const int cur = st & 1;
-    if (st + 1 < nsteps) {
-      issue(st + 1, cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (st + 1 < nsteps) issue(st + 1, cur ^ 1);
     const bf16* as = As + cur * TN_BMK * 128;
     const bf16* bs = Bs + cur * TN_BMK * 128;
+    bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { af[0][i] = lds_tr8_swz(as, 8 * hi, 8 * hi + 4, wn * 64 + i * 32); bfr[0][i] = lds_tr8_swz(bs, 8 * hi, 8 * hi + 4, wk * 64 + i * 32); }
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      const int r0 = ks * 16 + 8 * hi;
-      bf16x8 af[2], bfr[2];
+      const int c = ks & 1;
+      if (ks + 1 < 4) {
+        const int r0 = (ks + 1) * 16 + 8 * hi;
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        af[i] = lds_tr8_swz(as, r0, r0 + 4, wn * 64 + i * 32);
-        bfr[i] = lds_tr8_swz(bs, r0, r0 + 4, wk * 64 + i * 32);
+        for (int i = 0; i < 2; i++) { af[c ^ 1][i] = lds_tr8_swz(as, r0, r0 + 4, wn * 64 + i * 32); bfr[c ^ 1][i] = lds_tr8_swz(bs, r0, r0 + 4, wk * 64 + i * 32); }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bfr[c][j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
   }
 
 #pragma unroll
@@ -567,9 +693,28 @@ static bool use_glds() {
   return v == 1;
 }
 
+static int tile256_mode() {          // TFX_GEMM_256: 0 = never, 1 = auto (default), 2 = always
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TFX_GEMM_256"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int smem = 2 * (BM * BK + BN * BK) * 2;
   int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int mode = tile256_mode();
+  const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
+  // 256x256 tiles when they still fill the chip (>= 2 tiles per CU) and the ragged last N tile wastes < 15 %
+  const bool want256 = mode == 2 || (mode == 1 && t256 >= 512 && (p.N % BN2 == 0 || p.N % BN2 >= 224 || p.N >= 8 * BN2));
+  if (use_glds() && want256) {
+    static bool attr_set = false;
+    const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_set = true; }
+    // one tile per block: walking several tiles per block (grid = #CUs, cross-tile prefetch) measured slower at large K and
+    // no faster at K = 512, where the row-scattered epilogue stores are what costs (tools/bench_gemm.py, TFX_DEBUG_NOSTORE)
+    hipLaunchKernelGGL(gemm_nt_256_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
+    return (int)hipGetLastError();
+  }
   if (use_glds()) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
   else hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
   return (int)hipGetLastError();
@@ -595,7 +740,7 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   static bool attr_set = false;
   const int smem = 2 * 2 * TN_BMK * TN_LD * 2;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   GemmTN q = p;

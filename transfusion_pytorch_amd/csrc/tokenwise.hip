@@ -822,12 +822,23 @@ __global__ __launch_bounds__(256) void colsum8_k(const bf16* src, int ld, int R,
   float a[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) a[e] = 0.f;
-  if (c0 < C)
-    for (int r = rbeg + ry; r < rend; r += 4) {
+  if (c0 < C) {
+    int r = rbeg + ry;
+    for (; r + 12 < rend; r += 16) {                     // 4 independent 16-byte loads in flight per thread
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *(const bf16x8*)(src + (size_t)(rowmap ? rowmap[r + 4 * u] : r + 4 * u) * ld + c0);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[e] += bf2f(v[u][e]);
+    }
+    for (; r < rend; r += 4) {
       bf16x8 v = *(const bf16x8*)(src + (size_t)(rowmap ? rowmap[r] : r) * ld + c0);
 #pragma unroll
       for (int e = 0; e < 8; e++) a[e] += bf2f(v[e]);
     }
+  }
 #pragma unroll
   for (int e = 0; e < 8; e++) s[ry][cx][e] = a[e];
   __syncthreads();
@@ -901,7 +912,10 @@ int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) {
 int tfx_rmsnorm_fwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_rmsnorm_bwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_attnres_fwd(const tfx_attnres_args* a, void* s) { if (a->L > 64) return -2; DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
-int tfx_attnres_bwd(const tfx_attnres_args* a, void* s) { if (a->L > 64) return -2; DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+int tfx_attnres_bwd(const tfx_attnres_args* a, void* s) {
+  if (a->L > 64) return -2;
+  DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET();
+}
 int tfx_embed_fwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_embed_bwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_bwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 
@@ -959,7 +973,7 @@ int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const
   if (R == 0 || C == 0) return 0;
   if (C % 8 == 0 && ld % 8 == 0) {
     const int gx = (C + 511) / 512;
-    int gy = 1024 / gx; if (gy < 1) gy = 1;
+    int gy = 384 / gx; if (gy < 1) gy = 1;          // few, long blocks: the closing atomics (8 per thread) are the cost to amortise
     int rpb8 = (R + gy - 1) / gy; if (rpb8 < 32) rpb8 = 32;
     hipLaunchKernelGGL(colsum8_k, dim3(gx, (R + rpb8 - 1) / rpb8), dim3(256), 0, ST(s), src, ld, R, C, colmap, rowmap, out, rpb8); RET();
   }
