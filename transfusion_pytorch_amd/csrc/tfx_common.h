@@ -56,9 +56,9 @@ TFX_DEV bf16x8 lds_tr8(const bf16* tile, int stride, int rowA, int rowB, int c0)
   const int col = c0 + 16 * ((l >> 4) & 1) + 4 * (q & 3);
   s16x4 lo = lds_tr4(tile + (rowA + (q >> 2)) * stride + col);
   s16x4 hi = lds_tr4(tile + (rowB + (q >> 2)) * stride + col);
-  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-  u.s.a = lo; u.s.b = hi;
-  return u.v;
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+  const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};                                   // dword-granular register sequence
+  return __builtin_bit_cast(bf16x8, v);
 }
 
 TFX_DEV float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
