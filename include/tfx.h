@@ -74,7 +74,6 @@ typedef struct {
   float alpha;
   const int32_t* a_rowmap;    /* gather rows of A / B (row index = map[m]); NULL = identity */
   const int32_t* b_rowmap;
-  int32_t splits256;          /* row-chunk count to use when the launcher picks the 256x256-tile kernel (0 = `splits`) */
 } tfx_gemm_tn_args;
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
 

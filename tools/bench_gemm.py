@@ -34,7 +34,7 @@ def tn(M, N, K, splits):
     A = torch.randn(M, N, device=dev).to(BF); B = torch.randn(M, K, device=dev).to(BF)
     C = torch.zeros(N, K, device=dev)
     a = capi.make_args('tfx_gemm_tn_args', A=A, lda=N, a_cols=N, B=B, ldb=K, b_cols=K, M=M, N=N, K=K, C=C, ldc=K, k_valid=K,
-                       splits=splits, splits256=splits, accumulate=1, alpha=1.0)
+                       splits=splits, accumulate=1, alpha=1.0)
     t = timeit(lambda: capi.call('tfx_gemm_tn', a, st()))
     print(f'TN {M}: {N}x{K} splits={splits:3d}: {t * 1e6:8.1f} us  {2 * M * N * K / t / 1e12:7.1f} TFLOP/s')
 

@@ -785,115 +785,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTN p) {
     }
 }
 
-// TN, 256x256 output tile, 8 waves (2 over n x 4 over k, wave tile 128x64), 64-row contraction steps, 2-stage LDS-DMA ring.
-// LDS rows are 512 B (256 columns); 16-byte slot index XOR ((row & 3) << 2) keeps the ds_read_b64_tr_b16 groups conflict-free.
-TFX_DEV bf16x8 lds_tr8_swz256(const bf16* tile, int rowA, int rowB, int c0) {
-  const int l = threadIdx.x & 63;
-  const int q = l & 15;
-  const int col = c0 + 16 * ((l >> 4) & 1) + 4 * (q & 3);
-  const int ra = rowA + (q >> 2), rb = rowB + (q >> 2);
-  s16x4 lo = lds_tr4(tile + ra * 256 + ((((col >> 3) ^ ((ra & 3) << 2))) << 3) + (col & 7));
-  s16x4 hi = lds_tr4(tile + rb * 256 + ((((col >> 3) ^ ((rb & 3) << 2))) << 3) + (col & 7));
-  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-  const u32x4 v = {l2[0], l2[1], h2[0], h2[1]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-__global__ __launch_bounds__(512, 2) void gemm_tn_256_kernel(GemmTN p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16* As = (bf16*)smem_raw;                         // [2][64*256]
-  bf16* Bs = As + 2 * TN_BMK * 256;                   // [2][64*256]
-
-  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = w >> 2, wk = w & 3;
-  const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
-  const int ntile = ntn * ntk;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int split = p.splits == 1 ? 0 : xcd + 8 * (local / ntile);
-  const int bid = p.splits == 1 ? xcd_remap(blockIdx.x, gridDim.x) : local % ntile;
-  const int n0 = (bid / ntk) * 256, k0 = (bid % ntk) * 256;
-  const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
-  const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
-  if (mbeg >= mend) return;
-  const int nsteps = (mend - mbeg) / TN_BMK;
-
-  // wave w stages rows [8w, 8w+8) of both tiles: 4 DMA pieces of 2 rows x 512 B each
-  const bf16 *ga[4], *gb[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int row = w * 8 + j * 2 + (l >> 5);
-    const int c = (l & 31) ^ ((row & 3) << 2);
-    const int ca = min(n0 + c * 8, p.a_cols - 8), cb = min(k0 + c * 8, p.b_cols - 8);
-    ga[j] = p.A + (size_t)(mbeg + row) * p.lda + ca;
-    gb[j] = p.B + (size_t)(mbeg + row) * p.ldb + cb;
-  }
-  const size_t stepA = (size_t)TN_BMK * p.lda, stepB = (size_t)TN_BMK * p.ldb;
-  auto issue = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      glds16(ga[j], As + buf * TN_BMK * 256 + (w * 8 + j * 2) * 256);
-      glds16(gb[j], Bs + buf * TN_BMK * 256 + (w * 8 + j * 2) * 256);
-      ga[j] += stepA; gb[j] += stepB;
-    }
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  issue(0);
-  for (int st = 0; st < nsteps; st++) {
-    const int cur = st & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (st + 1 < nsteps) issue(cur ^ 1);
-    const bf16* as = As + cur * TN_BMK * 256;
-    const bf16* bs = Bs + cur * TN_BMK * 256;
-    bf16x8 af[2][4], bfr[2][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++) af[0][i] = lds_tr8_swz256(as, 8 * hi, 8 * hi + 4, wn * 128 + i * 32);
-#pragma unroll
-    for (int j = 0; j < 2; j++) bfr[0][j] = lds_tr8_swz256(bs, 8 * hi, 8 * hi + 4, wk * 64 + j * 32);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const int c = ks & 1;
-      if (ks + 1 < 4) {
-        const int r0 = (ks + 1) * 16 + 8 * hi;
-#pragma unroll
-        for (int i = 0; i < 4; i++) af[c ^ 1][i] = lds_tr8_swz256(as, r0, r0 + 4, wn * 128 + i * 32);
-#pragma unroll
-        for (int j = 0; j < 2; j++) bfr[c ^ 1][j] = lds_tr8_swz256(bs, r0, r0 + 4, wk * 64 + j * 32);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bfr[c][j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int n = n0 + wn * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (n >= p.N) continue;
-      const int no = p.rowmap ? p.rowmap[n] : n;
-      if (no < 0) continue;
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int k = k0 + wk * 64 + j * 32 + (l & 31);
-        if (k < p.k_valid) atomicAdd(p.C + (size_t)no * p.ldc + k, acc[i][j][r] * p.alpha);
-      }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -957,17 +848,6 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   q.splits = p.splits == 1 ? 1 : (p.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernel's block order)
   int grid = ((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
   const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
-  static int tn256 = -1;
-  if (tn256 < 0) { const char* e = getenv("TFX_TN_256"); tn256 = e ? atoi(e) : 0; }   // measured: no gain over 128x128 for the few-tile weight-gradient shapes (tools/bench_gemm.py)
-  if (dma_ok && (tn256 == 2 || (tn256 == 1 && q.N >= 256 && q.K >= 256))) {
-    static bool attr256 = false;
-    const int smem2 = 2 * 2 * TN_BMK * 256 * 2;
-    if (!attr256) { (void)hipFuncSetAttribute((const void*)gemm_tn_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr256 = true; }
-    if (p.splits256 > 0) q.splits = p.splits256 == 1 ? 1 : (p.splits256 + 7) / 8 * 8;
-    int grid2 = ((q.N + 255) / 256) * ((q.K + 255) / 256) * q.splits;
-    hipLaunchKernelGGL(gemm_tn_256_kernel, dim3(grid2), dim3(512), smem2, s, q);
-    return (int)hipGetLastError();
-  }
   static int tnms = -1;
   if (tnms < 0) { const char* e = getenv("TFX_TN_MS"); tnms = e ? atoi(e) : 1; }
   if (dma_ok && tnms) {
