@@ -45,14 +45,48 @@ TFX_DEV bf16x8 g_rowfrag(const bf16* base, int ld, int row, int nrows, int ks) {
   return *(const bf16x8*)(base + (size_t)row * ld + 16 * ks + 8 * (l >> 5));
 }
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-// tanh for the soft-cap.  Scores are q~.k~ with |q~|,|k~| bounded by the QK-RMSNorm gains, so x = s/cap is small:
-// the odd Taylor polynomial to x^9 is exact to 1.3e-6 for |x| <= 0.45 and costs 6 plain VALU ops; if ANY lane of the
-// wave exceeds the bound the whole wave takes the exact exp2/rcp form (wave-uniform branch, no divergence).
-TFX_DEV float tanh_poly(float x) {
-  const float x2 = x * x;
-  return x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Soft-cap in the log2 domain: s2 = cap*log2e*tanh(s/cap).  Scores are q~.k~ with |q~|,|k~| bounded by the QK-RMSNorm
+// gains, so x = s/cap is small: the odd Taylor polynomial to x^9 is exact to 1.3e-6 for |x| <= 0.45.  It is evaluated
+// directly in s (the 1/cap powers and log2e are folded into the coefficients) on PAIRS of scores so that every step
+// is a packed v_pk_mul/v_pk_fma (a wave64 VALU op costs 4 cycles; the packed forms halve that per score).  If ANY lane
+// of the wave exceeds the bound the whole wave takes the exact exp2/rcp form (wave-uniform branch, no divergence).
+// Because |s2| <= cap*log2e (72 for cap 50), exp2(s2) can never overflow or vanish in fp32/bf16: the softmax uses the
+// FIXED reference 0 instead of a running maximum, which removes the max/rescale work of online softmax entirely.
+struct SoftCap { float k1, k3, k5, k7, k9, icap, cap2, smax, g2; };
+TFX_DEV SoftCap make_softcap(float cap) {
+  SoftCap c;
+  const float ic = 1.f / cap, i2 = ic * ic;
+  c.k1 = LOG2E; c.k3 = -LOG2E * i2 * 0.33333334f; c.k5 = LOG2E * i2 * i2 * 0.13333334f;
+  c.k7 = -LOG2E * i2 * i2 * i2 * 0.053968254f; c.k9 = LOG2E * i2 * i2 * i2 * i2 * 0.021869488f;
+  c.icap = ic; c.cap2 = cap * LOG2E; c.smax = 0.45f * cap; c.g2 = 1.f / (c.cap2 * c.cap2);
+  return c;
 }
 TFX_DEV float tanh_exact(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (2.f * LOG2E))); }
+TFX_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+TFX_DEV f32x2 bc2(float v) { f32x2 r = {v, v}; return r; }
+// in place: s <- cap*log2e*tanh(s/cap) for one 32x32 accumulator block
+TFX_DEV void softcap16(f32x16& s, const SoftCap& c) {
+  float amax = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[r]));
+  if (__any(amax > c.smax)) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = c.cap2 * tanh_exact(s[r] * c.icap);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const f32x2 v = {s[2 * i], s[2 * i + 1]};
+    const f32x2 u = v * v;
+    f32x2 q = pk_fma(u, bc2(c.k9), bc2(c.k7));
+    q = pk_fma(u, q, bc2(c.k5));
+    q = pk_fma(u, q, bc2(c.k3));
+    q = pk_fma(u, q, bc2(c.k1));
+    const f32x2 o = v * q;
+    s[2 * i] = o[0]; s[2 * i + 1] = o[1];
+  }
+}
 TFX_DEV float wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -95,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) o[i][r] = 0.f;
-  float m = -INFINITY, lsum = 0.f;             // running max / sum in the log2 domain
-  const float icap = 1.f / p.softcap, cap2 = p.softcap * LOG2E;
+  f32x2 lsum2 = {0.f, 0.f};                     // sum of exp2(s2) (fixed reference 0, see SoftCap)
+  const SoftCap sc_ = make_softcap(p.softcap);
   const int kve_min = wave_min_i(kve);
 
   TileRegs kr, vr;
@@ -116,41 +150,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) s[kb] = MFMA(lds_rowfrag(Ks, kb * 32, ks), qf[ks], s[kb]);   // S^T[key][q]
     }
-    // soft-cap in the log2 domain: s2 = cap*log2e * tanh(s/cap)
-    float amax = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[kb][r]));
-    const bool exact = __any(amax * icap > 0.45f);
     const bool need_mask = (j + 1) * 64 > kve_min;            // wave-uniform: interior tiles skip the compare/select
-    float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++)
+    for (int kb = 0; kb < 2; kb++) {
+      softcap16(s[kb], sc_);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float x = s[kb][r] * icap;
-        float v = cap2 * (exact ? tanh_exact(x) : tanh_poly(x));
+      for (int i = 0; i < 8; i++) {
+        f32x2 e = {__builtin_amdgcn_exp2f(s[kb][2 * i]), __builtin_amdgcn_exp2f(s[kb][2 * i + 1])};
         if (need_mask) {
-          const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          v = key < kve ? v : -INFINITY;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int r = 2 * i + t;
+            const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            e[t] = key < kve ? e[t] : 0.f;
+          }
         }
-        s[kb][r] = v; mx = fmaxf(mx, v);
+        s[kb][2 * i] = e[0]; s[kb][2 * i + 1] = e[1];
+        lsum2 += e;
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);             // finite after tile 0 (key 0 is visible to every query)
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    float ps = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) { float e = __builtin_amdgcn_exp2f(s[kb][r] - mn); s[kb][r] = e; ps += e; }
-    ps += __shfl_xor(ps, 32, 64);
-    lsum = lsum * alpha + ps; m = mn;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -161,6 +179,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
         for (int db = 0; db < 2; db++) o[db] = MFMA(lds_tr8(Vs, LDT, ra, ra + 8, db * 32), pf, o[db]);   // O^T[d][q]
       }
   }
+  float lsum = lsum2[0] + lsum2[1];
+  lsum += __shfl_xor(lsum, 32, 64);
   if (qrow < n) {
     const float g = sigmoidf_(bf2f(p.gate[(tok0 + qrow) * p.ld_gate + h]));
     const float sc = g * __builtin_amdgcn_rcpf(lsum);
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
         for (int e = 0; e < 4; e++) v[e] = f2bf(o[db][rg * 4 + e] * sc);
         *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
       }
-    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = (m + __log2f(lsum)) * LN2;
+    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = __log2f(lsum) * LN2;
   }
 }
 
@@ -234,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
-  const float icap = 1.f / p.softcap, cap2 = p.softcap * LOG2E;
+  const SoftCap sc_ = make_softcap(p.softcap);
 
   TileRegs kr, vr;
   tile_gload(kr, kb_, p.ld_k, 0, n);
@@ -255,20 +275,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
         s = MFMA(lds_rowfrag(Ks, kb * 32, ks), qf[ks], s);         // S^T[key][q]
         dp = MFMA(lds_rowfrag(Vs, kb * 32, ks), dof[ks], dp);      // dP^T[key][q]
       }
-      float amax = 0.f;
+      softcap16(s, sc_);                                             // s = s2 = cap*log2e*tanh(s/cap)
 #pragma unroll
-      for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[r]));
-      const bool exact = __any(amax * icap > 0.45f);
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float x = s[r] * icap;
-        const float th = exact ? tanh_exact(x) : tanh_poly(x);
-        float pr = __builtin_amdgcn_exp2f(cap2 * th - lse2);
+      for (int i = 0; i < 8; i++) {
+        const f32x2 a2 = {s[2 * i], s[2 * i + 1]};
+        const f32x2 arg = a2 - bc2(lse2);
+        f32x2 pr = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
         if (need_mask) {
-          const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          pr = key < kve ? pr : 0.f;
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int r = 2 * i + t;
+            const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            pr[t] = key < kve ? pr[t] : 0.f;
+          }
         }
-        s[r] = pr * (dp[r] - dlt) * (1.f - th * th);               // dS_raw^T
+        const f32x2 dth = pk_fma(a2 * a2, bc2(-sc_.g2), bc2(1.f));  // 1 - tanh^2
+        const f32x2 dpp = {dp[2 * i], dp[2 * i + 1]};
+        const f32x2 ds = pr * (dpp - bc2(dlt)) * dth;                // dS_raw^T
+        s[2 * i] = ds[0]; s[2 * i + 1] = ds[1];
       }
 #pragma unroll
       for (int tt = 0; tt < 2; tt++) {
@@ -323,7 +347,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-  const float icap = 1.f / p.softcap, cap2 = p.softcap * LOG2E;
+  const SoftCap sc_ = make_softcap(p.softcap);
+  const int kw_last = k0 + w * 32 + 31;                    // last key of this wave's 32-key block
 
   TileRegs qr, dr;
   tile_gload(qr, qb, p.ld_q, qt0 * 64, n);
@@ -350,10 +375,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
         s = MFMA(lds_rowfrag(Qs, qb2 * 32, ks), kf[ks], s);       // S[q][key]
         dp = MFMA(lds_rowfrag(Ds, qb2 * 32, ks), vf[ks], dp);     // dP[q][key]
       }
-      float amax = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[r]));
-      const bool exact = __any(amax * icap > 0.45f);
+      softcap16(s, sc_);                                             // s = s2 = cap*log2e*tanh(s/cap)
+      // kv_end is non-decreasing over the real queries: the 32-query block is fully visible to this wave's keys
+      // iff its first query sees the wave's last key and the block holds no rows past the end (wave-uniform)
+      const bool need_mask = kw_last >= s_kve[qb2 * 32] || jt * 64 + qb2 * 32 + 31 >= n;
       f32x16 pr;
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
@@ -361,13 +386,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
         const f32x4 ls4 = *(const f32x4*)(s_lse + ql), dl4 = *(const f32x4*)(s_dlt + ql);
         const int* kv4 = s_kve + ql;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < 4; e += 2) {
           const int r = rg * 4 + e;
-          const float x = s[r] * icap;
-          const float th = exact ? tanh_exact(x) : tanh_poly(x);
-          const float pv = krow < kv4[e] ? __builtin_amdgcn_exp2f(cap2 * th - ls4[e]) : 0.f;
-          pr[r] = pv;
-          s[r] = pv * (dp[r] - dl4[e]) * (1.f - th * th);          // dS_raw[q][key]
+          const f32x2 a2 = {s[r], s[r + 1]};
+          const f32x2 l2 = {ls4[e], ls4[e + 1]}, d2 = {dl4[e], dl4[e + 1]};
+          const f32x2 arg = a2 - l2;
+          f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          if (need_mask) {
+            pv[0] = krow < kv4[e] ? pv[0] : 0.f;
+            pv[1] = krow < kv4[e + 1] ? pv[1] : 0.f;
+          }
+          const f32x2 dth = pk_fma(a2 * a2, bc2(-sc_.g2), bc2(1.f));  // 1 - tanh^2
+          const f32x2 dpp = {dp[r], dp[r + 1]};
+          const f32x2 ds = pv * (dpp - d2) * dth;                      // dS_raw[q][key]
+          pr[r] = pv[0]; pr[r + 1] = pv[1];
+          s[r] = ds[0]; s[r + 1] = ds[1];
         }
       }
 #pragma unroll
@@ -401,12 +434,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
 int attn_fwd(const tfx_attn_args& p, hipStream_t s) {
   if (p.n <= 0 || p.b <= 0 || p.h <= 0) return -1;
   if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out) & 7) return -2;
+  if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;     // fixed-reference softmax needs exp2(cap*log2e) finite in fp32 sums
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }
 int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
   if (p.n <= 0 || p.b <= 0 || p.h <= 0) return -1;
   if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out | p.ld_dout | p.ld_do | p.ld_dq | p.ld_dk | p.ld_dv) & 7) return -2;
+  if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;
   long long nthreads = (long long)p.b * p.n * p.h * 8;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
