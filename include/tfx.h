@@ -222,6 +222,11 @@ typedef struct { const float* src; int32_t ld_src, Rs, Cs; const int32_t* rowmap
 int tfx_cast_rows(const tfx_cast_args* a, void* stream);
 /* dst[c][r] = src[rowmap ? rowmap[r] : r][c]  (transposed shadow for the dX GEMMs) */
 int tfx_cast_rows_t(const tfx_cast_args* a, void* stream);
+/* all shadows in one launch: `jobs_dev` is a DEVICE array of n_jobs jobs sorted by first_block; job j owns blocks
+ * [first_block, first_block + nb) with nb = ceil(Rd*ld_dst/2048) (plain) or ceil(ld_dst/64)*ceil(Rd/64) (transposed);
+ * n_blocks is the total; ld_dst % 8 == 0.  Fields as in tfx_cast_args. */
+typedef struct { const float* src; int32_t ld_src, Rs, Cs; const int32_t* rowmap; tfx_bf16* dst; int32_t ld_dst, Rd, Cd; int32_t transposed, first_block; } tfx_cast_job;
+int tfx_cast_batch(const tfx_cast_job* jobs_dev, int32_t n_jobs, int32_t n_blocks, void* stream);
 /* out_f32[i] = gather of fp32 vector through a map (bias shadows): dst[i] = map[i] >= 0 ? src[map[i]] : 0 */
 int tfx_gather_f32(const float* src, const int32_t* map, float* dst, int32_t n, void* stream);
 /* out[t][c] (bf16, ld % 8 == 0) = 1 if token t is text and max(ids[t],0) == c else 0  (embedding-gradient GEMM operand) */

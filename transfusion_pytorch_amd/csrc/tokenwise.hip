@@ -665,31 +665,32 @@ __global__ void fourier_k(tfx_fourier_args p) {
 }
 
 __global__ __launch_bounds__(256) void ce_k(tfx_ce_args p) {
+  // one wave per token, grid-stride over tokens so that each block issues ONE pair of atomics (the per-4-token
+  // atomics of the first version serialised in L2 and set the kernel's duration)
   __shared__ float sacc[2][WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int t = blockIdx.x * WAVES + w;
   float loss = 0.f, cnt = 0.f;
-  if (t < p.T) {
+  for (int t = blockIdx.x * WAVES + w; t < p.T; t += gridDim.x * WAVES) {
     const int lab = p.labels[t];
     const float* lg = p.logits + (size_t)t * p.ld;
     bf16* dl = p.dlogits + (size_t)t * p.ld_d;
     if (lab < 0) {
       for (int c = lane; c < p.ld_d; c += 64) dl[c] = f2bf(0.f);
-    } else {
-      float mx = -INFINITY;
-      for (int c = lane; c < p.V; c += 64) mx = fmaxf(mx, lg[c]);
-      mx = wave_max(mx);
-      float se = 0.f;
-      for (int c = lane; c < p.V; c += 64) se += __expf(lg[c] - mx);
-      se = wave_sum(se);
-      const float lse = mx + __logf(se);
-      for (int c = lane; c < p.ld_d; c += 64) {
-        float g = 0.f;
-        if (c < p.V) g = (__expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * p.grad_scale;
-        dl[c] = f2bf(g);
-      }
-      loss = lse - lg[lab]; cnt = 1.f;
+      continue;
     }
+    float mx = -INFINITY;
+    for (int c = lane; c < p.V; c += 64) mx = fmaxf(mx, lg[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < p.V; c += 64) se += __expf(lg[c] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    for (int c = lane; c < p.ld_d; c += 64) {
+      float g = 0.f;
+      if (c < p.V) g = (__expf(lg[c] - lse) - (c == lab ? 1.f : 0.f)) * p.grad_scale;
+      dl[c] = f2bf(g);
+    }
+    loss += lse - lg[lab]; cnt += 1.f;
   }
   if (lane == 0) { sacc[0][w] = loss; sacc[1][w] = cnt; }
   __syncthreads();
@@ -719,8 +720,8 @@ __global__ __launch_bounds__(256) void mse_k(tfx_mse_args p) {
   if (threadIdx.x == 0) { float a = 0.f; for (int i = 0; i < WAVES; i++) a += sacc[i]; atomicAdd(p.acc, a); }
 }
 
-__global__ void cast_rows_k(tfx_cast_args p) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+TFX_DEV void cast_rows_body(const tfx_cast_args& p, long long blk) {
+  const long long i = blk * 256 + threadIdx.x;
   if (i >= (long long)p.Rd * p.ld_dst) return;
   const int r = (int)(i / p.ld_dst), c = (int)(i % p.ld_dst);
   float v = 0.f;
@@ -731,9 +732,8 @@ __global__ void cast_rows_k(tfx_cast_args p) {
   p.dst[i] = f2bf(v);
 }
 // dst[c][r] = src[map(r)][c];  dst has Rd (= padded Cs) rows and ld_dst >= Cd (= padded #r) columns
-__global__ void cast_rows_t_k(tfx_cast_args p) {
-  __shared__ float tile[32][33];
-  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;     // r: dst column index, c: dst row index
+TFX_DEV void cast_rows_t_body(const tfx_cast_args& p, int bx, int by, float (*tile)[33]) {
+  const int r0 = bx * 32, c0 = by * 32;                     // r: dst column index, c: dst row index
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
   for (int j = ty; j < 32; j += 8) {
     int r = r0 + j, c = c0 + tx;
@@ -749,6 +749,71 @@ __global__ void cast_rows_t_k(tfx_cast_args p) {
     int c = c0 + j, r = r0 + tx;
     if (c < p.Rd && r < p.ld_dst) p.dst[(size_t)c * p.ld_dst + r] = f2bf(tile[tx][j]);
   }
+}
+__global__ __launch_bounds__(256) void cast_rows_k(tfx_cast_args p) { cast_rows_body(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void cast_rows_t_k(tfx_cast_args p) {
+  __shared__ float tile[32][33];
+  cast_rows_t_body(p, blockIdx.x, blockIdx.y, tile);
+}
+// every shadow of the parameter set in ONE launch: block -> job by binary search over the jobs' first blocks.
+// plain jobs: 8 elements per thread (2 x 16-B loads, one 16-B store); transposed jobs: 64x64 tiles through LDS
+// (256-B read segments, 128-B write segments).
+TFX_DEV void cast8_body(const tfx_cast_args& p, long long blk) {
+  const long long i = (blk * 256 + threadIdx.x) * 8;
+  if (i >= (long long)p.Rd * p.ld_dst) return;
+  const int r = (int)(i / p.ld_dst), c = (int)(i % p.ld_dst);          // ld_dst % 8 == 0: the 8 elements share a row
+  const int rs = p.rowmap ? p.rowmap[r] : r;
+  const int cmax = min(p.Cs, p.Cd);
+  bf16x8 o;
+  if (rs >= 0 && rs < p.Rs) {
+    const float* sp = p.src + (size_t)rs * p.ld_src + c;
+    if (c + 8 <= cmax && (((uintptr_t)sp) & 15) == 0) {
+      const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; e++) { o[e] = f2bf(a[e]); o[4 + e] = f2bf(b[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = f2bf(c + e < cmax ? sp[e] : 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(0.f);
+  }
+  *(bf16x8*)(p.dst + i) = o;
+}
+TFX_DEV void cast64_t_body(const tfx_cast_args& p, int bx, int by, float (*tile)[65]) {
+  const int r0 = bx * 64, c0 = by * 64;                     // r: dst column index, c: dst row index
+  {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+      const int r = r0 + j, c = c0 + tx;
+      float v = 0.f;
+      if (r < p.Cd && c < p.Cs) {
+        const int rs = p.rowmap ? p.rowmap[r] : r;
+        if (rs >= 0 && rs < p.Rs) v = p.src[(size_t)rs * p.ld_src + c];
+      }
+      tile[j][tx] = v;
+    }
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 64; j += 8) {
+    const int c = c0 + j, r = r0 + 2 * tx;
+    if (c < p.Rd && r < p.ld_dst) {                        // ld_dst % 8 == 0 -> r + 1 is in range too
+      bf16x2 o; o[0] = f2bf(tile[2 * tx][j]); o[1] = f2bf(tile[2 * tx + 1][j]);
+      *(bf16x2*)(p.dst + (size_t)c * p.ld_dst + r) = o;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void cast_batch_k(const tfx_cast_job* jobs, int n_jobs) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+  const tfx_cast_job j = jobs[lo];
+  const tfx_cast_args p = {j.src, j.ld_src, j.Rs, j.Cs, j.rowmap, j.dst, j.ld_dst, j.Rd, j.Cd};
+  const int lb = blockIdx.x - j.first_block;
+  if (j.transposed) { const int tx = (p.ld_dst + 63) / 64; cast64_t_body(p, lb % tx, lb / tx, tile); }
+  else cast8_body(p, lb);
 }
 // one-hot rows of the text tokens (zero rows for modality tokens): the embedding gradient becomes a TN GEMM
 __global__ void onehot_k(const int* ids, const int* tok_inst, bf16* out, int T, int ld) {
@@ -866,23 +931,38 @@ __global__ __launch_bounds__(256) void sumsq_k(const float* g, long long n, floa
 }
 
 // clip_grad_norm_(max_norm) + Adam, fused: coef = min(1, max_norm / (norm + 1e-6))   train_toy.py:55-57
-__global__ void adam_k(tfx_adam_args p) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void adam_k(tfx_adam_args p, float step_size, float inv_sqrt_bc2) {
+  // 4 parameters per thread (16-B accesses); bias corrections are computed once on the host side of the launch
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= p.n) return;
   float coef = p.grad_scale;
   if (p.max_norm > 0.f) {
     float norm = sqrtf(p.sumsq[0]) * p.grad_scale;
     coef *= fminf(1.f, p.max_norm / (norm + 1e-6f));
   }
-  float g = p.g[i] * coef;
-  float w = p.p[i];
-  if (p.weight_decay != 0.f) g += p.weight_decay * w;
-  float m = p.beta1 * p.m[i] + (1.f - p.beta1) * g;
-  float v = p.beta2 * p.v[i] + (1.f - p.beta2) * g * g;
-  p.m[i] = m; p.v[i] = v;
-  const float bc1 = 1.f - powf(p.beta1, (float)p.step), bc2 = 1.f - powf(p.beta2, (float)p.step);
-  const float denom = sqrtf(v) / sqrtf(bc2) + p.eps;
-  p.p[i] = w - p.lr / bc1 * m / denom;
+  if (i + 4 <= p.n) {
+    const f32x4 g4 = *(const f32x4*)(p.g + i), w4 = *(const f32x4*)(p.p + i);
+    f32x4 m4 = *(const f32x4*)(p.m + i), v4 = *(const f32x4*)(p.v + i), o4;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float g = g4[e] * coef;
+      if (p.weight_decay != 0.f) g += p.weight_decay * w4[e];
+      m4[e] = p.beta1 * m4[e] + (1.f - p.beta1) * g;
+      v4[e] = p.beta2 * v4[e] + (1.f - p.beta2) * g * g;
+      o4[e] = w4[e] - step_size * m4[e] / (sqrtf(v4[e]) * inv_sqrt_bc2 + p.eps);
+    }
+    *(f32x4*)(p.m + i) = m4; *(f32x4*)(p.v + i) = v4; *(f32x4*)(p.p + i) = o4;
+  } else {
+    for (long long j = i; j < p.n; j++) {
+      float g = p.g[j] * coef;
+      const float w = p.p[j];
+      if (p.weight_decay != 0.f) g += p.weight_decay * w;
+      const float m = p.beta1 * p.m[j] + (1.f - p.beta1) * g;
+      const float v = p.beta2 * p.v[j] + (1.f - p.beta2) * g * g;
+      p.m[j] = m; p.v[j] = v;
+      p.p[j] = w - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + p.eps);
+    }
+  }
 }
 
 }  // namespace tfx
@@ -933,7 +1013,10 @@ int tfx_noise_mix(const tfx_noise_mix_args* a, void* s) {
   hipLaunchKernelGGL(noise_mix_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
 }
 int tfx_fourier(const tfx_fourier_args* a, void* s) { if (a->I == 0) return 0; hipLaunchKernelGGL(fourier_k, dim3(a->I), dim3(256), 0, ST(s), *a); RET(); }
-int tfx_ce_fwd_bwd(const tfx_ce_args* a, void* s) { hipLaunchKernelGGL(ce_k, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a); RET(); }
+int tfx_ce_fwd_bwd(const tfx_ce_args* a, void* s) {
+  int g = grid_tokens(a->T); if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(ce_k, dim3(g), dim3(256), 0, ST(s), *a); RET();
+}
 int tfx_mse_fwd_bwd(const tfx_mse_args* a, void* s) {
   long long n = (long long)a->R * a->ld_d; if (n == 0) return 0;
   long long g = (n + 255) / 256; if (g > 2048) g = 2048;
@@ -945,6 +1028,10 @@ int tfx_cast_rows(const tfx_cast_args* a, void* s) {
 }
 int tfx_cast_rows_t(const tfx_cast_args* a, void* s) {
   hipLaunchKernelGGL(cast_rows_t_k, dim3((a->ld_dst + 31) / 32, (a->Rd + 31) / 32), dim3(256), 0, ST(s), *a); RET();
+}
+int tfx_cast_batch(const tfx_cast_job* jobs_dev, int32_t n_jobs, int32_t n_blocks, void* s) {
+  if (n_jobs <= 0 || n_blocks <= 0) return 0;
+  hipLaunchKernelGGL(cast_batch_k, dim3(n_blocks), dim3(256), 0, ST(s), jobs_dev, n_jobs); RET();
 }
 int tfx_onehot_bf16(const int32_t* ids, const int32_t* tok_inst, tfx_bf16* out, int32_t T, int32_t ld, void* s) {
   if (T == 0) return 0; if (ld % 8) return -1;
@@ -992,7 +1079,10 @@ int tfx_sumsq(const float* g, int64_t n, float* out, void* s) {
 }
 int tfx_adam_step(const tfx_adam_args* a, void* s) {
   if (a->n == 0) return 0;
-  hipLaunchKernelGGL(adam_k, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
+  if (((uintptr_t)a->p | (uintptr_t)a->g | (uintptr_t)a->m | (uintptr_t)a->v) & 15) return -1;
+  const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
+  const long long nthr = (a->n + 3) / 4;
+  hipLaunchKernelGGL(adam_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ST(s), *a, (float)(a->lr / bc1), (float)(1.0 / sqrt(bc2))); RET();
 }
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* s) { return gemm_nt(*a, ST(s)); }
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* s) { return gemm_tn(*a, ST(s)); }

@@ -8,6 +8,7 @@ list can be captured in a hipGraph.  Math follows SURVEY.md Appendix A (referenc
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,9 @@ def skip_sources(md: ModelDims):
             src[i] = stack.pop()
     assert not stack
     return src
+
+
+_TN_SPLIT_PRICE = float(os.environ.get('TFX_TN_SPLIT_PRICE', '0.03'))
 
 
 class Plan:
@@ -111,13 +115,13 @@ class Plan:
     def _tn(self, lst, M, N, K, **kw):
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         # each XCD owns whole row-chunks (gemm.hip); 64 blocks are resident per XCD (2 per CU).  Pick the split count
-        # that minimises (block waves per XCD) x (rows per block) plus a small price for the fp32 atomics per split
+        # that minimises (block waves per XCD) x (rows per block) plus a price for the fp32 atomics per split (cold gradient lines: tuned on the full step, not the L2-hot microbenchmark)
         # (measured on MI355X with tools/bench_gemm.py).
         best, splits = None, 8
         for s in (() if tiles >= 512 else (8, 16, 24, 32, 48, 64)):
             if s > 8 and M // s < 256:
                 break
-            cost = -(-(tiles * s // 8) // 64) * (8.0 / s) + 0.004 * s
+            cost = -(-(tiles * s // 8) // 64) * (8.0 / s) + _TN_SPLIT_PRICE * s
             if best is None or cost < best - 1e-9:
                 best, splits = cost, s
         if tiles >= 512:

@@ -189,6 +189,7 @@ class ParamStore:
         self.shadows = {}
         self._shadow_version = None
         self._maps = {}
+        self._jobs, self._job_table = [], None
         self.device = torch.device('cpu')
 
     # ------------------------------------------------------------------ flat <-> views
@@ -250,15 +251,30 @@ class ParamStore:
         return self.shadows[key]
 
     def _cast(self, stream, src_ptr, ld_src, Rs, Cs, dst, rowmap=None, transpose=False, n_rows_logical=None):
-        """dst[r][c] = src[map(r)][c]   (or dst[c][r] when transpose)."""
-        if transpose:
-            a = capi.make_args('tfx_cast_args', src=src_ptr, ld_src=ld_src, Rs=Rs, Cs=Cs, rowmap=capi.ptr(rowmap), dst=dst,
-                               ld_dst=dst.shape[1], Rd=dst.shape[0], Cd=n_rows_logical)
-            capi.call('tfx_cast_rows_t', a, stream)
-        else:
-            a = capi.make_args('tfx_cast_args', src=src_ptr, ld_src=ld_src, Rs=Rs, Cs=Cs, rowmap=capi.ptr(rowmap), dst=dst,
-                               ld_dst=dst.shape[1], Rd=dst.shape[0], Cd=dst.shape[1])
-            capi.call('tfx_cast_rows', a, stream)
+        """record one shadow job: dst[r][c] = src[map(r)][c]   (or dst[c][r] when transpose)."""
+        ld_dst, Rd = dst.shape[1], dst.shape[0]
+        assert ld_dst % 8 == 0
+        nb = ((ld_dst + 63) // 64) * ((Rd + 63) // 64) if transpose else (Rd * ld_dst + 2047) // 2048
+        self._jobs.append((dict(src=src_ptr, ld_src=ld_src, Rs=Rs, Cs=Cs, rowmap=capi.ptr(rowmap), dst=dst.data_ptr(), ld_dst=ld_dst, Rd=Rd,
+                                Cd=n_rows_logical if transpose else ld_dst, transposed=int(transpose)), nb))
+
+    def _launch_casts(self, stream):
+        """all recorded shadow jobs in one tfx_cast_batch launch; the device job table is cached per flat-buffer address."""
+        key = (self.flat.data_ptr(), len(self._jobs))
+        if self._job_table is None or self._job_table[0] != key:
+            J = capi.STRUCTS['tfx_cast_job']
+            arr = (J * len(self._jobs))()
+            first = 0
+            for i, (f, nb) in enumerate(self._jobs):
+                for k, v in f.items():
+                    setattr(arr[i], k, v)
+                arr[i].first_block = first
+                first += nb
+            import ctypes
+            raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8)
+            self._job_table = (key, raw.to(self.device), len(self._jobs), first)
+        _, tab, nj, nblk = self._job_table
+        capi.check(capi.lib().tfx_cast_batch(tab.data_ptr(), nj, nblk, stream), 'tfx_cast_batch')
 
     def refresh_shadows(self, stream, force=False):
         ver = self.params_version()
@@ -267,6 +283,7 @@ class ParamStore:
         md = self.md
         d, hd, di, dip, D = md.dim, md.hd, md.di, md.dip, md.depth
         S, C = self._shadow, self._cast
+        self._jobs = []
         # AdaLN conditioning: one [nt3, 4d] matrix (+ transposed) for every layer / wrapper
         C(stream, self.ptr('transformer.layers.0.1.to_film.weight'), 4 * d, md.nt3, 4 * d, S('ada', md.nt3, 4 * d))
         C(stream, self.ptr('transformer.layers.0.1.to_film.weight'), 4 * d, md.nt3, 4 * d, S('ada_t', 4 * d, md.nt3), transpose=True, n_rows_logical=md.nt3)
@@ -298,4 +315,5 @@ class ParamStore:
         C(stream, self.ptr('text_embed.weight'), d, md.vocab, d, S('embed', md.vocab, d))
         C(stream, self.ptr('to_text_logits.weight'), d, md.vocab, d, S('logits', md.vocab, d))
         C(stream, self.ptr('to_text_logits.weight'), d, md.vocab, d, S('logits_t', d, md.vp), transpose=True, n_rows_logical=md.vocab)
+        self._launch_casts(stream)
         self._shadow_version = ver
