@@ -878,9 +878,10 @@ template <typename T> __global__ __launch_bounds__(256) void colsum_k(const T* s
   }
 }
 
-// bf16 column sums, 16-byte loads: a thread owns 8 consecutive columns, 4 row lanes per block
-__global__ __launch_bounds__(256) void colsum8_k(const bf16* src, int ld, int R, int C, const int* colmap, const int* rowmap, float* out, int rows_per_block) {
-  __shared__ float s[4][64][9];
+// bf16 column sums, 16-byte loads: a thread owns 8 consecutive columns, 8 row lanes per 512-thread block, 8 independent
+// loads in flight per thread (HBM latency x bandwidth needs >= 16 MB outstanding across the chip)
+__global__ __launch_bounds__(512) void colsum8_k(const bf16* src, int ld, int R, int C, const int* colmap, const int* rowmap, float* out, int rows_per_block) {
+  __shared__ float s[8][64][9];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c0 = (blockIdx.x * 64 + cx) * 8;
   const int rbeg = blockIdx.y * rows_per_block, rend = min(R, rbeg + rows_per_block);
@@ -889,16 +890,16 @@ __global__ __launch_bounds__(256) void colsum8_k(const bf16* src, int ld, int R,
   for (int e = 0; e < 8; e++) a[e] = 0.f;
   if (c0 < C) {
     int r = rbeg + ry;
-    for (; r + 12 < rend; r += 16) {                     // 4 independent 16-byte loads in flight per thread
-      bf16x8 v[4];
+    for (; r + 56 < rend; r += 64) {
+      bf16x8 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = *(const bf16x8*)(src + (size_t)(rowmap ? rowmap[r + 4 * u] : r + 4 * u) * ld + c0);
+      for (int u = 0; u < 8; u++) v[u] = *(const bf16x8*)(src + (size_t)(rowmap ? rowmap[r + 8 * u] : r + 8 * u) * ld + c0);
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < 8; u++)
 #pragma unroll
         for (int e = 0; e < 8; e++) a[e] += bf2f(v[u][e]);
     }
-    for (; r < rend; r += 4) {
+    for (; r < rend; r += 8) {
       bf16x8 v = *(const bf16x8*)(src + (size_t)(rowmap ? rowmap[r] : r) * ld + c0);
 #pragma unroll
       for (int e = 0; e < 8; e++) a[e] += bf2f(v[e]);
@@ -907,11 +908,15 @@ __global__ __launch_bounds__(256) void colsum8_k(const bf16* src, int ld, int R,
 #pragma unroll
   for (int e = 0; e < 8; e++) s[ry][cx][e] = a[e];
   __syncthreads();
-  if (ry == 0 && c0 < C) {
+  // 512 threads close 512 columns: thread t sums the 8 row lanes of column t
+  {
+    const int cc = threadIdx.x >> 3, e = threadIdx.x & 7;
+    const int col = (blockIdx.x * 64 + cc) * 8 + e;
+    if (col < C) {
+      float v = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      float v = s[0][cx][e] + s[1][cx][e] + s[2][cx][e] + s[3][cx][e];
-      int co = colmap ? colmap[c0 + e] : c0 + e;
+      for (int y = 0; y < 8; y++) v += s[y][cc][e];
+      const int co = colmap ? colmap[col] : col;
       if (co >= 0 && v != 0.f) atomicAdd(out + co, v);
     }
   }
@@ -977,7 +982,7 @@ using namespace tfx;
 extern "C" {
 
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
-static inline int grid_segs(int n_seg) { int g = (n_seg + WAVES - 1) / WAVES; return g < 512 ? (g < 1 ? 1 : g) : 512; }
+static inline int grid_segs(int n_seg) { int g = (n_seg + WAVES - 1) / WAVES; static const int cap = getenv("TFX_SEG_CAP") ? atoi(getenv("TFX_SEG_CAP")) : 1024; return g < cap ? (g < 1 ? 1 : g) : cap; }
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) {
   if (a->seg_start) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
@@ -1060,9 +1065,9 @@ int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const
   if (R == 0 || C == 0) return 0;
   if (C % 8 == 0 && ld % 8 == 0) {
     const int gx = (C + 511) / 512;
-    int gy = 384 / gx; if (gy < 1) gy = 1;          // few, long blocks: the closing atomics (8 per thread) are the cost to amortise
-    int rpb8 = (R + gy - 1) / gy; if (rpb8 < 32) rpb8 = 32;
-    hipLaunchKernelGGL(colsum8_k, dim3(gx, (R + rpb8 - 1) / rpb8), dim3(256), 0, ST(s), src, ld, R, C, colmap, rowmap, out, rpb8); RET();
+    int gy = 768 / gx; if (gy < 1) gy = 1;          // ~3 blocks of 512 threads per CU; one closing atomic per thread
+    int rpb8 = (R + gy - 1) / gy; if (rpb8 < 64) rpb8 = 64;
+    hipLaunchKernelGGL(colsum8_k, dim3(gx, (R + rpb8 - 1) / rpb8), dim3(512), 0, ST(s), src, ld, R, C, colmap, rowmap, out, rpb8); RET();
   }
   int rpb = colsum_rows_per_block(R);
   hipLaunchKernelGGL(colsum_k<bf16>, dim3((C + 63) / 64, (R + rpb - 1) / rpb), dim3(256), 0, ST(s), src, ld, R, C, colmap, rowmap, out, rpb); RET();
