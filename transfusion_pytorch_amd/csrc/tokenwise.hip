@@ -247,32 +247,48 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_seg_k(tfx
     for (int i = 0; i < NC; i++)
 #pragma unroll
       for (int e = 0; e < 8; e++) { ag.v[i][e] = 0.f; ab.v[i][e] = 0.f; }
-    for (int t = t0; t < t0 + len; t++) {
-      Row<NC> x, du;
-      load_row(x, p.x + (size_t)t * d, d, lane);
-      load_row(du, p.du + (size_t)t * d, d, lane);
-      const float mean = p.mean[t], rstd = p.rstd[t];
-      float c1 = 0.f, c2 = 0.f;
+    // U tokens per trip: all 3U row loads are issued before the first dependent use (a wave walks its segment
+    // serially, so without this every token pays two full memory round trips)
+    constexpr int U = NC == 1 ? 4 : (NC == 2 ? 2 : 1);
+    const int tend = t0 + len;
+    for (int tb = t0; tb < tend; tb += U) {
+      Row<NC> xs[U], dus[U], dxs[U];
+      float means[U], rstds[U];
 #pragma unroll
-      for (int i = 0; i < NC; i++) {
-        int c = lane + 64 * i;
-        if (c * 8 >= d) continue;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          float xh = (x.v[i][e] - mean) * rstd;
-          ag.v[i][e] += du.v[i][e] * xh; ab.v[i][e] += du.v[i][e];
-          float dxh = du.v[i][e] * (1.f + g.v[i][e]);
-          c1 += dxh; c2 += dxh * xh;
-          x.v[i][e] = xh; du.v[i][e] = dxh;
-        }
+      for (int u = 0; u < U; u++) {
+        const int t = min(tb + u, tend - 1);
+        load_row(xs[u], p.x + (size_t)t * d, d, lane);
+        load_row(dus[u], p.du + (size_t)t * d, d, lane);
+        load_row(dxs[u], p.dx + (size_t)t * d, d, lane);
+        means[u] = p.mean[t]; rstds[u] = p.rstd[t];
       }
-      c1 = wave_sum(c1) / d; c2 = wave_sum(c2) / d;
-      Row<NC> dx; load_row(dx, p.dx + (size_t)t * d, d, lane);
 #pragma unroll
-      for (int i = 0; i < NC; i++)
+      for (int u = 0; u < U; u++) {
+        const int t = tb + u;
+        if (t >= tend) break;
+        Row<NC>& x = xs[u]; Row<NC>& du = dus[u]; Row<NC>& dx = dxs[u];
+        const float mean = means[u], rstd = rstds[u];
+        float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) dx.v[i][e] += rstd * (du.v[i][e] - c1 - x.v[i][e] * c2);
-      store_row(dx, p.dx + (size_t)t * d, d, lane);
+        for (int i = 0; i < NC; i++) {
+          int c = lane + 64 * i;
+          if (c * 8 >= d) continue;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float xh = (x.v[i][e] - mean) * rstd;
+            ag.v[i][e] += du.v[i][e] * xh; ab.v[i][e] += du.v[i][e];
+            float dxh = du.v[i][e] * (1.f + g.v[i][e]);
+            c1 += dxh; c2 += dxh * xh;
+            x.v[i][e] = xh; du.v[i][e] = dxh;
+          }
+        }
+        c1 = wave_sum(c1) / d; c2 = wave_sum(c2) / d;
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) dx.v[i][e] += rstd * (du.v[i][e] - c1 - x.v[i][e] * c2);
+        store_row(dx, p.dx + (size_t)t * d, d, lane);
+      }
     }
     if (inst < 0) {
 #pragma unroll
@@ -315,15 +331,26 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_seg_k(tf
     for (int i = 0; i < NC; i++)
 #pragma unroll
       for (int e = 0; e < 8; e++) { sc.v[i][e] = inst < 0 ? 1.f + sc.v[i][e] : sigmoidf_(sc.v[i][e]); az.v[i][e] = 0.f; }
-    for (int t = t0; t < t0 + len; t++) {
-      Row<NC> g, y;
-      load_row(g, p.g + (size_t)t * d, d, lane);
-      load_row(y, p.y + (size_t)t * d, d, lane);
+    constexpr int U = NC == 1 ? 4 : (NC == 2 ? 2 : 1);      // U tokens per trip, loads first (see adaln_pre_bwd_seg_k)
+    const int tend = t0 + len;
+    for (int tb = t0; tb < tend; tb += U) {
+      Row<NC> gs[U], ys[U];
 #pragma unroll
-      for (int i = 0; i < NC; i++)
+      for (int u = 0; u < U; u++) {
+        const int t = min(tb + u, tend - 1);
+        load_row(gs[u], p.g + (size_t)t * d, d, lane);
+        load_row(ys[u], p.y + (size_t)t * d, d, lane);
+      }
 #pragma unroll
-        for (int e = 0; e < 8; e++) { az.v[i][e] += g.v[i][e] * y.v[i][e]; g.v[i][e] *= sc.v[i][e]; }
-      store_row(g, p.dy + (size_t)t * d, d, lane);
+      for (int u = 0; u < U; u++) {
+        const int t = tb + u;
+        if (t >= tend) break;
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) { az.v[i][e] += gs[u].v[i][e] * ys[u].v[i][e]; gs[u].v[i][e] *= sc.v[i][e]; }
+        store_row(gs[u], p.dy + (size_t)t * d, d, lane);
+      }
     }
     if (inst < 0) {
 #pragma unroll
