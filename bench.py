@@ -191,6 +191,14 @@ def main():
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
         n_launch = len(events)
         fcore = f_core_per_sample(d=args.dim, D=args.depth)
+        # HBM bytes per launch of the roofline kernel family: rocprofv3 PMC passes of this same command, committed under
+        # profiles/ (tools/pmc_traffic.sh; FETCH_SIZE x2 gfx950 correction applied there) - counters cannot be read in-process
+        traffic, traffic_src = None, None
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+        if os.path.exists(tj) and (args.batch, args.dim, args.depth) == (64, 512, 8):
+            tr = json.load(open(tj))
+            if tr.get('kernel_family') == args.roofline_kernel:
+                traffic, traffic_src = tr['bytes_per_launch'], tr['source']
         out = {
             'metric': 'train samples/sec, dim512 d8 seq1024 text+latent', 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
@@ -204,7 +212,7 @@ def main():
             'f_core_gflop_per_sample': fcore / 1e9,
             'host_ms_per_step': host_t / args.steps * 1e3,
             'roofline': {'bound': 'mfma', 'kernel': args.roofline_kernel, 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': None, 'launches_per_step': n_launch / max(args.steps, 1),
+                         'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src, 'launches_per_step': n_launch / max(args.steps, 1),
                          'avg_launch_us': kt / max(n_launch, 1) * 1e6, 'algorithmic_gflop_per_step': kf / max(args.steps, 1) / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:

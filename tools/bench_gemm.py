@@ -22,12 +22,13 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
-def nt(M, N, K, epi='TFX_EPI_BF16'):
-    A = torch.randn(M, K, device=dev).to(BF); B = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
-    C = torch.empty(M, N, device=dev, dtype=BF)
-    a = capi.make_args('tfx_gemm_nt_args', A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS[epi], C=C, ldc=N)
+def nt(M, N, K, epi='TFX_EPI_BF16', pad=0, padc=0):
+    """pad / padc: extra elements in the row stride of A,B / of C (channel-camping experiment)"""
+    A = torch.randn(M, K + pad, device=dev).to(BF); B = (torch.randn(N, K + pad, device=dev) * K ** -0.5).to(BF)
+    C = torch.empty(M, N + padc, device=dev, dtype=BF)
+    a = capi.make_args('tfx_gemm_nt_args', A=A, lda=K + pad, B=B, ldb=K + pad, M=M, N=N, K=K, epi=capi.ENUMS[epi], C=C, ldc=N + padc)
     t = timeit(lambda: capi.call('tfx_gemm_nt', a, st()))
-    print(f'NT {M}x{N}x{K}: {t * 1e6:8.1f} us  {2 * M * N * K / t / 1e12:7.1f} TFLOP/s')
+    print(f'NT {M}x{N}x{K} pad={pad},{padc}: {t * 1e6:8.1f} us  {2 * M * N * K / t / 1e12:7.1f} TFLOP/s')
 
 
 def tn(M, N, K, splits):
@@ -38,6 +39,14 @@ def tn(M, N, K, splits):
     t = timeit(lambda: capi.call('tfx_gemm_tn', a, st()))
     print(f'TN {M}: {N}x{K} splits={splits:3d}: {t * 1e6:8.1f} us  {2 * M * N * K / t / 1e12:7.1f} TFLOP/s')
 
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'pad':
+    T = 65536
+    for (N, K) in [(512, 512), (1544, 512), (512, 1408), (2816, 512)]:
+        for pad, padc in ((0, 0), (64, 0), (0, 64), (64, 64), (8, 8)):
+            nt(T, N, K, pad=pad, padc=padc)
+    for pad in (0, 64): nt(8192, 8192, 8192, pad=pad, padc=pad)
+    sys.exit(0)
 
 if __name__ == '__main__':
     T = 65536

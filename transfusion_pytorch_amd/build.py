@@ -16,7 +16,7 @@ LIB = os.path.join(LIBDIR, 'libtfx_hip.so')
 SOURCES = ['gemm.hip', 'attention.hip', 'tokenwise.hip']
 HEADERS = [os.path.join(CSRC, 'tfx_common.h'), os.path.join(CSRC, 'tfx_kernels.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'tfx.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result'] + os.environ.get('TFX_HIPCC_EXTRA', '').split()   # e.g. -DTFX_PP_TIMING (tools/pp_timing.py)
 
 
 def _hipcc() -> str:

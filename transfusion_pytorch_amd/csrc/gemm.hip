@@ -105,6 +105,187 @@ template <> struct Epilogue<EPI_GEGLU_BWD> {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Pipelined epilogue for the LDS-DMA kernels (N % 4 == 0).  gfx950 has ONE in-order vmcnt for loads and stores, so an
+// epilogue that loads side data (row map, bias, residual, saved activations) between its stores drains every store
+// issued so far at each load's wait - a chain of memory round trips that cost ~12 us per 256x256 tile (the "fixed" part
+// of the K=512 GEMMs).  Here every load of 32-row block i+1 is issued BEFORE the stores of block i, the row map and the
+// bias are fetched once up front, and column guards are plain exec masks: no wait ever follows a store.
+// ------------------------------------------------------------------------------------------------
+template <int EPI> struct EpiIn { };
+template <> struct EpiIn<EPI_RESID> { bf16x4 r[2][4]; };
+template <> struct EpiIn<EPI_GEGLU_BWD> { bf16x4 a[2][4], g[2][4]; };
+
+template <int EPI, int NI>
+TFX_DEV void fast_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+  int mo[NI];
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    const int m = m_w + i * 32 + r;
+    mo[i] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
+  }
+  f32x4 bias[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int n = n_w + j * 32 + 8 * g + 4 * hi;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      bias[j][g] = z;
+      if constexpr (EPI != EPI_GEGLU_BWD) { if (p.bias) bias[j][g] = *(const f32x4*)(p.bias + min(n, p.N - 4)); }   // uniform branch
+    }
+  // side-data loads are unconditional (addresses clamped into range): a load under a divergent branch makes the
+  // compiler fall back to vmcnt(0) at the join, which would drain the stores again
+  auto load_in = [&](EpiIn<EPI>& in, int i) {
+    const int m = min(m_w + i * 32 + r, p.M - 1);
+    if constexpr (EPI == EPI_RESID) {
+      const bf16* rp = p.R + (size_t)(p.resid_mapped ? max(mo[i], 0) : m) * p.ldr;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) in.r[j][g] = *(const bf16x4*)(rp + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
+    } else if constexpr (EPI == EPI_GEGLU_BWD) {
+      const bf16* ap = p.aux + (size_t)m * p.ldaux + 4 * hi;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int blk = min((n_w >> 5) + j, (p.N >> 5) - 1);
+#pragma unroll
+        for (int g = 0; g < 4; g++) { in.a[j][g] = *(const bf16x4*)(ap + blk * 64 + 8 * g); in.g[j][g] = *(const bf16x4*)(ap + blk * 64 + 32 + 8 * g); }
+      }
+    }
+  };
+  auto emit = [&](const EpiIn<EPI>& in, int i) {
+    if (mo[i] < 0) return;
+    if constexpr (EPI == EPI_GEGLU) {
+      bf16* c = (bf16*)p.C + (size_t)mo[i] * p.ldc + n_w + 4 * hi;
+      bf16* c2 = (bf16*)p.C2 + (size_t)mo[i] * p.ldc2 + (n_w >> 6) * 32 + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        if (n_w + 8 * g + 4 * hi >= p.N) continue;
+        f32x4 a, gt, h;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e] + bias[0][g][e]; gt[e] = acc[i][1][4 * g + e] + bias[1][g][e]; h[e] = a[e] * gelu_erf(gt[e]); }
+        store_bf16x4(c + 8 * g, a); store_bf16x4(c + 32 + 8 * g, gt); store_bf16x4(c2 + 8 * g, h);
+      }
+    } else if constexpr (EPI == EPI_GEGLU_BWD) {
+      bf16* c = (bf16*)p.C + (size_t)mo[i] * p.ldc + (n_w >> 5) * 64 + 4 * hi;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (n_w + j * 32 >= p.N) continue;                   // N (= dip) is a multiple of 64
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          f32x4 da, dg;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float dh = acc[i][j][4 * g + e], a = bf2f(in.a[j][g][e]), gg = bf2f(in.g[j][g][e]);
+            const float cdf = 0.5f * (1.f + erff(gg * 0.70710678118654752440f));        // one erf serves gelu and its derivative
+            da[e] = dh * gg * cdf;
+            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * __expf(-0.5f * gg * gg));
+          }
+          store_bf16x4(c + j * 64 + 8 * g, da); store_bf16x4(c + j * 64 + 32 + 8 * g, dg);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int n = n_w + j * 32 + 8 * g + 4 * hi;
+          if (n >= p.N) continue;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] + bias[j][g][e];
+          if constexpr (EPI == EPI_BF16) {
+            store_bf16x4((bf16*)p.C + (size_t)mo[i] * p.ldc + n, v);
+          } else if constexpr (EPI == EPI_F32) {
+            *(f32x4*)((float*)p.C + (size_t)mo[i] * p.ldc + n) = v;
+          } else if constexpr (EPI == EPI_SILU) {
+            f32x4 s;
+#pragma unroll
+            for (int e = 0; e < 4; e++) s[e] = v[e] * sigmoidf_(v[e]);
+            store_bf16x4((bf16*)p.C + (size_t)mo[i] * p.ldc + n, s);
+            store_bf16x4((bf16*)p.C2 + (size_t)mo[i] * p.ldc2 + n, v);
+          } else if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += bf2f(in.r[j][g][e]);
+            store_bf16x4((bf16*)p.C + (size_t)mo[i] * p.ldc + n, v);
+          }
+        }
+    }
+  };
+  EpiIn<EPI> in[2];
+  load_in(in[0], 0);
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    if (i + 1 < NI) load_in(in[(i + 1) & 1], i + 1);
+    emit(in[i & 1], i);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged store of a wave's 32x64 bf16 block.  fast_epilogue's bf16x4 stores put 64 different rows (64 cache
+// lines) behind every store instruction; s_memtime stamps of the 256x256 kernel show that issuing them takes ~10k
+// cycles per tile - as long as 3.3 K-tiles of MFMA work - because the address coalescer walks the lines one by one.
+// Staging the block through a wave-private 4 KiB LDS area (128-byte rows, chunk index XOR ((row >> 1) & 7): conflict-free
+// for both the 8-byte writes and the 16-byte reads) turns them into 16-byte stores with 8 lanes per 128-byte row segment:
+// 8 lines per instruction.  No block barrier: the area is wave-private and one wave's LDS operations execute in order.
+// ------------------------------------------------------------------------------------------------
+TFX_DEV void stage_put4(bf16* st, int row, int col, f32x4 v) {
+  bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+  *(bf16x4*)(st + row * 64 + (((col >> 3) ^ ((row >> 1) & 7)) << 3) + (col & 7)) = o;
+}
+// C(bf16)[mo][n_w .. n_w+63] = acc + bias for the NI 32-row blocks of a wave; needs ldc % 8 == 0, N % 8 == 0, C 16-byte aligned
+template <int NI>
+TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+  int mo[NI][4];                                               // output row of (block i, flush pass q): row q * 8 + (l >> 3)
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int m = m_w + i * 32 + q * 8 + (l >> 3);
+      mo[i][q] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
+    }
+  f32x4 bias[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      bias[j][g] = z;
+      if (p.bias) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
+    }
+  const bool col_ok = n_w + ch * 8 < p.N;
+#ifdef TFX_PP_TIMING
+  unsigned long long* stamps = (unsigned long long*)p.aux + (size_t)blockIdx.x * 8;
+  if (threadIdx.x == 0) stamps[5] = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    bf16* s = st + (i & 1) * 2048;                             // two areas: block i+1 is written while block i's stores drain
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] + bias[j][g][e];
+        stage_put4(s, r, j * 32 + 8 * g + 4 * hi, v);
+      }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = q * 8 + (l >> 3);
+      const bf16x8 v = *(const bf16x8*)(s + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+      if (col_ok && mo[i][q] >= 0) *(bf16x8*)((bf16*)p.C + (size_t)mo[i][q] * p.ldc + n_w + ch * 8) = v;
+    }
+#ifdef TFX_PP_TIMING
+    if (threadIdx.x == 0 && i < 2) stamps[6 + i] = __builtin_readcyclecounter();
+#endif
+  }
+}
+TFX_DEV bool can_stage_bf16(const GemmNT& p) { return ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------------------
 // gemm_nt
 // ------------------------------------------------------------------------------------------------
 template <int EPI>
@@ -421,36 +602,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
     }
   }
 
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int m = m0 + wm * 64 + i * 32 + (l & 31);
-    if (m >= p.M) continue;
-    const int mo = p.rowmap ? p.rowmap[m] : m;
-    if (mo < 0) continue;
-    if constexpr (EPI == EPI_GEGLU) {
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int n_a = n0 + wn * 64 + 8 * g + 4 * hi;
-        if (n_a >= p.N) continue;
-        f32x4 a, gt;
-#pragma unroll
-        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e]; gt[e] = acc[i][1][4 * g + e]; }
-        GegluFwd::apply(p, mo, n_a, a, gt);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
-          if (n >= p.N) continue;
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e];
-          Epilogue<EPI>::apply(p, m, mo, n, v);
-        }
-    }
-  }
+  fast_epilogue<EPI, 2>(p, acc, m0 + wm * 64, n0 + wn * 64);      // N % 4 == 0 (launcher)
 }
 
 // 256x256x64 tile, 8 waves (2 x 4, wave tile 128x64 = 4x2 MFMA blocks), 2-stage LDS-DMA ring (128 KiB, one block per CU).
@@ -547,36 +699,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256_kernel(GemmNT p) {
       buf ^= 1;
     }
 
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int m = m0 + wm * 128 + i * 32 + (l & 31);
-      if (m >= p.M) continue;
-      const int mo = p.rowmap ? p.rowmap[m] : m;
-      if (mo < 0) continue;
-      if constexpr (EPI == EPI_GEGLU) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int n_a = n0 + wn * 64 + 8 * g + 4 * hi;
-          if (n_a >= p.N) continue;
-          f32x4 a, gt;
-#pragma unroll
-          for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e]; gt[e] = acc[i][1][4 * g + e]; }
-          GegluFwd::apply(p, mo, n_a, a, gt);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
-            if (n >= p.N) continue;
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e];
-            Epilogue<EPI>::apply(p, m, mo, n, v);
-          }
-      }
-    }
+    fast_epilogue<EPI, 4>(p, acc, m0 + wm * 128, n0 + wn * 64);   // N % 4 == 0 (launcher)
   }
 }
 
@@ -601,6 +724,162 @@ TFX_DEV bf16x8 lds_tr8_swz(const bf16* tile, int rowA, int rowB, int c0) {
 TFX_DEV void glds16_asm(const bf16* g, const bf16* lds_wave_base) {
   const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)lds_wave_base);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong 256x256x64 NT kernel ("pp").  In the kernels above both waves of a SIMD are always in the same part of the
+// K-step (both fetch fragments, then both issue MFMAs), so the matrix pipe idles while LDS / DMA work is issued and vice
+// versa (PMC: MFMA busy 35-42 %).  Here a K-tile is cut into 4 half-tiles (A rows {a0 | a1}, B columns {b0 | b1} of every
+// wave) and 4 phases, one 64x32 output quadrant x K=64 each (8 MFMAs per wave):
+//      phase 1: read a0,b0 ; MFMA (a0,b0)      phase 2: read b1 ; MFMA (a0,b1)
+//      phase 3: read a1    ; MFMA (a1,b1)      phase 4: -       ; MFMA (a1,b0)
+// Every phase is  [ds_reads + LDS-DMA issue] s_barrier [MFMAs at raised priority] s_barrier , and the two wave groups
+// (wr = 0 / 1; one wave of each per SIMD) run ONE barrier apart, so one group's MFMAs always overlap the other group's
+// loads.  LDS holds two K-tiles (2 x 4 half-tiles x 16 KiB).  A half-tile slot is re-filled two phases after its last
+// read (safe under the one-barrier skew) and three half-tiles stay in flight across the only wait of a K-tile,
+// `s_waitcnt vmcnt(6)` before phase 4's first barrier, which certifies the next K-tile one phase before its first read.
+// (Schedule after the 8-phase template of cdna_hip_programming.md; DMAs are inline asm so hipcc does not drain them.)
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* lds = (bf16*)smem_raw;                                    // [2 K-tiles][A0, A1, B0, B1][128 rows x 64]
+  constexpr int HALF = 128 * BK;
+
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int ntn = (p.N + BN2 - 1) / BN2;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM2, n0 = (bid % ntn) * BN2;
+  const int nk = p.K / BK;
+
+  // half-tile row r' (0..127):  A_h -> tile row (r' >> 6) * 128 + h * 64 + (r' & 63) ;  B_h -> tile col (r' >> 5) * 64 + h * 32 + (r' & 31)
+  // wave w stages rows [16w, 16w+16) of every half-tile: 2 DMA pieces of 8 rows x 128 B
+  const bf16 *gA[2][2], *gA2[2][2], *gB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int rp = w * 16 + j * 8 + (l >> 3);
+      const int c = (l & 7) ^ ((rp >> 1) & 7);
+      int rm = min(m0 + (rp >> 6) * 128 + h * 64 + (rp & 63), p.M - 1);
+      if (p.a_rowmap) rm = p.a_rowmap[rm];
+      const int rn = min(n0 + (rp >> 5) * 64 + h * 32 + (rp & 31), p.N - 1);
+      gA[h][j] = p.A + (size_t)rm * p.lda + c * 8;
+      gA2[h][j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
+      gB[h][j] = p.B + (size_t)rn * p.ldb + c * 8;
+    }
+  auto issueA = [&](int kt, int h) {
+    const int k0 = kt * BK;
+    const bool second = p.A2 && k0 >= p.K1;
+    bf16* dst = lds + ((kt & 1) * 4 + h) * HALF + w * 16 * BK;
+#pragma unroll
+    for (int j = 0; j < 2; j++) glds16_asm(second ? gA2[h][j] + (k0 - p.K1) : gA[h][j] + k0, dst + j * 8 * BK);
+  };
+  auto issueB = [&](int kt, int h) {
+    bf16* dst = lds + ((kt & 1) * 4 + 2 + h) * HALF + w * 16 * BK;
+#pragma unroll
+    for (int j = 0; j < 2; j++) glds16_asm(gB[h][j] + kt * BK, dst + j * 8 * BK);
+  };
+  const int ra = wr * 64 + (l & 31), rb = wc * 32 + (l & 31);
+  auto ldA = [&](int kt, int h, int il, int ks) {
+    const int r = ra + il * 32;
+    return *(const bf16x8*)(lds + ((kt & 1) * 4 + h) * HALF + r * BK + (((ks * 2 + hi) ^ ((r >> 1) & 7)) << 3));
+  };
+  auto ldB = [&](int kt, int h, int ks) {
+    return *(const bf16x8*)(lds + ((kt & 1) * 4 + 2 + h) * HALF + rb * BK + (((ks * 2 + hi) ^ ((rb >> 1) & 7)) << 3));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+#ifdef TFX_PP_TIMING
+  // debug build: wave 0 / lane 0 of every block stamps s_memtime into (uint64*)aux[blockIdx * 8 + i] (EPI_BF16 does not use aux)
+  unsigned long long* stamps = (unsigned long long*)p.aux + (size_t)blockIdx.x * 8;
+#define PP_STAMP(i) { if (t == 0) stamps[i] = __builtin_readcyclecounter(); }
+#else
+#define PP_STAMP(i)
+#endif
+  PP_STAMP(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
+  issueA(0, 0); issueB(0, 0); issueB(0, 1); issueA(0, 1);
+  if (nk > 1) {
+    issueA(1, 0); issueB(1, 0); issueB(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  PP_STAMP(1)
+  if (wr == 1) __builtin_amdgcn_s_barrier();                      // group 1 runs one barrier behind group 0 from here on
+
+#define PP_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#define PP_MFMA(I0, J, AF, BF)                                                                                \
+  __builtin_amdgcn_s_setprio(1);                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                          \
+    acc[I0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF[0][ks], acc[I0][J], 0, 0, 0);            \
+    acc[I0 + 1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF[1][ks], acc[I0 + 1][J], 0, 0, 0);    \
+  }                                                                                                           \
+  __builtin_amdgcn_s_setprio(0);                                                                              \
+  asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));   /* pin: LLVM may sink pure MFMAs past the barrier */
+
+  for (int kt = 0; kt < nk; kt++) {
+    bf16x8 a[2][4], b0[4], b1[4];
+    // ---- phase 1
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) b0[ks] = ldB(kt, 0, ks);
+#pragma unroll
+    for (int il = 0; il < 2; il++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) a[il][ks] = ldA(kt, 0, il, ks);
+    if (kt + 1 < nk) issueA(kt + 1, 1);
+    PP_BAR()
+    PP_MFMA(0, 0, a, b0)
+    PP_BAR()
+    // ---- phase 2
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) b1[ks] = ldB(kt, 1, ks);
+    PP_BAR()
+    PP_MFMA(0, 1, a, b1)
+    PP_BAR()
+    // ---- phase 3
+#pragma unroll
+    for (int il = 0; il < 2; il++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) a[il][ks] = ldA(kt, 1, il, ks);
+    if (kt + 2 < nk) { issueA(kt + 2, 0); issueB(kt + 2, 0); }
+    PP_BAR()
+    PP_MFMA(2, 1, a, b1)
+    PP_BAR()
+    // ---- phase 4
+    if (kt + 2 < nk) { issueB(kt + 2, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR()
+    PP_MFMA(2, 0, a, b0)
+    PP_BAR()
+  }
+#undef PP_BAR
+#undef PP_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  PP_STAMP(2)
+  if constexpr (EPI == EPI_BF16) {
+    if (can_stage_bf16(p)) staged_epilogue_bf16<4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 4096);   // all of LDS is free after the last barrier
+    else fast_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64);
+  } else {
+    fast_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64);    // N % 4 == 0 (launcher)
+  }
+  PP_STAMP(3)
+#ifdef TFX_PP_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_STAMP(4)
+#endif
+#undef PP_STAMP
 }
 
 // TN, 4-stage ring of 32-row slabs (16 KiB per stage, 64 KiB per block -> 2 blocks per CU), three slabs in flight.
@@ -807,16 +1086,24 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
   // 256x256 tiles when they still fill the chip (>= 2 tiles per CU) and the ragged last N tile wastes < 15 %
   const bool want256 = mode == 2 || (mode == 1 && t256 >= 512 && (p.N % BN2 == 0 || p.N % BN2 >= 224 || p.N >= 8 * BN2));
-  if (use_glds() && want256) {
+  const bool dma = use_glds() && (p.N & 3) == 0;      // the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups
+  if (dma && want256) {
     static bool attr_set = false;
     const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_set = true; }
-    // one tile per block: walking several tiles per block (grid = #CUs, cross-tile prefetch) measured slower at large K and
-    // no faster at K = 512, where the row-scattered epilogue stores are what costs (tools/bench_gemm.py, TFX_DEBUG_NOSTORE)
+    // one tile per block: walking several tiles per block (grid = #CUs, cross-tile prefetch) measured slower at large K
+    static int pp = -1;
+    if (pp < 0) { const char* e = getenv("TFX_NT_PP"); pp = e ? atoi(e) : 1; }
+    if (pp) {
+      static bool attr_pp = false;
+      if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
+      hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
+      return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(gemm_nt_256_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
     return (int)hipGetLastError();
   }
-  if (use_glds()) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
+  if (dma) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
   else hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
   return (int)hipGetLastError();
 }

@@ -204,7 +204,7 @@ class Plan:
                     gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1])
         self._k(L, 'tfx_rmsnorm_fwd', 'tfx_rmsnorm_args', T=T, d=d, x=self.xres[D], y=self.embed, gamma=pp('transformer.norm.gamma'))
         self.fwd_embed_end = len(L)          # launches up to here produce `embed` (return_embed / decode paths stop here)
-        self._nt(L, A=self.embed, lda=d, B=S['logits'], ldb=d, M=T, N=md.vocab, K=d, epi=E['TFX_EPI_F32'], C=self.logits, ldc=md.vp)
+        self._nt(L, A=self.embed, lda=d, B=S['logits'], ldb=d, M=T, N=md.vp, K=d, algo_n=md.vocab, epi=E['TFX_EPI_F32'], C=self.logits, ldc=md.vp)   # zero pad rows: N % 4 == 0 keeps the LDS-DMA kernel
         self.fwd_logits_end = len(L)
         if self.cache is not None:
             # decode plans: flow prediction only (model_to_latent on the modality rows), no losses.  `row_src` = row_tok with

@@ -313,7 +313,7 @@ class ParamStore:
             C(stream, self.ptr(f'model_to_latent_projs.{t}.weight'), d, dl, d, S(f'outp{t}', dl, d))
             C(stream, self.ptr(f'model_to_latent_projs.{t}.weight'), d, dl, d, S(f'outp_t{t}', d, dlp), transpose=True, n_rows_logical=dl)
         C(stream, self.ptr('text_embed.weight'), d, md.vocab, d, S('embed', md.vocab, d))
-        C(stream, self.ptr('to_text_logits.weight'), d, md.vocab, d, S('logits', md.vocab, d))
+        C(stream, self.ptr('to_text_logits.weight'), d, md.vocab, d, S('logits', md.vp, d))
         C(stream, self.ptr('to_text_logits.weight'), d, md.vocab, d, S('logits_t', d, md.vp), transpose=True, n_rows_logical=md.vocab)
         self._launch_casts(stream)
         self._shadow_version = ver
