@@ -283,7 +283,115 @@ TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w
 #endif
   }
 }
-TFX_DEV bool can_stage_bf16(const GemmNT& p) { return ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0; }
+// 32x32 bf16 block (64-byte rows; chunk XOR ((row >> 2) & 3)) for the GEGLU product h = a * gelu(g)
+TFX_DEV void stage_put4_32(bf16* st, int row, int col, f32x4 v) {
+  bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
+  *(bf16x4*)(st + row * 32 + (((col >> 3) ^ ((row >> 2) & 3)) << 3) + (col & 7)) = o;
+}
+// GEGLU forward / backward with staged stores.  Forward: per 32-row block one [a|g] block (32x64) and one h block (32x32).
+// Backward: per 32-row block two [da|dg] blocks (one per 32 dh columns).  The saved-activation loads of the backward stay
+// per-lane 8-byte loads, issued one block ahead of their use (see fast_epilogue).
+template <int EPI, int NI>
+TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+  int mo[NI][4], mo2[NI][2];                                   // rows of the 8-lane-per-row / 4-lane-per-row flush passes
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int m = m_w + i * 32 + q * 8 + (l >> 3); mo[i][q] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1; }
+#pragma unroll
+    for (int q = 0; q < 2; q++) { const int m = m_w + i * 32 + q * 16 + (l >> 2); mo2[i][q] = (EPI == EPI_GEGLU && m < p.M) ? (p.rowmap ? p.rowmap[m] : m) : -1; }
+  }
+  auto flush64 = [&](const bf16* s, int i, int n_base, int Nout) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = q * 8 + (l >> 3);
+      const bf16x8 v = *(const bf16x8*)(s + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+      if (n_base + ch * 8 < Nout && mo[i][q] >= 0) *(bf16x8*)((bf16*)p.C + (size_t)mo[i][q] * p.ldc + n_base + ch * 8) = v;
+    }
+  };
+  if constexpr (EPI == EPI_GEGLU) {
+    f32x4 ba[4], bg[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ba[g] = z; bg[g] = z;
+      if (p.bias) { const int n_a = min(n_w + 8 * g + 4 * hi, p.N - 36); ba[g] = *(const f32x4*)(p.bias + n_a); bg[g] = *(const f32x4*)(p.bias + n_a + 32); }
+    }
+    const int c4 = l & 3;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      bf16* s = st + (i & 1) * 3072;                           // [a|g] 2048 elements + h 1024 elements, double-buffered
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int nl = 8 * g + 4 * hi;
+        f32x4 a, gt, h;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e] + ba[g][e]; gt[e] = acc[i][1][4 * g + e] + bg[g][e]; h[e] = a[e] * gelu_erf(gt[e]); }
+        stage_put4(s, r, nl, a); stage_put4(s, r, 32 + nl, gt); stage_put4_32(s + 2048, r, nl, h);
+      }
+      flush64(s, i, n_w, p.N);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int row = q * 16 + (l >> 2);
+        const bf16x8 v = *(const bf16x8*)(s + 2048 + row * 32 + ((c4 ^ ((row >> 2) & 3)) << 3));
+        const int feat = (n_w >> 6) * 32 + c4 * 8;
+        if (n_w < p.N && mo2[i][q] >= 0) *(bf16x8*)((bf16*)p.C2 + (size_t)mo2[i][q] * p.ldc2 + feat) = v;
+      }
+    }
+  } else {   // EPI_GEGLU_BWD
+    bf16x4 a4[2][2][4], g4[2][2][4];                           // [buffer][j][g]
+    auto load_aux = [&](int b, int i) {
+      const int m = min(m_w + i * 32 + r, p.M - 1);
+      const bf16* ap = p.aux + (size_t)m * p.ldaux + 4 * hi;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int blk = min((n_w >> 5) + j, (p.N >> 5) - 1);
+#pragma unroll
+        for (int g = 0; g < 4; g++) { a4[b][j][g] = *(const bf16x4*)(ap + blk * 64 + 8 * g); g4[b][j][g] = *(const bf16x4*)(ap + blk * 64 + 32 + 8 * g); }
+      }
+    };
+    load_aux(0, 0);
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      if (i + 1 < NI) load_aux((i + 1) & 1, i + 1);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        bf16* s = st + j * 2048;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          f32x4 da, dg;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float dh = acc[i][j][4 * g + e], a = bf2f(a4[i & 1][j][g][e]), gg = bf2f(g4[i & 1][j][g][e]);
+            const float cdf = 0.5f * (1.f + erff(gg * 0.70710678118654752440f));        // one erf serves gelu and its derivative
+            da[e] = dh * gg * cdf;
+            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * __expf(-0.5f * gg * gg));
+          }
+          stage_put4(s, r, 8 * g + 4 * hi, da); stage_put4(s, r, 32 + 8 * g + 4 * hi, dg);
+        }
+        if (n_w + j * 32 < p.N) flush64(s, i, ((n_w >> 5) + j) * 64, 2 * p.N);
+      }
+    }
+  }
+}
+template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
+  bool ok = ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0;
+  if constexpr (EPI == EPI_GEGLU) ok = ok && (p.ldc2 & 7) == 0 && (((uintptr_t)p.C2) & 15) == 0;
+  return ok;
+}
+// epilogue of the LDS-DMA kernels: staged stores where the layout allows, else the direct pipelined form.
+// `st` = this wave's private LDS staging area (>= 12 KiB), valid once every wave has left the K loop.
+template <int EPI, int NI>
+TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  if constexpr (EPI == EPI_BF16) {
+    if (can_stage<EPI>(p)) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }
+  } else if constexpr (EPI == EPI_GEGLU || EPI == EPI_GEGLU_BWD) {
+    if (can_stage<EPI>(p)) { staged_epilogue_geglu<EPI, NI>(p, acc, m_w, n_w, st); return; }
+  }
+  fast_epilogue<EPI, NI>(p, acc, m_w, n_w);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // gemm_nt
@@ -602,7 +710,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
     }
   }
 
-  fast_epilogue<EPI, 2>(p, acc, m0 + wm * 64, n0 + wn * 64);      // N % 4 == 0 (launcher)
+  __builtin_amdgcn_s_barrier();                                  // every wave is done with the operand tiles: LDS becomes staging space
+  nt_epilogue<EPI, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, As + w * 8192);   // 16 KiB per wave of the 64 KiB ring
 }
 
 // 256x256x64 tile, 8 waves (2 x 4, wave tile 128x64 = 4x2 MFMA blocks), 2-stage LDS-DMA ring (128 KiB, one block per CU).
@@ -868,12 +977,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #undef PP_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();
   PP_STAMP(2)
-  if constexpr (EPI == EPI_BF16) {
-    if (can_stage_bf16(p)) staged_epilogue_bf16<4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 4096);   // all of LDS is free after the last barrier
-    else fast_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64);
-  } else {
-    fast_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64);    // N % 4 == 0 (launcher)
-  }
+  nt_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 8192);   // all of LDS is free after the last barrier: 16 KiB per wave
   PP_STAMP(3)
 #ifdef TFX_PP_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
