@@ -13,6 +13,10 @@ for (M, N, K) in [(65536, 512, 512), (65536, 512, 2816)]:
     for _ in range(3):
         capi.call('tfx_gemm_nt', a, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    st.zero_(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); capi.call('tfx_gemm_nt', a, torch.cuda.current_stream().cuda_stream); e1.record(); torch.cuda.synchronize()
+    print(f'   event time of this launch: {e0.elapsed_time(e1) * 1e3:.1f} us')
     s = st.cpu().double()
     t0 = s[:, 0].min()
     d = lambda i, j: (s[:, j] - s[:, i])

@@ -891,6 +891,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #pragma unroll
     for (int j = 0; j < 2; j++) glds16_asm(gB[h][j] + kt * BK, dst + j * 8 * BK);
   };
+  auto issueA1 = [&](int kt, int h, int j) {                      // one piece (8 rows) of a half-tile
+    const int k0 = kt * BK;
+    const bool second = p.A2 && k0 >= p.K1;
+    glds16_asm(second ? gA2[h][j] + (k0 - p.K1) : gA[h][j] + k0, lds + ((kt & 1) * 4 + h) * HALF + (w * 16 + j * 8) * BK);
+  };
+  auto issueB1 = [&](int kt, int h, int j) { glds16_asm(gB[h][j] + kt * BK, lds + ((kt & 1) * 4 + 2 + h) * HALF + (w * 16 + j * 8) * BK); };
   const int ra = wr * 64 + (l & 31), rb = wc * 32 + (l & 31);
   auto ldA = [&](int kt, int h, int il, int ks) {
     const int r = ra + il * 32;
@@ -917,10 +923,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 #endif
   PP_STAMP(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
-  issueA(0, 0); issueB(0, 0); issueB(0, 1); issueA(0, 1);
+  // DMA schedule, 2 pieces per wave and phase, issued inside the MFMA blocks:  p1: A1(kt+1)  p2: B1(kt+1)  p3: A0(kt+2)  p4: B0(kt+2)
+  // (every slot is re-filled >= 2 phases after its last read: A1 read p3, B1 read p2, A0/B0 read p1 of the K-tile before).
+  // One wait per K-tile: vmcnt(2) before p4's first barrier leaves only A0(kt+2) outstanding, i.e. certifies all of K-tile kt+1
+  // one phase before its first read.
+  issueA(0, 0); issueB(0, 0); issueA(0, 1); issueB(0, 1);
   if (nk > 1) {
-    issueA(1, 0); issueB(1, 0); issueB(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    issueA(1, 0); issueB(1, 0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // all of K-tile 0 landed, A0,B0 of K-tile 1 in flight
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -929,48 +939,51 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();                      // group 1 runs one barrier behind group 0 from here on
 
 #define PP_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
-#define PP_MFMA(I0, J, AF, BF)                                                                                \
+// MFMA block of one phase; the phase's two LDS-DMA pieces are issued BETWEEN its MFMAs (after k-steps 0 and 2), where their
+// issue cost hides under the matrix pipe (~60 cycles there against 100-185 in a segment that also carries the ds_reads).
+#define PP_MFMA(I0, J, AF, BF, DMA0, DMA1)                                                                    \
   __builtin_amdgcn_s_setprio(1);                                                                              \
   _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                          \
     acc[I0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF[0][ks], acc[I0][J], 0, 0, 0);            \
     acc[I0 + 1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF[1][ks], acc[I0 + 1][J], 0, 0, 0);    \
+    if (ks == 0) { DMA0; }                                                                                    \
+    if (ks == 2) { DMA1; }                                                                                    \
   }                                                                                                           \
   __builtin_amdgcn_s_setprio(0);                                                                              \
   asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));   /* pin: LLVM may sink pure MFMAs past the barrier */
 
   for (int kt = 0; kt < nk; kt++) {
     bf16x8 a[2][4], b0[4], b1[4];
-    // ---- phase 1
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // ---- phase 1: read a0, b0 ; MFMA (a0, b0) + DMA A1(kt+1)
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) b0[ks] = ldB(kt, 0, ks);
 #pragma unroll
     for (int il = 0; il < 2; il++)
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) a[il][ks] = ldA(kt, 0, il, ks);
-    if (kt + 1 < nk) issueA(kt + 1, 1);
     PP_BAR()
-    PP_MFMA(0, 0, a, b0)
+    PP_MFMA(0, 0, a, b0, if (n1) issueA1(kt + 1, 1, 0), if (n1) issueA1(kt + 1, 1, 1))
     PP_BAR()
-    // ---- phase 2
+    // ---- phase 2: read b1 ; MFMA (a0, b1) + DMA B1(kt+1)
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) b1[ks] = ldB(kt, 1, ks);
     PP_BAR()
-    PP_MFMA(0, 1, a, b1)
+    PP_MFMA(0, 1, a, b1, if (n1) issueB1(kt + 1, 1, 0), if (n1) issueB1(kt + 1, 1, 1))
     PP_BAR()
-    // ---- phase 3
+    // ---- phase 3: read a1 ; MFMA (a1, b1) + DMA A0(kt+2)
 #pragma unroll
     for (int il = 0; il < 2; il++)
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) a[il][ks] = ldA(kt, 1, il, ks);
-    if (kt + 2 < nk) { issueA(kt + 2, 0); issueB(kt + 2, 0); }
     PP_BAR()
-    PP_MFMA(2, 1, a, b1)
+    PP_MFMA(2, 1, a, b1, if (n2) issueA1(kt + 2, 0, 0), if (n2) issueA1(kt + 2, 0, 1))
     PP_BAR()
-    // ---- phase 4
-    if (kt + 2 < nk) { issueB(kt + 2, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    // ---- phase 4: certify K-tile kt+1 (only A0(kt+2) may still be outstanding) ; MFMA (a1, b0) + DMA B0(kt+2)
+    if (n2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR()
-    PP_MFMA(2, 0, a, b0)
+    PP_MFMA(2, 0, a, b0, if (n2) issueB1(kt + 2, 0, 0), if (n2) issueB1(kt + 2, 0, 1))
     PP_BAR()
   }
 #undef PP_BAR
