@@ -11,7 +11,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'tfx.h')
-LIB_PATH = os.path.join(HERE, 'lib', 'libtfx_hip.so')
+LIB_PATH = os.environ.get('TFX_LIB') or os.path.join(HERE, 'lib', 'libtfx_hip.so')     # TFX_LIB: A/B a second build (tools/ab.sh)
 
 _SCALARS = {'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'int': ctypes.c_int}
 

@@ -629,7 +629,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
 // swizzle is applied to the SOURCE address (each lane fetches the chunk its LDS slot must hold) and to the
 // read address - same involution on both sides (cdna_hip_programming.md rule 21).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 TFX_DEV void glds16(const bf16* g, bf16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
@@ -826,14 +825,6 @@ TFX_DEV bf16x8 lds_tr8_swz(const bf16* tile, int rowA, int rowB, int c0) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// LDS-DMA issued from inline asm: hipcc waits vmcnt(0) before every builtin global_load_lds (it models the DMA as a
-// pending LDS write), which caps the pipeline at one tile in flight.  The asm form is invisible to that bookkeeping, so
-// the kernel counts its own DMAs with `s_waitcnt vmcnt(N)` (cdna_hip_programming.md 5.7).  M0 = wave-uniform LDS byte
-// address, written in the same statement that uses it.
-TFX_DEV void glds16_asm(const bf16* g, const bf16* lds_wave_base) {
-  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
-}
 
 // ------------------------------------------------------------------------------------------------
 // Ping-pong 256x256x64 NT kernel ("pp").  In the kernels above both waves of a SIMD are always in the same part of the

@@ -61,6 +61,16 @@ TFX_DEV bf16x8 lds_tr8(const bf16* tile, int stride, int rowA, int rowB, int c0)
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// LDS-DMA (global_load_lds_dwordx4) issued from inline asm: lane i of the wave writes 16 bytes at lds_wave_base + 16*i
+// (lane-linear 1 KiB piece), M0 = wave-uniform LDS byte address.  hipcc models the builtin form as a pending LDS write
+// and drains it with vmcnt(0); the asm form is invisible to that bookkeeping, so kernels count their own DMAs with
+// `s_waitcnt vmcnt(N)` (cdna_hip_programming.md 5.7).
+typedef __attribute__((address_space(3))) void lds_void_t;
+TFX_DEV void glds16_asm(const bf16* g, const bf16* lds_wave_base) {
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
 TFX_DEV float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 TFX_DEV float gelu_erf_grad(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
