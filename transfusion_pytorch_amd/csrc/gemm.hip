@@ -1192,8 +1192,9 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int mode = tile256_mode();
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
-  // 256x256 tiles when they still fill the chip (>= 2 tiles per CU) and the ragged last N tile wastes < 15 %
-  const bool want256 = mode == 2 || (mode == 1 && t256 >= 512 && (p.N % BN2 == 0 || p.N % BN2 >= 224 || p.N >= 8 * BN2));
+  // 256x256 tiles when they still fill the chip (>= 2 tiles per CU); a ragged last N tile costs less than the 128x128 kernel loses (measured)
+  static const int rem_min = getenv("TFX_GEMM_256_REM") ? atoi(getenv("TFX_GEMM_256_REM")) : 8;
+  const bool want256 = mode == 2 || (mode == 1 && t256 >= 512 && (p.N % BN2 == 0 || p.N % BN2 >= rem_min || p.N >= 8 * BN2));
   const bool dma = use_glds() && (p.N & 3) == 0;      // the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups
   if (dma && want256) {
     static bool attr_set = false;
