@@ -18,6 +18,21 @@ CASES = {
     'canon512': (dict(num_text_tokens=256, dim=512, depth=8, dim_latents=(384,),    heads=8, dim_head=64), 'canonical', 2),
 }
 
+# pure-text cases (Transfusion.forward_text): name -> (cfg kwargs, batch, tokens per row incl. the shifted one)
+TEXT_CASES = {
+    'text1': (dict(num_text_tokens=256, dim=128, depth=4, dim_latents=(32,), heads=2, dim_head=64), 3, 98),
+}
+
+
+def build_text_case(name: str):
+    kw, b, n1 = TEXT_CASES[name]
+    cfg = OracleConfig(**kw)
+    text = D.det_randint(f'{name}/text', (b, n1), 0, cfg.num_text_tokens)
+    text[1, -17:] = -1                                     # a padded row: ignore_index labels, id 0 embedded (T:2608)
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag=name)
+    return cfg, sd, text
+
+
 TRAINABLE_EXCLUDE = ('rotary_emb.freqs', 'transformer.to_time_cond.0.weights')
 
 

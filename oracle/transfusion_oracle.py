@@ -351,6 +351,28 @@ def forward_train(sd, cfg: OracleConfig, modalities, times, noise, return_all=Fa
                 is_mod=is_mod, times_tok=times_tok, tokens=tokens)
 
 
+# ---------------------------------------------------------------------------
+# Transfusion.forward_text  (T:2586-2664): pure-text LM path = the transformer with a causal mask, no conditioning,
+# cross entropy over the text-only part of the vocabulary (text_only_logits_mask, T:1509-1510, T:2653)
+# ---------------------------------------------------------------------------
+
+def forward_text(sd, cfg: OracleConfig, text, return_all=False):
+    """text: (b, n+1) int64 token ids (-1 = padding / ignore).  Returns the loss (T:2655-2659)."""
+    inp, labels = text[:, :-1], text[:, 1:]                               # T:2603-2604
+    b, n = inp.shape
+    tokens = sd['text_embed.weight'][inp.masked_fill(inp == -1, 0)]       # T:2608-2609
+    kv_end = torch.arange(1, n + 1).repeat(b, 1)                          # causal_mask=True  (T:2627)
+    rot = torch.arange(n)[None].repeat(b, 1)                              # T:2617-2621
+    is_mod = torch.zeros(b, n, dtype=torch.bool)
+    embed = transformer_forward(sd, cfg, tokens, torch.zeros(b, n), is_mod, kv_end, rot)
+    logits = F.linear(embed, sd['to_text_logits.weight'])                 # T:2639
+    masked = logits[..., :cfg.num_text_tokens]                            # == masked_fill(~text_only_logits_mask, -max) under softmax
+    loss = F.cross_entropy(masked.reshape(-1, masked.shape[-1]), labels.reshape(-1), ignore_index=cfg.ignore_index)
+    if not return_all:
+        return loss
+    return dict(loss=loss, logits=logits, embed=embed)
+
+
 def train_step(sd, cfg, modalities, times, noise, opt_state, lr=3e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8):
     """One `train_toy.py:50-57` step on the restatement: fwd + bwd + clip_grad_norm_(0.5) + Adam(3e-4).
     `sd` values that require grad are updated in place.  Used by bench.py's cpu_baseline ("port")."""

@@ -124,6 +124,38 @@ def test_tiny_matches_live_oracle_and_updates():
         assert torch.allclose(rp, p.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_forward_text_matches_reference_golden():
+    """`forward_text` (T:2586-2664) against the reference's golden loss / logits / gradients
+    (tests/golden/text1.pt, oracle/make_golden_text.py).  Same tolerances as the interleaved path."""
+    from oracle.cases import build_text_case
+    cfg, sd, text = build_text_case('text1')
+    g = torch.load(os.path.join(GOLDEN, 'text1.pt'))
+    model = build_native(cfg, sd)
+    model.train()
+    loss = model.forward_text(text)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f'  loss native {float(loss):.6f} reference {float(g["loss"]):.6f}')
+    assert abs(float(loss) - float(g['loss'])) <= 2e-3 * max(1., abs(float(g['loss'])))
+    plan = model._live[0]
+    embed = plan.embed.view(plan.b, plan.n, -1).float().cpu()
+    assert rel(embed, g['embed']) <= 1.5e-2
+    worst, wsum, nsum = 0., 0., 0.
+    for k, p in model.named_parameters():
+        if k not in g['grad_norms'] or g['grad_norms'][k] < 1e-7:
+            continue
+        assert p.grad is not None, k
+        r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
+        gn = float(p.grad.double().norm())
+        assert abs(gn - g['grad_norms'][k]) <= 6e-2 * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
+    print(f'  gradients: worst head rel {worst:.3e}, norm-weighted mean {wsum / nsum:.3e}')
+    assert worst <= 8e-2 and wsum / nsum <= 2e-2
+    with torch.no_grad():
+        logits = model(text[:, :-1].cuda(), return_loss=False)             # tensor input routes to forward_text (T:2967)
+    assert rel(logits.float().cpu(), g['logits']) <= 1.5e-2
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

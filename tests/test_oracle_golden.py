@@ -77,3 +77,19 @@ def test_oracle_matches_live_reference(name):
     assert (out['logits'] - ref['logits']).abs().max() < 1e-4
     for k, gr in ref['grads'].items():
         assert (sdg[k].grad - gr).norm() <= 1e-5 * gr.norm() + 1e-9, k
+
+
+def test_forward_text_restatement_matches_reference_golden():
+    """pure-text path (T:2586-2664): restatement vs the reference's golden (oracle/make_golden_text.py)"""
+    from oracle.cases import build_text_case, with_grad
+    from oracle.transfusion_oracle import forward_text
+    cfg, sd, text = build_text_case('text1')
+    g = torch.load(os.path.join(GOLDEN, 'text1.pt'))
+    sdg = with_grad(sd)
+    out = forward_text(sdg, cfg, text, return_all=True)
+    out['loss'].backward()
+    assert abs(float(out['loss'].detach()) - float(g['loss'])) < 2e-5
+    assert float((out['logits'].detach() - g['logits']).abs().max()) < 2e-4
+    for k, v in g['grad_norms'].items():
+        gn = float(sdg[k].grad.double().norm())
+        assert abs(gn - v) <= 1e-4 * max(v, 1e-6), k

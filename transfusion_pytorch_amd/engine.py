@@ -251,6 +251,10 @@ class Plan:
         for a in self._seg_args:
             a.n_seg = n_seg
 
+    def set_ce_vocab(self, V: int):
+        """number of logit columns the cross entropy runs over (the full vocabulary, or the text-only prefix for forward_text)"""
+        self._ce_args.V = V
+
     def set_loss_scales(self, ce_scale: float, mse_scales: dict):
         self._ce_args.grad_scale = ce_scale
         for t, s in mse_scales.items():

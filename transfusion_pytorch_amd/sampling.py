@@ -291,6 +291,48 @@ class Sampler:
         return [[(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in st.parts] for st in states]
 
     # ------------------------------------------------------------------ helpers
+    # ------------------------------------------------------------------ pure-text generation (T:2666-2707)
+    def generate_text_only(self, prompt, seq_len, temperature, min_p):
+        """KV-cached greedy / min-p sampling of text only: prefill the prompt once, then one-token decode plans.
+        Mirrors the reference exactly: temperature 0 takes the argmax over ALL logits, otherwise min-p filter, then the
+        text-only mask (T:2690-2698)."""
+        m, md, dev = self.m, self.md, self.dev
+        m._require_gpu()
+        prompt = prompt.to(dev)
+        B, n0 = prompt.shape
+        num = max(0, seq_len - n0)
+        out = torch.empty(B, num, dtype=torch.long, device=dev)
+        if num == 0:
+            return out
+        N = m.num_text_tokens
+
+        def pick(logits):
+            if temperature == 0.:
+                return logits.argmax(dim=-1)
+            lg = _min_p_filter(logits / temperature, min_p)
+            lg = lg[:, :N]                                            # text_only_logits_mask
+            return torch.multinomial(lg.softmax(dim=-1), 1).squeeze(-1)
+
+        plan, S = m._forward_plain([[row] for row in prompt], torch.ones(B, 1, device=dev), add_meta=False)
+        n_pad = S['n']
+        maxlen = (max(n_pad, n0 + num) + 64) // 64 * 64
+        m._decode_plans = {}
+        cache = self._alloc_cache(B, maxlen)
+        self._fill_cache(cache, plan, B, n_pad)
+        tok = pick(plan.logits.view(B, n_pad, md.vp)[:, n0 - 1, :md.vocab].float())
+        out[:, 0] = tok
+        stream = m._stream()
+        p = self._decode_plan(('text', cache.data_ptr()), B, 1, cache, False)
+        rows = np.arange(B, dtype=np.int32) * maxlen
+        for step in range(1, num):
+            L = n0 + step - 1                                          # keys already in the cache
+            self._load(p, ids=tok.to(torch.int32).cpu().numpy(), pos=rows + L, kve=np.full(B, L + 1, np.int32), rot=np.full(B, L, np.int32),
+                       tok_inst=np.full(B, -1, np.int32))
+            Plan.run(p.fwd, stream, 0, p.fwd_logits_end)
+            tok = pick(p.logits[:, :md.vocab].float())
+            out[:, step] = tok
+        return out
+
     def _ensure_capacity(self, cache, states, extra):
         need = max(s.cache_len for s in states) + extra + 1
         if need <= cache.shape[2]:

@@ -128,6 +128,7 @@ class Transfusion(nn.Module):
         self._struct_cache = {}
         self._step_id = 0
         self._live = None
+        self._bwd_scale = None
         self._anchor = None
         self._rope = None
         self._noise_override = None          # test hook: type -> (R, dl) noise (parity runs inject the oracle's noise)
@@ -269,7 +270,10 @@ class Transfusion(nn.Module):
                 return_kv_cache=False, return_times=False, prob_uncond=None):
         self._require_gpu()
         if torch.is_tensor(modalities):
-            raise NotImplementedError('forward_text / forward_modality (pure text / pure modality tensors) are "next" rows of SURVEY.md 8(f)')
+            if modalities.dtype in (torch.int32, torch.int64):                             # T:2967-2968
+                return self.forward_text(modalities, return_loss=return_loss, return_embed=return_embed, cache=cache,
+                                         return_hiddens=return_hiddens, return_kv_cache=return_kv_cache)
+            raise NotImplementedError('forward_modality (a pure modality tensor) is a "next" row of SURVEY.md 8(f)')
         if cache is not None or decoding_text_or_modality is not None or return_kv_cache or velocity_consistency_ema_model is not None \
                 or return_hiddens or return_only_pred_flows:
             raise NotImplementedError('kv-cache decoding / EMA velocity consistency / hiddens through forward() are not wired in the native path yet')
@@ -346,6 +350,8 @@ class Transfusion(nn.Module):
             w_t = float(tm.is_type[t]) / total                                              # T:3343
             mse_scales[t] = 2.0 * self.flow_loss_weight * w_t / (r * md.dim_latents[t])
         plan.set_loss_scales(self.text_loss_weight / total, mse_scales)
+        plan.set_ce_vocab(md.vocab)
+        self._bwd_scale = None
         plan.acc.zero_()
         Plan.run(plan.fwd, stream)
 
@@ -373,13 +379,66 @@ class Transfusion(nn.Module):
             ret = (*ret, times)
         return ret
 
+    # ------------------------------------------------------------------ pure-text LM path (T:2586-2664)
+    def forward_text(self, text, return_loss=True, return_embed=False, cache=None, return_hiddens=False, return_kv_cache=False):
+        """`Transfusion.forward_text`: the hot path with zero modalities - causal mask, no conditioning, cross entropy over the
+        text-only part of the vocabulary (`text_only_logits_mask`, T:1509, T:2653).  KV-cached decoding goes through `sample_*`."""
+        self._require_gpu()
+        if cache is not None or return_hiddens or return_kv_cache:
+            raise NotImplementedError('forward_text: kv cache / hiddens are not wired in the native path (use sample_many for decoding)')
+        dev, stream, md = self.device, self._stream(), self.md
+        text = text.to(dev)
+        inp, labels = (text[:, :-1], text[:, 1:]) if return_loss else (text, None)          # T:2603-2604
+        b, n = inp.shape
+        key = ('text', b, n)
+        S = self._struct_cache.get(key)
+        if S is None:
+            ar = torch.arange(n, dtype=torch.int32)
+            tok_inst = np.full((b, n), -1, dtype=np.int32)
+            seg_start, seg_len = token_segments(tok_inst)
+            D = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev)
+            S = self._struct_cache[key] = dict(tok_inst=D(tok_inst.reshape(-1)), kv_end=D((ar + 1).repeat(b)), q_start=D(ar.repeat(b)),
+                                               rot_pos=D(ar.repeat(b)), seg_start=D(seg_start), seg_len=D(seg_len))
+        self.store.refresh_shadows(stream)
+        plan = self._plan(b, n, 0, {}, training=return_loss)
+        if plan.loaded_structure is not S:
+            plan.set_rope_tables(*self._rope_tables(n))
+            plan.tok_inst.copy_(S['tok_inst']); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['q_start']); plan.rot_pos.copy_(S['rot_pos'])
+            plan.set_segments(S['seg_start'], S['seg_len'])
+            plan.loaded_structure = S
+        plan.text_ids.copy_(inp.masked_fill(inp == -1, 0).reshape(-1))                      # T:2608
+        if not return_loss:
+            Plan.run(plan.fwd, stream, 0, plan.fwd_embed_end if return_embed else plan.fwd_logits_end)
+            if return_embed:
+                return plan.embed.view(b, n, md.dim).float()
+            return plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
+        lab = labels.reshape(-1)
+        plan.labels.copy_(torch.where(lab == self.ignore_index, torch.full_like(lab, -1), lab))
+        plan.set_loss_scales(1.0, {})                        # mean over the valid labels: the count lives on the device (see _bwd_scale)
+        plan.set_ce_vocab(self.num_text_tokens)              # text_only_logits_mask (T:2653)
+        plan.acc.zero_()
+        Plan.run(plan.fwd, stream)
+        cnt = plan.acc[1].clamp(min=1.)
+        loss = plan.acc[0] / cnt                             # T:2655-2659
+        self._bwd_scale = (1. / cnt).detach()
+        self._step_id += 1
+        self._live = (plan, self._step_id)
+        if torch.is_grad_enabled():
+            if self._anchor is None or self._anchor.device != dev:
+                self._anchor = torch.zeros((), device=dev, requires_grad=True)
+            loss = _NativeLoss.apply(self._anchor, self, loss)
+        return loss
+
     def _native_backward(self, grad_out, step_id):
         plan, live_id = self._live
         if live_id != step_id:
             raise RuntimeError('backward() of a stale loss: the native engine keeps the activations of the latest forward only')
         ps = self.store
         ps.ensure_grad_views()
-        go = grad_out.reshape(()).to(torch.bfloat16)          # d(total)/d(loss): scales the loss seeds (everything downstream is linear)
+        go = grad_out.reshape(())                             # d(total)/d(loss): scales the loss seeds (everything downstream is linear)
+        if self._bwd_scale is not None:
+            go = go * self._bwd_scale                         # forward_text: 1 / #valid labels, known on the device only
+        go = go.to(torch.bfloat16)
         plan.dlogits.mul_(go)
         for lt in plan.lat.values():
             lt['dpred'].mul_(go)
@@ -412,6 +471,17 @@ class Transfusion(nn.Module):
                                 return_unprocessed_modalities=return_unprocessed_modalities, cfg_scale=cfg_scale)[0]
 
     sample = sample_one
+
+    @torch.no_grad()
+    def generate_text_only(self, prompt, seq_len, temperature=1.0, min_p=0.1, cache_kv=True):
+        """T:2666-2707; always KV-cached (`cache_kv` kept for signature parity).  Returns the generated ids (b, seq_len - prompt_len)."""
+        from .sampling import Sampler
+        was_training = self.training
+        self.eval()
+        try:
+            return Sampler(self).generate_text_only(prompt, seq_len, temperature, min_p)
+        finally:
+            self.train(was_training)
 
 
 def print_modality_sample(modality_sample):           # T:224-239
