@@ -114,7 +114,7 @@ typedef struct {
   float* dtable;                              /* fp32 [I, ld] (atomic accumulate) */
   float* dgamma_text;                         /* [d] (atomic accumulate) */
   /* optional segment mode (backward): runs of consecutive tokens sharing one tok_inst value; one wave owns a
-   * segment, so an instance's FiLM gradients are reduced in registers and STORED (no atomics).  NULL = per-token atomics */
+   * segment, so an instance's FiLM gradients are reduced in registers and STORED (no atomics).  NULL or n_seg == 0 = per-token atomics */
   const int32_t* seg_start; const int32_t* seg_len; int32_t n_seg;
 } tfx_adaln_pre_args;
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* stream);

@@ -33,6 +33,23 @@ def build_text_case(name: str):
     return cfg, sd, text
 
 
+# pure-modality cases (Transfusion.forward_modality): name -> (cfg kwargs, batch, axial shape, modality type)
+MODALITY_CASES = {
+    'flow1': (dict(num_text_tokens=256, dim=128, depth=4, dim_latents=(48, 32), heads=2, dim_head=64), 3, (5, 7), 1),
+}
+
+
+def build_modality_case(name: str):
+    kw, b, shape, ty = MODALITY_CASES[name]
+    cfg = OracleConfig(**kw)
+    dl = cfg.dim_latents[ty]
+    x = D.det_normalish(f'{name}/x', (b, *shape, dl))
+    noise = D.det_normalish(f'{name}/n', (b, *shape, dl))
+    times = D.det_uniform(f'{name}/t', (b,), 0.05, 0.95)
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag=name)
+    return cfg, sd, x, times, noise, ty
+
+
 TRAINABLE_EXCLUDE = ('rotary_emb.freqs', 'transformer.to_time_cond.0.weights')
 
 

@@ -373,6 +373,38 @@ def forward_text(sd, cfg: OracleConfig, text, return_all=False):
     return dict(loss=loss, logits=logits, embed=embed)
 
 
+# ---------------------------------------------------------------------------
+# Transfusion.forward_modality  (T:2710-2869): pure flow path = the transformer with `modality_only=True`
+# (every token conditioned on its sample's time, no mask, no rotary embedding), MSE on the predicted flow
+# ---------------------------------------------------------------------------
+
+def forward_modality(sd, cfg: OracleConfig, x, times, noise=None, modality_type=0, return_all=False):
+    """x: (b, *axial, dl) latents; times (b,); noise like x (None = no noising, the `return_loss=False` call)."""
+    b, dl = x.shape[0], x.shape[-1]
+    t = modality_type
+    if noise is not None:
+        tt = times.reshape(b, *([1] * (x.ndim - 1)))
+        xt = tt * x + (1. - tt) * noise                                    # T:2755
+        flow = x - noise                                                   # T:2757
+    else:
+        xt = x
+    key = f'latent_to_model_projs.{t}.weight'
+    tok = F.linear(xt, sd[key], sd[f'latent_to_model_projs.{t}.bias']) if key in sd else xt     # T:2770
+    tok = tok.reshape(b, -1, cfg.dim)                                      # pack 'b * d'  T:2783
+    n = tok.shape[1]
+    is_mod = torch.ones(b, n, dtype=torch.bool)
+    kv_end = torch.full((b, n), n)                                         # no mask  (modality_only, T:2800-2804)
+    rot = torch.zeros(b, n, dtype=torch.long)                              # no rotary embedding is passed: position 0 = identity rotation
+    embed = transformer_forward(sd, cfg, tok, times[:, None].expand(b, n), is_mod, kv_end, rot)
+    pred = F.linear(embed, sd[f'model_to_latent_projs.{t}.weight']).reshape(x.shape)            # T:2808
+    if noise is None:
+        return pred
+    loss = F.mse_loss(pred, flow)                                          # T:2817
+    if not return_all:
+        return loss
+    return dict(loss=loss, pred_flow=pred, flow=flow, embed=embed)
+
+
 def train_step(sd, cfg, modalities, times, noise, opt_state, lr=3e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8):
     """One `train_toy.py:50-57` step on the restatement: fwd + bwd + clip_grad_norm_(0.5) + Adam(3e-4).
     `sd` values that require grad are updated in place.  Used by bench.py's cpu_baseline ("port")."""

@@ -156,6 +156,43 @@ def test_forward_text_matches_reference_golden():
     assert rel(logits.float().cpu(), g['logits']) <= 1.5e-2
 
 
+def test_forward_modality_matches_reference_golden():
+    """`forward_modality` (T:2710-2869) and `generate_modality_only` (T:2871-2923) against the reference's
+    golden (tests/golden/flow1.pt, oracle/make_golden_modality.py): two modality types, axial shape (5, 7), type 1 trained."""
+    from oracle.cases import MODALITY_CASES, build_modality_case
+    from oracle.make_golden_modality import gen_noise
+    cfg, sd, x, times, noise, ty = build_modality_case('flow1')
+    shape = MODALITY_CASES['flow1'][2]
+    g = torch.load(os.path.join(GOLDEN, 'flow1.pt'))
+    model = build_native(cfg, sd)
+    model.train()
+    model._noise_override = {ty: noise.cuda()}
+    loss, (flow_loss, _, _) = model.forward_modality(x, times=times, modality_type=ty, return_loss_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f'  loss native {float(loss.detach()):.6f} reference {float(g["loss"]):.6f}')
+    assert abs(float(loss.detach()) - float(g['loss'])) <= 2e-3 * max(1., abs(float(g['loss'])))
+    worst, wsum, nsum = 0., 0., 0.
+    for k, p in model.named_parameters():
+        if k not in g['grad_norms'] or g['grad_norms'][k] < 1e-7:
+            continue
+        assert p.grad is not None, k
+        r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
+        gn = float(p.grad.double().norm())
+        assert abs(gn - g['grad_norms'][k]) <= 6e-2 * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
+    print(f'  gradients: worst head rel {worst:.3e}, norm-weighted mean {wsum / nsum:.3e}')
+    assert worst <= 8e-2 and wsum / nsum <= 2e-2
+    with torch.no_grad():
+        pred = model(x.cuda(), times=times, modality_type=ty, return_loss=False)          # float tensor routes to forward_modality (T:2989)
+    assert pred.shape == x.shape and rel(pred.cpu(), g['pred_noloss']) <= 1.5e-2
+    model._gen_noise_override = gen_noise('flow1', 2, shape, cfg.dim_latents[ty])
+    gen = model.generate_modality_only(batch_size=2, modality_type=ty, fixed_modality_shape=tuple(shape), modality_steps=g['gen_steps'])
+    r = rel(gen.cpu(), g['gen'])
+    print(f'  generate_modality_only ({g["gen_steps"]} grid points): rel {r:.3e}')
+    assert r <= 3e-2
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

@@ -93,3 +93,21 @@ def test_forward_text_restatement_matches_reference_golden():
     for k, v in g['grad_norms'].items():
         gn = float(sdg[k].grad.double().norm())
         assert abs(gn - v) <= 1e-4 * max(v, 1e-6), k
+
+
+def test_forward_modality_restatement_matches_reference_golden():
+    """pure flow path (T:2710-2869): restatement vs the reference's golden (oracle/make_golden_modality.py)"""
+    from oracle.cases import build_modality_case, with_grad
+    from oracle.transfusion_oracle import forward_modality
+    cfg, sd, x, times, noise, ty = build_modality_case('flow1')
+    g = torch.load(os.path.join(GOLDEN, 'flow1.pt'))
+    sdg = with_grad(sd)
+    loss = forward_modality(sdg, cfg, x, times, noise, ty)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 2e-5
+    for k, v in g['grad_norms'].items():
+        gn = float(sdg[k].grad.double().norm())
+        assert abs(gn - v) <= 1e-4 * max(v, 1e-6), k
+    with torch.no_grad():
+        pred = forward_modality(sd, cfg, x, times, None, ty)
+    assert float((pred - g['pred_noloss']).abs().max()) < 2e-4

@@ -1011,13 +1011,13 @@ extern "C" {
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 static inline int grid_segs(int n_seg) { int g = (n_seg + WAVES - 1) / WAVES; static const int cap = getenv("TFX_SEG_CAP") ? atoi(getenv("TFX_SEG_CAP")) : 1024; return g < cap ? (g < 1 ? 1 : g) : cap; }
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) {
-  if (a->seg_start) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
+  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }
 int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) {
-  if (a->seg_start) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
+  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }

@@ -215,13 +215,16 @@ class Plan:
                 self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_src[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
             self.fwd_pred_end = len(L)
             return
+        for t, r in self.R.items():          # flow predictions first, so that a loss-free forward can stop at fwd_pred_end
+            dl = md.dim_latents[t]; lt = self.lat[t]
+            self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_tok[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
+        self.fwd_pred_end = len(L)
         self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
                                        dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
         L.append(('tfx_ce_fwd_bwd', self._ce_args))
         self._mse_args = {}
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
-            self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_tok[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
             self._mse_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['flow'], grad_scale=0.0,
                                                dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + t))
             L.append(('tfx_mse_fwd_bwd', self._mse_args[t]))

@@ -131,6 +131,7 @@ class Transfusion(nn.Module):
         self._bwd_scale = None
         self._anchor = None
         self._rope = None
+        self._gen_noise_override = None      # test hook: initial noise of generate_modality_only
         self._noise_override = None          # test hook: type -> (R, dl) noise (parity runs inject the oracle's noise)
 
     # ------------------------------------------------------------------ nn.Module plumbing
@@ -273,7 +274,8 @@ class Transfusion(nn.Module):
             if modalities.dtype in (torch.int32, torch.int64):                             # T:2967-2968
                 return self.forward_text(modalities, return_loss=return_loss, return_embed=return_embed, cache=cache,
                                          return_hiddens=return_hiddens, return_kv_cache=return_kv_cache)
-            raise NotImplementedError('forward_modality (a pure modality tensor) is a "next" row of SURVEY.md 8(f)')
+            return self.forward_modality(modalities, times=times, modality_type=modality_type, return_loss=return_loss,             # T:2989-2990
+                                         velocity_consistency_ema_model=velocity_consistency_ema_model, return_loss_breakdown=return_breakdown)
         if cache is not None or decoding_text_or_modality is not None or return_kv_cache or velocity_consistency_ema_model is not None \
                 or return_hiddens or return_only_pred_flows:
             raise NotImplementedError('kv-cache decoding / EMA velocity consistency / hiddens through forward() are not wired in the native path yet')
@@ -428,6 +430,101 @@ class Transfusion(nn.Module):
                 self._anchor = torch.zeros((), device=dev, requires_grad=True)
             loss = _NativeLoss.apply(self._anchor, self, loss)
         return loss
+
+    # ------------------------------------------------------------------ pure flow path (T:2710-2869)
+    def forward_modality(self, modalities, times=None, modality_type=None, encode_modality=True, velocity_consistency_ema_model=None,
+                         velocity_consistency_delta_time=1e-5, return_loss=True, return_loss_breakdown=False):
+        """`Transfusion.forward_modality`: every token is a latent of ONE instance per sample (`modality_only=True`): conditioned on
+        the sample's time, no attention mask, no rotary embedding; loss = MSE(pred flow, x - noise).  Encoders / EMA velocity
+        consistency / reconstruction loss are outside the native path."""
+        self._require_gpu()
+        if velocity_consistency_ema_model is not None:
+            raise NotImplementedError('velocity consistency (EMA teacher) is outside the native path (SURVEY.md 8(f) rank 3)')
+        if self.num_modalities > 1 and modality_type is None:
+            raise AssertionError('`modality_type` must be explicitly passed in on forward when training on greater than 1 modality')
+        t = 0 if modality_type is None else int(modality_type)
+        dev, stream, md = self.device, self._stream(), self.md
+        x = modalities.to(dev, torch.float32)
+        dl = md.dim_latents[t]
+        assert x.shape[-1] == dl, f'last dimension must be dim_latent = {dl}'
+        b = x.shape[0]
+        L = int(np.prod(x.shape[1:-1])) if x.ndim > 2 else 1
+        rows = b * L
+        key = ('modality', b, L, t)
+        S = self._struct_cache.get(key)
+        if S is None:
+            inst = torch.arange(b, dtype=torch.int32).repeat_interleave(L)
+            S = self._struct_cache[key] = dict(tok_inst=inst.to(dev), kv_end=torch.full((rows,), L, dtype=torch.int32, device=dev),
+                                               zeros=torch.zeros(rows, dtype=torch.int32, device=dev),
+                                               row_tok=torch.arange(rows, dtype=torch.int32, device=dev),
+                                               empty=torch.zeros(0, dtype=torch.int32, device=dev))
+        self.store.refresh_shadows(stream)
+        plan = self._plan(b, L, b, {t: rows}, training=return_loss)
+        if plan.loaded_structure is not S:
+            plan.set_rope_tables(*self._rope_tables(0))
+            plan.tok_inst.copy_(S['tok_inst']); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['zeros']); plan.rot_pos.copy_(S['zeros'])
+            plan.set_segments(S['empty'], S['empty'])             # one instance spans a whole row: per-token atomics for the instance gradients
+            plan.row_tok[t].copy_(S['row_tok']); plan.row_inst[t].copy_(S['tok_inst'])
+            plan.text_ids.zero_()
+            plan.loaded_structure = S
+        if times is None:
+            times = torch.rand(b, device=dev)                                              # T:2746-2747
+        plan.inst_time.copy_(times.to(dev, torch.float32).reshape(b))
+        lt = plan.lat[t]
+        lt['x'].copy_(x.reshape(rows, dl))
+        if not return_loss:
+            plan.noise_args[t].eps = None                                                  # T:2759-2760: no noising
+            Plan.run(plan.fwd, stream, 0, plan.fwd_pred_end)
+            return lt['pred'].view(x.shape).clone()
+        if self._noise_override is not None:
+            lt['eps'].copy_(self._noise_override[t].reshape(rows, dl))
+        else:
+            lt['eps'].normal_()                                                            # T:2753
+        plan.noise_args[t].eps = lt['eps'].data_ptr()
+        plan.labels.fill_(-1)
+        plan.set_loss_scales(0.0, {t: 2.0 / (rows * dl)})
+        plan.set_ce_vocab(md.vocab)
+        self._bwd_scale = None
+        plan.acc.zero_()
+        Plan.run(plan.fwd, stream)
+        flow_loss = plan.acc[2 + t] / (rows * dl)                                          # T:2817
+        loss = flow_loss
+        self._step_id += 1
+        self._live = (plan, self._step_id)
+        if torch.is_grad_enabled():
+            if self._anchor is None or self._anchor.device != dev:
+                self._anchor = torch.zeros((), device=dev, requires_grad=True)
+            loss = _NativeLoss.apply(self._anchor, self, loss)
+        if not return_loss_breakdown:
+            return loss
+        zero = torch.zeros((), device=dev)
+        return loss, (flow_loss.detach(), zero, zero)
+
+    @torch.no_grad()
+    def generate_modality_only(self, batch_size=1, modality_type=None, fixed_modality_shape=None, modality_steps=16,
+                               return_unprocessed_modalities=False):
+        """T:2871-2923: fixed-grid midpoint ODE from noise to a sample, `modality_steps` grid points on [0, 1]."""
+        self._require_gpu()
+        if self.num_modalities > 1 and modality_type is None:
+            raise AssertionError('`modality_type` must be explicitly passed in on forward when training on greater than 1 modality')
+        t = 0 if modality_type is None else int(modality_type)
+        shape = fixed_modality_shape if fixed_modality_shape is not None else self.modality_default_shape[t]
+        assert shape is not None
+        dev = self.device
+        y = self._gen_noise_override.to(dev, torch.float32).clone() if getattr(self, '_gen_noise_override', None) is not None \
+            else torch.randn((batch_size, *shape, self.md.dim_latents[t]), device=dev)
+        was_training = self.training
+        self.eval()
+        try:
+            grid = torch.linspace(0., 1., modality_steps, device=dev)
+            f = lambda tt, yy: self.forward_modality(yy, times=tt.expand(batch_size), modality_type=t, encode_modality=False, return_loss=False)
+            for i in range(modality_steps - 1):                                            # torchdiffeq fixed-grid 'midpoint'
+                t0, dt = grid[i], grid[i + 1] - grid[i]
+                y_mid = y + f(t0, y) * (dt * 0.5)
+                y = y + dt * f(t0 + dt * 0.5, y_mid)
+        finally:
+            self.train(was_training)
+        return y
 
     def _native_backward(self, grad_out, step_id):
         plan, live_id = self._live
