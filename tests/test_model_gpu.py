@@ -124,6 +124,31 @@ def test_tiny_matches_live_oracle_and_updates():
         assert torch.allclose(rp, p.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_identity_latent_projection_matches_live_oracle():
+    """dim_latent == dim: the reference uses nn.Identity for latent_to_model (T:1478) - noised latents enter the stream unprojected.
+    Checked against the CPU oracle (pinned to the reference) on the same inputs."""
+    from oracle import detdata as D
+    from oracle.transfusion_oracle import OracleConfig
+    cfg = OracleConfig(num_text_tokens=256, dim=64, depth=2, dim_latents=(64,), heads=2, dim_head=64)
+    batch = D.ragged_batch('ident/b', 3, cfg.num_text_tokens, cfg.dim_latents)
+    times = D.det_times('ident/t', batch); noise = D.det_noise('ident/n', batch, cfg.num_modalities)
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag='ident')
+    assert 'latent_to_model_projs.0.weight' not in sd
+    sdg = with_grad(sd)
+    ref = forward_train(sdg, cfg, batch, times, noise, return_all=True)
+    ref['loss'].backward()
+    model = build_native(cfg, sd)
+    model.train()
+    model._noise_override = {t: v.cuda() for t, v in noise.items()}
+    loss = model(batch, times=times)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(ref['loss'])) <= 2e-3 * max(1., abs(float(ref['loss'])))
+    for k, p in model.named_parameters():
+        if sdg[k].requires_grad and sdg[k].grad is not None and float(sdg[k].grad.norm()) > 1e-7:
+            assert rel(p.grad, sdg[k].grad) <= 6e-2, k
+
+
 def test_forward_text_matches_reference_golden():
     """`forward_text` (T:2586-2664) against the reference's golden loss / logits / gradients
     (tests/golden/text1.pt, oracle/make_golden_text.py).  Same tolerances as the interleaved path."""

@@ -155,9 +155,11 @@ class Plan:
             self._k(L, 'tfx_noise_mix', 'tfx_noise_mix_args', R=r, dl=dl, x=lt['x'], eps=lt['eps'], row_inst=self.row_inst[t],
                     inst_time=self.inst_time, xt=lt['xt'], ld_xt=dlp, flow=lt['flow'])
             self.noise_args[t] = L[-1][1]
-            assert dl != d, 'dim_latent == dim (Identity latent_to_model, T:1478) is not wired in the native path yet'
-            self._nt(L, algo_k=dl, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
-                     bias=pp(f'latent_to_model_projs.{t}.bias'), rowmap=self.row_tok[t])
+            if dl == d:       # nn.Identity latent_to_model (T:1478): the noised rows ARE the tokens - scatter them into the stream
+                self._raw(L, capi.lib().tfx_scatter_rows_bf16, lt['xt'].data_ptr(), dlp, d, self.hid[0].data_ptr(), d, self.row_tok[t].data_ptr(), r)
+            else:
+                self._nt(L, algo_k=dl, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
+                         bias=pp(f'latent_to_model_projs.{t}.bias'), rowmap=self.row_tok[t])
         self._k(L, 'tfx_embed_fwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, table=S['embed'], x=self.hid[0])
         if I > 0:
             self._k(L, 'tfx_fourier', 'tfx_fourier_args', I=I, half=d // 2, times=self.inst_time, w=ps.fourier_w, out=self.fe, ld=md.kf)
@@ -348,6 +350,8 @@ class Plan:
         self._tn(L, T, md.vocab, d, A=self.onehot, lda=md.vp, a_cols=md.vp, B=self.dx0, ldb=d, b_cols=d, C=gp('text_embed.weight'), ldc=d)
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            if dl == d:
+                continue                                   # Identity latent_to_model: no parameters (the data gradient is not needed)
             self._tn(L, r, d, dl, A=self.dx0, lda=d, a_cols=d, a_rowmap=self.row_tok[t], B=lt['xt'], ldb=dlp, b_cols=dlp,
                      C=gp(f'latent_to_model_projs.{t}.weight'), ldc=dl)
             self._raw(L, lib.tfx_colsum_bf16, self.dx0.data_ptr(), d, r, d, None, self.row_tok[t].data_ptr(), gp(f'latent_to_model_projs.{t}.bias'))
