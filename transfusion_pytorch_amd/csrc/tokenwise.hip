@@ -51,6 +51,25 @@ template <int NC> TFX_DEV void load_vec(Row<NC>& r, const float* p, int d, int l
     }
   }
 }
+// raw (unconverted) row: 4 VGPRs per 8 elements - used where several rows are prefetched before their first use
+template <int NC> struct RowRaw { bf16x8 v[NC]; };
+template <int NC> TFX_DEV void load_raw(RowRaw<NC>& r, const bf16* p, int d, int lane) {
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    const int c = lane + 64 * i;
+    if (c * 8 < d) r.v[i] = *(const bf16x8*)(p + c * 8);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) r.v[i][e] = f2bf(0.f);
+    }
+  }
+}
+template <int NC> TFX_DEV void widen(Row<NC>& o, const RowRaw<NC>& r) {
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) o.v[i][e] = bf2f(r.v[i][e]);
+}
 // block-level reduction of per-lane column partials over the block's waves, then global atomics
 template <int NC> TFX_DEV void flush_col_partials(const Row<NC>& part, float* out, int d, float* smem /* [WAVES][NC*512] */) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -61,8 +80,8 @@ template <int NC> TFX_DEV void flush_col_partials(const Row<NC>& part, float* ou
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += blockDim.x) {
     float s = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < WAVES; ww++) s += smem[ww * NC * 512 + c];
+    const int nw = blockDim.x >> 6;
+    for (int ww = 0; ww < nw; ww++) s += smem[ww * NC * 512 + c];
     if (s != 0.f) atomicAdd(out + c, s);
   }
   __syncthreads();
@@ -228,8 +247,9 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_k(tfx_ad
 // value (a whole modality instance, or a short chunk of text), so the per-instance FiLM / ada-ln-zero
 // gradients are reduced in registers and written with plain stores - no atomics on the table gradients.
 // ------------------------------------------------------------------------------------------------
-template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_seg_k(tfx_adaln_pre_args p) {
-  __shared__ float smem[WAVES * NC * 512];
+constexpr int SEG_WAVES = 8;      // 512-thread blocks: half as many closing atomics per parameter as 4-wave blocks
+template <int NC> __global__ __launch_bounds__(512) void adaln_pre_bwd_seg_k(tfx_adaln_pre_args p) {
+  __shared__ float smem[SEG_WAVES * NC * 512];
   const int lane = threadIdx.x & 63;
   const int d = p.d;
   Row<NC> pg;
@@ -237,7 +257,7 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_seg_k(tfx
   for (int i = 0; i < NC; i++)
 #pragma unroll
     for (int e = 0; e < 8; e++) pg.v[i][e] = 0.f;
-  for (int s = blockIdx.x * WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * WAVES) {
+  for (int s = blockIdx.x * SEG_WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * SEG_WAVES) {
     const int t0 = p.seg_start[s], len = p.seg_len[s];
     const int inst = p.tok_inst[t0];
     Row<NC> g, ag, ab;
@@ -252,21 +272,22 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_seg_k(tfx
     constexpr int U = NC == 1 ? 4 : (NC == 2 ? 2 : 1);
     const int tend = t0 + len;
     for (int tb = t0; tb < tend; tb += U) {
-      Row<NC> xs[U], dus[U], dxs[U];
+      RowRaw<NC> xs[U], dus[U], dxs[U];                     // raw bf16: 12 prefetched rows cost 48 VGPRs, not 96
       float means[U], rstds[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int t = min(tb + u, tend - 1);
-        load_row(xs[u], p.x + (size_t)t * d, d, lane);
-        load_row(dus[u], p.du + (size_t)t * d, d, lane);
-        load_row(dxs[u], p.dx + (size_t)t * d, d, lane);
+        load_raw(xs[u], p.x + (size_t)t * d, d, lane);
+        load_raw(dus[u], p.du + (size_t)t * d, d, lane);
+        load_raw(dxs[u], p.dx + (size_t)t * d, d, lane);
         means[u] = p.mean[t]; rstds[u] = p.rstd[t];
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int t = tb + u;
         if (t >= tend) break;
-        Row<NC>& x = xs[u]; Row<NC>& du = dus[u]; Row<NC>& dx = dxs[u];
+        Row<NC> x, du, dx;
+        widen(x, xs[u]); widen(du, dus[u]); widen(dx, dxs[u]);
         const float mean = means[u], rstd = rstds[u];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -312,8 +333,8 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_seg_k(tfx
   flush_col_partials<NC>(pg, p.dgamma_text, d, smem);
 }
 
-template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_seg_k(tfx_adaln_post_args p) {
-  __shared__ float smem[WAVES * NC * 512];
+template <int NC> __global__ __launch_bounds__(512) void adaln_post_bwd_seg_k(tfx_adaln_post_args p) {
+  __shared__ float smem[SEG_WAVES * NC * 512];
   const int lane = threadIdx.x & 63;
   const int d = p.d;
   Row<NC> pl;
@@ -321,7 +342,7 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_seg_k(tf
   for (int i = 0; i < NC; i++)
 #pragma unroll
     for (int e = 0; e < 8; e++) pl.v[i][e] = 0.f;
-  for (int s = blockIdx.x * WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * WAVES) {
+  for (int s = blockIdx.x * SEG_WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * SEG_WAVES) {
     const int t0 = p.seg_start[s], len = p.seg_len[s];
     const int inst = p.tok_inst[t0];
     Row<NC> sc, az;
@@ -334,22 +355,24 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_seg_k(tf
     constexpr int U = NC == 1 ? 4 : (NC == 2 ? 2 : 1);      // U tokens per trip, loads first (see adaln_pre_bwd_seg_k)
     const int tend = t0 + len;
     for (int tb = t0; tb < tend; tb += U) {
-      Row<NC> gs[U], ys[U];
+      RowRaw<NC> gs[U], ys[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int t = min(tb + u, tend - 1);
-        load_row(gs[u], p.g + (size_t)t * d, d, lane);
-        load_row(ys[u], p.y + (size_t)t * d, d, lane);
+        load_raw(gs[u], p.g + (size_t)t * d, d, lane);
+        load_raw(ys[u], p.y + (size_t)t * d, d, lane);
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int t = tb + u;
         if (t >= tend) break;
+        Row<NC> gg, yy;
+        widen(gg, gs[u]); widen(yy, ys[u]);
 #pragma unroll
         for (int i = 0; i < NC; i++)
 #pragma unroll
-          for (int e = 0; e < 8; e++) { az.v[i][e] += gs[u].v[i][e] * ys[u].v[i][e]; gs[u].v[i][e] *= sc.v[i][e]; }
-        store_row(gs[u], p.dy + (size_t)t * d, d, lane);
+          for (int e = 0; e < 8; e++) { az.v[i][e] += gg.v[i][e] * yy.v[i][e]; gg.v[i][e] *= sc.v[i][e]; }
+        store_row(gg, p.dy + (size_t)t * d, d, lane);
       }
     }
     if (inst < 0) {
@@ -1009,15 +1032,15 @@ using namespace tfx;
 extern "C" {
 
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
-static inline int grid_segs(int n_seg) { int g = (n_seg + WAVES - 1) / WAVES; static const int cap = getenv("TFX_SEG_CAP") ? atoi(getenv("TFX_SEG_CAP")) : 1024; return g < cap ? (g < 1 ? 1 : g) : cap; }
+static inline int grid_segs(int n_seg) { int g = (n_seg + 7) / 8; static const int cap = getenv("TFX_SEG_CAP") ? atoi(getenv("TFX_SEG_CAP")) : 1024; return g < cap ? (g < 1 ? 1 : g) : cap; }
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) {
-  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
+  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(512), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }
 int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) {
-  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(256), 0, ST(s), *a)); }
+  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(512), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }
