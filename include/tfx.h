@@ -130,6 +130,7 @@ typedef struct {
   const tfx_bf16* g; tfx_bf16* dy;
   float* dtable; float* dlayerscale;
   const int32_t* seg_start; const int32_t* seg_len; int32_t n_seg;   /* optional segment mode, see tfx_adaln_pre_args */
+  float* dbias;                               /* optional [d]: += column sums of dy (the bias gradient of the Linear that produced y) */
 } tfx_adaln_post_args;
 int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* stream);
 int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* stream);

@@ -212,11 +212,11 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_k(tfx_ad
   __shared__ float smem[WAVES * NC * 512];
   const int lane = threadIdx.x & 63;
   const int d = p.d;
-  Row<NC> pl;
+  Row<NC> pl, pb;
 #pragma unroll
   for (int i = 0; i < NC; i++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) pl.v[i][e] = 0.f;
+    for (int e = 0; e < 8; e++) { pl.v[i][e] = 0.f; pb.v[i][e] = 0.f; }
   for (int t = blockIdx.x * WAVES + (threadIdx.x >> 6); t < p.T; t += gridDim.x * WAVES) {
     Row<NC> g, y, s;
     load_row(g, p.g + (size_t)t * d, d, lane);
@@ -234,12 +234,13 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_k(tfx_ad
         float sc;
         if (inst < 0) { sc = 1.f + s.v[i][e]; pl.v[i][e] += gy; }
         else { sc = sigmoidf_(s.v[i][e]); atomicAdd(p.dtable + (size_t)inst * p.ld_table + 2 * d + c * 8 + e, gy * sc * (1.f - sc)); }
-        g.v[i][e] *= sc;
+        g.v[i][e] *= sc; pb.v[i][e] += g.v[i][e];
       }
     }
     store_row(g, p.dy + (size_t)t * d, d, lane);
   }
   flush_col_partials<NC>(pl, p.dlayerscale, d, smem);
+  if (p.dbias) flush_col_partials<NC>(pb, p.dbias, d, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -337,11 +338,11 @@ template <int NC> __global__ __launch_bounds__(512) void adaln_post_bwd_seg_k(tf
   __shared__ float smem[SEG_WAVES * NC * 512];
   const int lane = threadIdx.x & 63;
   const int d = p.d;
-  Row<NC> pl;
+  Row<NC> pl, pb;                                           // per-lane partials: d layerscale, d bias (column sums of dy)
 #pragma unroll
   for (int i = 0; i < NC; i++)
 #pragma unroll
-    for (int e = 0; e < 8; e++) pl.v[i][e] = 0.f;
+    for (int e = 0; e < 8; e++) { pl.v[i][e] = 0.f; pb.v[i][e] = 0.f; }
   for (int s = blockIdx.x * SEG_WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * SEG_WAVES) {
     const int t0 = p.seg_start[s], len = p.seg_len[s];
     const int inst = p.tok_inst[t0];
@@ -371,7 +372,7 @@ template <int NC> __global__ __launch_bounds__(512) void adaln_post_bwd_seg_k(tf
 #pragma unroll
         for (int i = 0; i < NC; i++)
 #pragma unroll
-          for (int e = 0; e < 8; e++) { az.v[i][e] += gg.v[i][e] * yy.v[i][e]; gg.v[i][e] *= sc.v[i][e]; }
+          for (int e = 0; e < 8; e++) { az.v[i][e] += gg.v[i][e] * yy.v[i][e]; gg.v[i][e] *= sc.v[i][e]; pb.v[i][e] += gg.v[i][e]; }
         store_row(gg, p.dy + (size_t)t * d, d, lane);
       }
     }
@@ -397,6 +398,7 @@ template <int NC> __global__ __launch_bounds__(512) void adaln_post_bwd_seg_k(tf
     }
   }
   flush_col_partials<NC>(pl, p.dlayerscale, d, smem);
+  if (p.dbias) flush_col_partials<NC>(pb, p.dbias, d, smem);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -300,9 +300,8 @@ class Plan:
             # ---- feedforward wrapper
             self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.yf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                     layerscale=pp(f'{p}.2.layerscale'), g=G, dy=self.dy, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'),
-                    seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+                    seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0, dbias=gp(f'{p}.2.fn.net.3.bias'))   # ff2 bias gradient = column sums of dy
             self._seg_args.append(L[-1][1])
-            self._raw(L, lib.tfx_colsum_bf16, self.dy.data_ptr(), d, T, d, None, None, gp(f'{p}.2.fn.net.3.bias'))
             self._tn(L, T, d, di, A=self.dy, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
             self._nt(L, algo_n=di, A=self.dy, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=self.dag, ldc=2 * dip,
                      aux=self.ag[i], ldaux=2 * dip)
