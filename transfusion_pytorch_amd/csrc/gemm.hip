@@ -95,9 +95,9 @@ template <> struct Epilogue<EPI_GEGLU_BWD> {
     f32x4 da, dg;
     for (int e = 0; e < 4; e++) {
       const float a = bf2f(a4[e]), g = bf2f(g4[e]);
-      const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752440f));        // one erf serves gelu and its derivative
+      float E; const float cdf = gelu_cdf(g, E);                                    // one exponential serves Phi and phi
       da[e] = dh[e] * g * cdf;
-      dg[e] = dh[e] * a * (cdf + g * 0.39894228040143267794f * __expf(-0.5f * g * g));
+      dg[e] = dh[e] * a * (cdf + g * 0.39894228040143267794f * E);
     }
     bf16* c = (bf16*)p.C + (size_t)mo * p.ldc + col;
     store_bf16x4(c, da); store_bf16x4(c + 32, dg);
@@ -178,9 +178,9 @@ TFX_DEV void fast_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const float dh = acc[i][j][4 * g + e], a = bf2f(in.a[j][g][e]), gg = bf2f(in.g[j][g][e]);
-            const float cdf = 0.5f * (1.f + erff(gg * 0.70710678118654752440f));        // one erf serves gelu and its derivative
+            float E; const float cdf = gelu_cdf(gg, E);                                   // one exponential serves Phi and phi
             da[e] = dh * gg * cdf;
-            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * __expf(-0.5f * gg * gg));
+            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * E);
           }
           store_bf16x4(c + j * 64 + 8 * g, da); store_bf16x4(c + j * 64 + 32 + 8 * g, dg);
         }
@@ -364,9 +364,9 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const float dh = acc[i][j][4 * g + e], a = bf2f(a4[i & 1][j][g][e]), gg = bf2f(g4[i & 1][j][g][e]);
-            const float cdf = 0.5f * (1.f + erff(gg * 0.70710678118654752440f));        // one erf serves gelu and its derivative
+            float E; const float cdf = gelu_cdf(gg, E);                                   // one exponential serves Phi and phi
             da[e] = dh * gg * cdf;
-            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * __expf(-0.5f * gg * gg));
+            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * E);
           }
           stage_put4(s, r, 8 * g + 4 * hi, da); stage_put4(s, r, 32 + 8 * g + 4 * hi, dg);
         }
