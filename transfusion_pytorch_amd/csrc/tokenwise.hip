@@ -605,13 +605,14 @@ template <int NC> __global__ __launch_bounds__(256) void embed_bwd_k(tfx_embed_a
 // 8 threads per 64-wide head vector, 8 contiguous elements (4 rotary pairs) per thread
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args p) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long vid = gid >> 3;
+  // 32-bit index math (the launcher checks T * 2H * 8 < 2^31): a 64-bit divide by a run-time value costs ~100 instructions
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned vid = gid >> 3;
   const int sub = gid & 7;
-  const long long nvec = (long long)p.T * 2 * p.H;
+  const unsigned twoH = 2u * p.H, nvec = (unsigned)p.T * twoH;
   if (vid >= nvec) return;
-  const int t = (int)(vid / (2 * p.H)), rem = (int)(vid % (2 * p.H));
-  const int which = rem / p.H;
+  const int t = (int)(vid / twoH), rem = (int)(vid - (unsigned)t * twoH);
+  const int which = rem >= p.H;
   const int col = rem * 64 + sub * 8;          // which*H*64 + h*64 + sub*8
   bf16x8 x = *(const bf16x8*)(p.qkv + (size_t)t * p.ld_qkv + col);
   float v[8], q = 0.f;
@@ -637,14 +638,18 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args 
   __shared__ float sg[2][64];
   if (threadIdx.x < 128) sg[threadIdx.x >> 6][threadIdx.x & 63] = 0.f;
   __syncthreads();
-  const long long nvec = (long long)p.T * 2 * p.H;
   const int sub = threadIdx.x & 7;      // constant per thread (grid stride is a multiple of 8 threads)
   float pq[8], pk[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { pq[e] = 0.f; pk[e] = 0.f; }
-  for (long long vid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; vid < nvec; vid += ((long long)gridDim.x * blockDim.x) >> 3) {
-    const int t = (int)(vid / (2 * p.H)), rem = (int)(vid % (2 * p.H));
-    const int which = rem / p.H;
+  // incremental (t, rem) instead of a divide per trip; 32-bit (the launcher checks T * 2H * 8 < 2^31)
+  const int twoH = 2 * p.H, nvec_i = p.T * twoH;
+  const int stride = (int)((gridDim.x * blockDim.x) >> 3), st_t = stride / twoH, st_r = stride - st_t * twoH;
+  int vid = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+  int t = vid / twoH, rem = vid - t * twoH;
+  for (; vid < nvec_i; vid += stride, t += st_t, rem += st_r) {
+    if (rem >= twoH) { rem -= twoH; t++; }
+    const int which = rem >= p.H;
     const int col = rem * 64 + sub * 8;
     bf16x8 x = *(const bf16x8*)(p.qkv + (size_t)t * p.ld_qkv + col);
     bf16x8 dy8 = *(const bf16x8*)(p.dqk + (size_t)t * p.ld_dqk + col);
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args 
 #pragma unroll
     for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
     q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-    const float nrm = fmaxf(sqrtf(q), 1e-12f);
+    const float nrm = fmaxf(sqrtf(q), 1e-12f), inv = 1.f / nrm;
     const float sc = (which == 0 ? p.q_scale : 1.f) * 8.f;
     const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
     const int pos = p.rot_pos[t];
@@ -665,17 +670,17 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args 
       float ga = da * cs[i] + db * sn[i];          // inverse rotation
       float gb = db * cs[i] - da * sn[i];
       float ca = sc * (1.f + gm[2 * i]), cb = sc * (1.f + gm[2 * i + 1]);
-      float dga = ga * v[2 * i] / nrm * sc, dgb = gb * v[2 * i + 1] / nrm * sc;
+      float dga = ga * v[2 * i] * (inv * sc), dgb = gb * v[2 * i + 1] * (inv * sc);
       pq[2 * i] += which == 0 ? dga : 0.f; pq[2 * i + 1] += which == 0 ? dgb : 0.f;
       pk[2 * i] += which == 0 ? 0.f : dga; pk[2 * i + 1] += which == 0 ? 0.f : dgb;
       dyn[2 * i] = ga * ca; dyn[2 * i + 1] = gb * cb;
       S += dyn[2 * i] * v[2 * i] + dyn[2 * i + 1] * v[2 * i + 1];
     }
     S += __shfl_xor(S, 1, 64); S += __shfl_xor(S, 2, 64); S += __shfl_xor(S, 4, 64);
-    const float k = S / (nrm * nrm * nrm);
+    const float k = S * inv * inv * inv;
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(dyn[e] / nrm - v[e] * k);
+    for (int e = 0; e < 8; e++) o[e] = f2bf(dyn[e] * inv - v[e] * k);
     *(bf16x8*)(p.dqkv + (size_t)t * p.ld_dqkv + col) = o;
   }
 #pragma unroll
@@ -1058,10 +1063,12 @@ int tfx_embed_bwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunc
 
 int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* s) {
   long long nthreads = (long long)a->T * 2 * a->H * 8;
+  if (nthreads >= (1ll << 31)) return -3;
   hipLaunchKernelGGL(qk_norm_rope_fwd_k, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
 }
 int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* s) {
   long long nthreads = (long long)a->T * 2 * a->H * 8;
+  if (nthreads >= (1ll << 31)) return -3;
   long long g = (nthreads + 255) / 256; if (g > MAXB) g = MAXB;
   hipLaunchKernelGGL(qk_norm_rope_bwd_k, dim3((unsigned)g), dim3(256), 0, ST(s), *a); RET();
 }
