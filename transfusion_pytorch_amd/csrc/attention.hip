@@ -282,24 +282,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
 // backward prep: delta = sum_d dout*og ; dgate = delta*(1-sigmoid(g)) ; do_eff = dout*sigmoid(g)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(tfx_attn_args p) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long vid = gid >> 3;
+  // 32-bit index math (the launcher checks b * n * h * 8 < 2^31): 64-bit divides by run-time values cost ~100 instructions each
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned vid = gid >> 3;
   const int sub = gid & 7;
-  const long long T = (long long)p.b * p.n;
+  const unsigned T = (unsigned)p.b * p.n;
   if (vid >= T * p.h) return;
-  const long long t = vid / p.h; const int h = (int)(vid % p.h);
-  const bf16x8 d8 = *(const bf16x8*)(p.dout + t * p.ld_dout + h * DH + sub * 8);
-  const bf16x8 o8 = *(const bf16x8*)(p.out + t * p.ld_out + h * DH + sub * 8);
-  const float g = sigmoidf_(bf2f(p.gate[t * p.ld_gate + h]));
+  const unsigned t = vid / (unsigned)p.h; const int h = (int)(vid - t * p.h);
+  const bf16x8 d8 = *(const bf16x8*)(p.dout + (size_t)t * p.ld_dout + h * DH + sub * 8);
+  const bf16x8 o8 = *(const bf16x8*)(p.out + (size_t)t * p.ld_out + h * DH + sub * 8);
+  const float g = sigmoidf_(bf2f(p.gate[(size_t)t * p.ld_gate + h]));
   float dl = 0.f; bf16x8 e8;
 #pragma unroll
   for (int e = 0; e < 8; e++) { float d = bf2f(d8[e]); dl += d * bf2f(o8[e]); e8[e] = f2bf(d * g); }
-  *(bf16x8*)(p.do_eff + t * p.ld_do + h * DH + sub * 8) = e8;
+  *(bf16x8*)(p.do_eff + (size_t)t * p.ld_do + h * DH + sub * 8) = e8;
   dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
   if (sub == 0) {
-    const long long bb = t / p.n, i = t % p.n;
-    p.delta[(bb * p.h + h) * p.n + i] = dl;
-    p.dgate[t * p.ld_dgate + h] = f2bf(dl * (1.f - g));
+    const unsigned bb = t / (unsigned)p.n, i = t - bb * p.n;
+    p.delta[((size_t)bb * p.h + h) * p.n + i] = dl;
+    p.dgate[(size_t)t * p.ld_dgate + h] = f2bf(dl * (1.f - g));
   }
 }
 
@@ -526,6 +527,7 @@ int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
   if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out | p.ld_dout | p.ld_do | p.ld_dq | p.ld_dk | p.ld_dv) & 7) return -2;
   if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;
   long long nthreads = (long long)p.b * p.n * p.h * 8;
+  if (nthreads >= (1ll << 31)) return -4;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);

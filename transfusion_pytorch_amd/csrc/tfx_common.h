@@ -85,4 +85,4 @@ TFX_DEV float gelu_erf(float x) { float E; return x * gelu_cdf(x, E); }
 TFX_DEV float gelu_erf_grad(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
-TFX_DEV float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+TFX_DEV float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }   // v_rcp_f32: 1 ulp, no IEEE divide sequence
