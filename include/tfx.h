@@ -214,6 +214,8 @@ typedef struct {
   float grad_scale;                           /* 2 * weight / (R*dl) */
   tfx_bf16* dpred; int32_t ld_d;              /* bf16 [R, ld_d], pad columns zeroed */
   float* acc;                                 /* acc[0] += sum of squared error */
+  int32_t accumulate;                         /* != 0: dpred += gradient (a second target on the same prediction: the
+                                                 velocity-consistency term T:3394-3418), else dpred = gradient */
 } tfx_mse_args;
 int tfx_mse_fwd_bwd(const tfx_mse_args* a, void* stream);
 
@@ -251,6 +253,9 @@ typedef struct {
   int32_t step; const float* sumsq;
 } tfx_adam_args;
 int tfx_adam_step(const tfx_adam_args* a, void* stream);
+/* exponential moving average of a flat parameter buffer: ema = decay * ema + (1 - decay) * online   (ema_pytorch EMA.update, used by
+ * Transfusion.create_ema T:1681-1699) */
+int tfx_ema_update(float* ema, const float* online, int64_t n, float decay, void* stream);
 
 const char* tfx_version(void);
 

@@ -405,6 +405,29 @@ def forward_modality(sd, cfg: OracleConfig, x, times, noise=None, modality_type=
     return dict(loss=loss, pred_flow=pred, flow=flow, embed=embed)
 
 
+# ---------------------------------------------------------------------------
+# velocity-consistency term of Transfusion.forward  (T:3084-3088, T:3378-3418; consistency flow matching, arXiv 2407.02398)
+# ---------------------------------------------------------------------------
+
+def forward_velocity(sd, sd_teacher, cfg: OracleConfig, modalities, times, noise, noise_teacher, delta=1e-3, vc_weight=0.1, return_all=False):
+    """student at times * (1 - delta); EMA teacher (no grad, its own noise) at times + delta; per modality type
+    MSE(student pred flow, teacher pred flow), weighted like the flow losses (token share of the type) and by `vc_weight`."""
+    st = forward_train(sd, cfg, modalities, times * (1. - delta), noise, return_all=True)
+    with torch.no_grad():
+        te = forward_train(sd_teacher, cfg, modalities, times + delta, noise_teacher, return_all=True)
+    P = st['packed']
+    total = st['loss']
+    vel = []
+    for t in sorted(st['pred_flows']):
+        w_t = sum(L for ty, L in zip(P.inst_type, P.inst_len) if ty == t) / P.total_tokens
+        v = F.mse_loss(st['pred_flows'][t], te['pred_flows'][t])
+        vel.append(v)
+        total = total + vc_weight * v * w_t
+    if not return_all:
+        return total
+    return dict(loss=total, velocity=vel, student=st, teacher=te)
+
+
 def train_step(sd, cfg, modalities, times, noise, opt_state, lr=3e-4, clip=0.5, betas=(0.9, 0.999), eps=1e-8):
     """One `train_toy.py:50-57` step on the restatement: fwd + bwd + clip_grad_norm_(0.5) + Adam(3e-4).
     `sd` values that require grad are updated in place.  Used by bench.py's cpu_baseline ("port")."""

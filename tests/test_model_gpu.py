@@ -218,6 +218,51 @@ def test_forward_modality_matches_reference_golden():
     assert r <= 3e-2
 
 
+def test_velocity_consistency_matches_reference_golden():
+    """`forward(..., velocity_consistency_ema_model=teacher)` (T:3084-3088, T:3378-3418) against the reference's
+    golden (tests/golden/velocity1.pt): student and teacher with different weights and different injected noise; plus the EMA
+    wrapper (`create_ema`, fused tfx_ema_update) against a torch lerp."""
+    from oracle.make_golden_velocity import DELTA, velocity_case
+    cfg, sd, sd_t, batch, times, noise, noise_t = velocity_case()
+    g = torch.load(os.path.join(GOLDEN, 'velocity1.pt'))
+    student, teacher = build_native(cfg, sd), build_native(cfg, sd_t)
+    student.train(); teacher.eval()
+    student._noise_override = {t: v.cuda() for t, v in noise.items()}
+    teacher._noise_override = {t: v.cuda() for t, v in noise_t.items()}
+    loss, bd = student(batch, times=times, velocity_consistency_ema_model=teacher, velocity_consistency_delta_time=DELTA, return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f'  loss native {float(loss.detach()):.6f} reference {float(g["loss"]):.6f}; velocity {[round(float(v), 5) for v in bd.velocity]} vs '
+          f'{[round(float(v), 5) for v in g["velocity_losses"]]}')
+    assert abs(float(loss.detach()) - float(g['loss'])) <= 2e-3 * max(1., abs(float(g['loss'])))
+    for a, r in zip(bd.velocity, g['velocity_losses']):
+        assert abs(float(a) - float(r)) <= 3e-3 * max(1., abs(float(r)))
+    worst, wsum, nsum = 0., 0., 0.
+    for k, p in student.named_parameters():
+        if k not in g['grad_norms'] or g['grad_norms'][k] < 1e-7:
+            continue
+        r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
+        gn = float(p.grad.double().norm())
+        assert abs(gn - g['grad_norms'][k]) <= 6e-2 * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
+    print(f'  gradients: worst head rel {worst:.3e}, norm-weighted mean {wsum / nsum:.3e}')
+    assert worst <= 8e-2 and wsum / nsum <= 2e-2
+    # EMA wrapper: after the warm-up copy, update() is ema = d*ema + (1-d)*online in one fused launch
+    ema = student.create_ema()
+    ema.update_after_step, ema.update_every = 0, 1
+    ema.update(); ema.update()                                       # step 0: copy, step 1: copy + initted
+    before = ema.ema_model.store.flat.clone()
+    with torch.no_grad():
+        student.store.flat.add_(0.01)
+    ema.update()
+    d = ema.get_current_decay()
+    torch.cuda.synchronize()
+    expect = before * d + student.store.flat * (1 - d)
+    assert 0. < d < 1. and torch.allclose(ema.ema_model.store.flat, expect, rtol=1e-6, atol=1e-7)
+    out = ema(batch, times=times, return_loss=False)                 # forward goes to the averaged copy
+    assert out.shape[0] == len(batch)
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

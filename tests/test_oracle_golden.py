@@ -111,3 +111,21 @@ def test_forward_modality_restatement_matches_reference_golden():
     with torch.no_grad():
         pred = forward_modality(sd, cfg, x, times, None, ty)
     assert float((pred - g['pred_noloss']).abs().max()) < 2e-4
+
+
+def test_velocity_consistency_restatement_matches_reference_golden():
+    """velocity-consistency term (T:3084-3088, T:3378-3418): restatement vs the reference's golden (oracle/make_golden_velocity.py)"""
+    from oracle.cases import with_grad
+    from oracle.make_golden_velocity import DELTA, velocity_case
+    from oracle.transfusion_oracle import forward_velocity
+    cfg, sd, sd_t, batch, times, noise, noise_t = velocity_case()
+    g = torch.load(os.path.join(GOLDEN, 'velocity1.pt'))
+    sdg = with_grad(sd)
+    out = forward_velocity(sdg, sd_t, cfg, batch, times, noise, noise_t, delta=DELTA, return_all=True)
+    out['loss'].backward()
+    assert abs(float(out['loss'].detach()) - float(g['loss'])) < 2e-5
+    for a, r in zip(out['velocity'], g['velocity_losses']):
+        assert abs(float(a.detach()) - float(r)) < 2e-5
+    for k, v in g['grad_norms'].items():
+        gn = float(sdg[k].grad.double().norm())
+        assert abs(gn - v) <= 1e-4 * max(v, 1e-6), k

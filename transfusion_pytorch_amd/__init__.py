@@ -9,4 +9,6 @@ from .transfusion import (
     create_dataloader,
 )
 
-__all__ = ['Transfusion', 'Transformer', 'LossBreakdown', 'print_modality_sample', 'create_dataloader']
+from .ema import EMA
+
+__all__ = ['Transfusion', 'Transformer', 'LossBreakdown', 'print_modality_sample', 'create_dataloader', 'EMA']

@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void mse_k(tfx_mse_args p) {
       float df = p.pred[(size_t)r * p.ld_pred + c] - p.flow[(size_t)r * p.dl + c];
       s += df * df; g = df * p.grad_scale;
     }
-    p.dpred[i] = f2bf(g);
+    p.dpred[i] = f2bf(p.accumulate ? g + bf2f(p.dpred[i]) : g);
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sacc[threadIdx.x >> 6] = s;
@@ -1027,6 +1027,18 @@ __global__ __launch_bounds__(256) void adam_k(tfx_adam_args p, float step_size, 
   }
 }
 
+__global__ __launch_bounds__(256) void ema_k(float* ema, const float* online, long long n, float decay) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    f32x4 e = *(const f32x4*)(ema + i); const f32x4 o = *(const f32x4*)(online + i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) e[k] = o[k] + decay * (e[k] - o[k]);
+    *(f32x4*)(ema + i) = e;
+  } else {
+    for (long long j = i; j < n; j++) ema[j] = online[j] + decay * (ema[j] - online[j]);
+  }
+}
+
 }  // namespace tfx
 
 // ------------------------------------------------------------------------------------------------
@@ -1147,6 +1159,11 @@ int tfx_adam_step(const tfx_adam_args* a, void* s) {
   const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
   const long long nthr = (a->n + 3) / 4;
   hipLaunchKernelGGL(adam_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ST(s), *a, (float)(a->lr / bc1), (float)(1.0 / sqrt(bc2))); RET();
+}
+int tfx_ema_update(float* ema, const float* online, int64_t n, float decay, void* s) {
+  if (n <= 0) return 0;
+  if (((uintptr_t)ema | (uintptr_t)online) & 15) return -1;
+  hipLaunchKernelGGL(ema_k, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, ST(s), ema, online, (long long)n, decay); RET();
 }
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* s) { return gemm_nt(*a, ST(s)); }
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* s) { return gemm_tn(*a, ST(s)); }

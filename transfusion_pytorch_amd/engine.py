@@ -85,7 +85,8 @@ class Plan:
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64)
             self.lat[t] = dict(x=e(r, dl, dtype=torch.float32), eps=e(r, dl, dtype=torch.float32), xt=z(r, dlp),
                                flow=e(r, dl, dtype=torch.float32), pred=e(r, dl, dtype=torch.float32), dpred=z(r, dlp))
-        self.acc = z(8, dtype=torch.float32)
+        self.acc = z(max(8, 2 + 2 * len(md.dim_latents)), dtype=torch.float32)      # [ce sum, ce count, flow sse per type..., velocity sse per type...]
+        self.vel = []                         # optional launches: velocity-consistency MSE against an EMA teacher's flows (T:3394-3418)
         self.cos_tab = self.sin_tab = None
         self.fwd, self.bwd = [], []
         self.noise_args = {}
@@ -230,6 +231,13 @@ class Plan:
             self._mse_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['flow'], grad_scale=0.0,
                                                dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + t))
             L.append(('tfx_mse_fwd_bwd', self._mse_args[t]))
+        self._vel_args = {}
+        for t, r in self.R.items():          # second target on the same prediction; dpred accumulates.  Run only when a teacher is given
+            dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            lt['vel'] = torch.zeros(r, dl, device=self.ps.device, dtype=torch.float32)
+            self._vel_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['vel'], grad_scale=0.0,
+                                               dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + len(md.dim_latents) + t), accumulate=1)
+            self.vel.append(('tfx_mse_fwd_bwd', self._vel_args[t]))
 
     def _attn_kw(self, i, bwd=False):
         md, hd, ldq = self.md, self.md.hd, self.md.ldq

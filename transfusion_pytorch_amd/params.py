@@ -225,6 +225,10 @@ class ParamStore:
         self._shadow_version = None
         self._maps = {}
 
+    def mark_dirty(self):
+        """the master buffer changed behind autograd's back (fused optimizer / EMA kernels): rebuild the bf16 shadows on next use"""
+        self._shadow_version = None
+
     def params_version(self):
         return sum(p._version for p in self.params.values()) + self.fourier_w._version
 

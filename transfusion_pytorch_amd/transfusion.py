@@ -80,6 +80,12 @@ class Transfusion(nn.Module):
         eps=1e-2, prob_uncond=0.1, modality_processing: str = 'auto',
     ):
         super().__init__()
+        self._init_kwargs = dict(num_text_tokens=num_text_tokens, transformer=transformer, model_output_clean=model_output_clean, dim_latent=dim_latent,
+                                 channel_first_latent=channel_first_latent, add_pos_emb=add_pos_emb, modality_default_shape=modality_default_shape,
+                                 fallback_to_default_shape_if_invalid=fallback_to_default_shape_if_invalid, modality_num_dim=modality_num_dim,
+                                 to_modality_shape_fn=to_modality_shape_fn, ignore_index=ignore_index, flow_loss_weight=flow_loss_weight,
+                                 text_loss_weight=text_loss_weight, velocity_consistency_loss_weight=velocity_consistency_loss_weight,
+                                 odeint_kwargs=odeint_kwargs, eps=eps, prob_uncond=prob_uncond, modality_processing=modality_processing)
         assert modality_processing in PROCESSING_STRATEGIES, \
             f'unknown modality processing strategy `{modality_processing}`, available: {list(PROCESSING_STRATEGIES)}'      # MP:1254-1256
         self.modality_processing = modality_processing
@@ -276,10 +282,14 @@ class Transfusion(nn.Module):
                                          return_hiddens=return_hiddens, return_kv_cache=return_kv_cache)
             return self.forward_modality(modalities, times=times, modality_type=modality_type, return_loss=return_loss,             # T:2989-2990
                                          velocity_consistency_ema_model=velocity_consistency_ema_model, return_loss_breakdown=return_breakdown)
-        if cache is not None or decoding_text_or_modality is not None or return_kv_cache or velocity_consistency_ema_model is not None \
-                or return_hiddens or return_only_pred_flows:
-            raise NotImplementedError('kv-cache decoding / EMA velocity consistency / hiddens through forward() are not wired in the native path yet')
-        return_loss = return_loss and not return_embed
+        if cache is not None or decoding_text_or_modality is not None or return_kv_cache or return_hiddens:
+            raise NotImplementedError('kv-cache decoding / hiddens through forward() are not wired in the native path (use sample_many)')
+        ema = velocity_consistency_ema_model
+        if ema is not None and hasattr(ema, 'ema_model'):                                  # EMA wrapper, T:2967-2969
+            ema = ema.ema_model
+        if ema is not None and not isinstance(ema, Transfusion):
+            raise NotImplementedError('velocity_consistency_ema_model must be a native Transfusion (or the EMA wrapper of one)')
+        return_loss = (return_loss and not return_embed) or return_only_pred_flows or ema is not None
         dev = self.device
         stream = self._stream()
         ps, md = self.store, self.md
@@ -298,6 +308,9 @@ class Transfusion(nn.Module):
             fn = num_modalities_to_times_fn
             times = fn(S['num_mod_dev'].long()) if fn is not None else self._default_times(S['num_mod'], S['num_mod_dev'])
         times = times.to(dev, torch.float32)
+        if ema is not None:                                                                # T:3086-3088
+            orig_times = times.clone()
+            times = times * (1. - velocity_consistency_delta_time)
 
         ps.refresh_shadows(stream)
         plan = self._plan(b, n, I, R, training=return_loss)
@@ -345,6 +358,18 @@ class Transfusion(nn.Module):
             logits = plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
             return (logits, times) if return_times else logits
 
+        if return_only_pred_flows:                                                        # T:3313-3316 (the EMA teacher's call)
+            Plan.run(plan.fwd, stream, 0, plan.fwd_pred_end)
+            if getattr(self, '_flat_pred_flows', False):
+                return {t: plan.lat[t]['pred'] for t in R}
+            out = [[] for _ in range(self.num_modalities)]
+            cursor = {t: 0 for t in R}
+            for gi in range(len(P.inst_b)):
+                t, L = int(P.inst_type[gi]), int(P.inst_len[gi])
+                rows = plan.lat[t]['pred'][cursor[t]:cursor[t] + L]; cursor[t] += L
+                out[t].append(rows.view(*P.inst_shape[gi], md.dim_latents[t]).clone())
+            return out
+
         # ---- loss seeds (the token-count normalisers cancel: d loss / d logit = w / total_tokens, T:3331)
         total = float(P.total_tokens)
         mse_scales = {}
@@ -366,6 +391,29 @@ class Transfusion(nn.Module):
             flow_losses.append(fl)
             loss = loss + self.flow_loss_weight * fl * (float(tm.is_type[t]) / total)
 
+        velocity_losses = None
+        if ema is not None:                                                                # T:3383-3418
+            M = self.num_modalities
+            was_training = ema.training
+            ema.eval()
+            ema._flat_pred_flows = True
+            try:
+                with torch.no_grad():
+                    teacher = ema(modalities, times=orig_times + velocity_consistency_delta_time, return_only_pred_flows=True)
+            finally:
+                ema._flat_pred_flows = False
+                ema.train(was_training)
+            velocity_losses = []
+            for t, r in sorted(R.items()):
+                w_t = float(tm.is_type[t]) / total
+                plan.lat[t]['vel'].copy_(teacher[t])
+                plan._vel_args[t].grad_scale = 2.0 * self.velocity_consistency_loss_weight * w_t / (r * md.dim_latents[t])
+            Plan.run(plan.vel, stream)
+            for t, r in sorted(R.items()):
+                vl = plan.acc[2 + M + t] / (r * md.dim_latents[t])
+                velocity_losses.append(vl)
+                loss = loss + self.velocity_consistency_loss_weight * vl * (float(tm.is_type[t]) / total)
+
         self._step_id += 1
         self._live = (plan, self._step_id)
         if torch.is_grad_enabled():
@@ -376,7 +424,7 @@ class Transfusion(nn.Module):
             return loss
         ret = (loss,)
         if return_breakdown:
-            ret = (*ret, LossBreakdown(loss, text_loss, flow_losses, None, None))
+            ret = (*ret, LossBreakdown(loss, text_loss, flow_losses, velocity_losses, None))
         if return_times:
             ret = (*ret, times)
         return ret
@@ -568,6 +616,17 @@ class Transfusion(nn.Module):
                                 return_unprocessed_modalities=return_unprocessed_modalities, cfg_scale=cfg_scale)[0]
 
     sample = sample_one
+
+    def _clone_architecture(self):
+        """a fresh model with this one's constructor arguments on the same device (weights NOT copied)"""
+        kw = dict(self._init_kwargs)
+        kw['transformer'] = self.transformer_config
+        m = Transfusion(**kw)
+        return m.to(self.device) if self.device.type == 'cuda' else m
+
+    def create_ema(self, beta=0.99, *ema_kwargs):                   # T:1681-1699
+        from .ema import EMA
+        return EMA(self, beta=beta, forward_method_names=('sample', 'sample_one', 'sample_many', 'generate_text_only', 'generate_modality_only'))
 
     @torch.no_grad()
     def generate_text_only(self, prompt, seq_len, temperature=1.0, min_p=0.1, cache_kv=True):
