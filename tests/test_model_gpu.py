@@ -124,6 +124,41 @@ def test_tiny_matches_live_oracle_and_updates():
         assert torch.allclose(rp, p.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('dim,depth,heads,dls', [(192, 3, 3, (40,)), (320, 5, 2, (24, 72)), (576, 2, 1, (8,)), (64, 1, 4, (16,))])
+def test_odd_configurations_match_live_oracle(dim, depth, heads, dls):
+    """shapes off the golden grid - odd depth (U-Net skip pairing, T:1206-1219), heads * 64 != dim, dim not a multiple of 128 /
+    above 512 (two column chunks per lane), tiny latents - against the CPU oracle (pinned to the reference) on the same inputs."""
+    from oracle import detdata as D
+    from oracle.transfusion_oracle import OracleConfig
+    cfg = OracleConfig(num_text_tokens=96, dim=dim, depth=depth, dim_latents=dls, heads=heads, dim_head=64)
+    tag = f'odd/{dim}/{depth}/{heads}'
+    batch = D.ragged_batch(f'{tag}/b', 3, cfg.num_text_tokens, cfg.dim_latents)
+    times = D.det_times(f'{tag}/t', batch); noise = D.det_noise(f'{tag}/n', batch, cfg.num_modalities)
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag=tag)
+    sdg = with_grad(sd)
+    ref = forward_train(sdg, cfg, batch, times, noise, return_all=True)
+    ref['loss'].backward()
+    model = build_native(cfg, sd)
+    model.train()
+    model._noise_override = {t: v.cuda() for t, v in noise.items()}
+    loss = model(batch, times=times)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f'  dim {dim} depth {depth} heads {heads}: loss native {float(loss.detach()):.6f} oracle {float(ref["loss"].detach()):.6f}')
+    assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-3 * max(1., abs(float(ref['loss'].detach())))
+    plan = model._live[0]
+    assert rel(plan.logits.view(plan.b, plan.n, -1)[..., :cfg.vocab].float().cpu(), ref['logits'].detach()) <= 1.5e-2
+    wsum = nsum = 0.
+    for k, p in model.named_parameters():
+        gr = sdg[k].grad if sdg[k].requires_grad else None
+        if gr is None or float(gr.norm()) < 1e-7:
+            continue
+        r = rel(p.grad, gr)
+        assert r <= 8e-2, (k, r)
+        wsum += r * float(gr.norm()); nsum += float(gr.norm())
+    assert wsum / nsum <= 2e-2
+
+
 def test_identity_latent_projection_matches_live_oracle():
     """dim_latent == dim: the reference uses nn.Identity for latent_to_model (T:1478) - noised latents enter the stream unprojected.
     Checked against the CPU oracle (pinned to the reference) on the same inputs."""
