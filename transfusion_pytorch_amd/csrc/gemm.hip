@@ -713,103 +713,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
   nt_epilogue<EPI, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, As + w * 8192);   // 16 KiB per wave of the 64 KiB ring
 }
 
-// 256x256x64 tile, 8 waves (2 x 4, wave tile 128x64 = 4x2 MFMA blocks), 2-stage LDS-DMA ring (128 KiB, one block per CU).
-// One staged K-tile feeds 2048 MFMA-cycles per SIMD - about the loaded-memory latency - so a single tile in flight
-// covers it, and the L2->LDS traffic per flop is half that of the 128x128 tile.
-constexpr int BM2 = 256, BN2 = 256;
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_256_kernel(GemmNT p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16* As = (bf16*)smem_raw;                 // [2][256*64]
-  bf16* Bs = As + 2 * BM2 * BK;               // [2][256*64]
-
-  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = w >> 2, wn = w & 3;
-  const int ntn = (p.N + BN2 - 1) / BN2;
-  const int ntiles = ((p.M + BM2 - 1) / BM2) * ntn;
-  const int nk = p.K / BK;
-  const int G = gridDim.x;                    // PERSISTENT: block b walks virtual tiles b, b+G, ... (G is a multiple of 8 or == ntiles)
-
-  // per-lane staging pointers of the tile being ISSUED (wave w stages rows [32w, 32w+32) of A and of B: 4 pieces of 8 rows each)
-  const bf16 *ga[4], *ga2[4], *gb[4];
-  auto setup = [&](int vt) {
-    const int bid = xcd_remap(vt, ntiles);
-    const int m0 = (bid / ntn) * BM2, n0 = (bid % ntn) * BN2;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int row = w * 32 + j * 8 + (l >> 3);
-      const int c = (l & 7) ^ ((row >> 1) & 7);
-      int rm = min(m0 + row, p.M - 1);
-      if (p.a_rowmap) rm = p.a_rowmap[rm];
-      const int rn = min(n0 + row, p.N - 1);
-      ga[j] = p.A + (size_t)rm * p.lda + c * 8;
-      ga2[j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
-      gb[j] = p.B + (size_t)rn * p.ldb + c * 8;
-    }
-  };
-  auto issue = [&](int kt, int buf) {
-    const int k0 = kt * BK;
-    const bool second = p.A2 && k0 >= p.K1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      glds16(second ? ga2[j] + (k0 - p.K1) : ga[j] + k0, As + buf * BM2 * BK + (w * 32 + j * 8) * BK);
-      glds16(gb[j] + k0, Bs + buf * BN2 * BK + (w * 32 + j * 8) * BK);
-    }
-  };
-  const int arow0 = wm * 128 + (l & 31), brow0 = wn * 64 + (l & 31);
-  auto ldfrag = [&](const bf16* base, int r, int ks) { return *(const bf16x8*)(base + r * BK + (((ks * 2 + hi) ^ ((r >> 1) & 7)) << 3)); };
-
-  int buf = 0;
-  int vt = blockIdx.x;
-  if (vt >= ntiles) return;
-  setup(vt);
-  issue(0, 0);
-  for (; vt < ntiles; vt += G) {
-    const int bid = xcd_remap(vt, ntiles);
-    const int m0 = (bid / ntn) * BM2, n0 = (bid % ntn) * BN2;
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    for (int kt = 0; kt < nk; kt++) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the current K-tile have landed
-      __builtin_amdgcn_s_barrier();                           // ... everyone's have, and the other buffer is free
-      if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-      else if (vt + G < ntiles) { setup(vt + G); issue(0, buf ^ 1); }   // cross-tile prefetch: flies under the epilogue
-      const bf16* as = As + buf * BM2 * BK;
-      const bf16* bs = Bs + buf * BN2 * BK;
-      bf16x8 af[2][4], bfr[2][2];
-#pragma unroll
-      for (int i = 0; i < 4; i++) af[0][i] = ldfrag(as, arow0 + i * 32, 0);
-#pragma unroll
-      for (int j = 0; j < 2; j++) bfr[0][j] = ldfrag(bs, brow0 + j * 32, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const int c = ks & 1;
-        if (ks + 1 < 4) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) af[c ^ 1][i] = ldfrag(as, arow0 + i * 32, ks + 1);
-#pragma unroll
-          for (int j = 0; j < 2; j++) bfr[c ^ 1][j] = ldfrag(bs, brow0 + j * 32, ks + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[c][j], af[c][i], acc[i][j], 0, 0, 0);
-      }
-      buf ^= 1;
-    }
-
-    fast_epilogue<EPI, 4>(p, acc, m0 + wm * 128, n0 + wn * 64);   // N % 4 == 0 (launcher)
-  }
-}
+constexpr int BM2 = 256, BN2 = 256;     // tile of the ping-pong kernel below
 
 // TN with LDS-DMA: unpadded [64][128] tiles, 16-byte chunk index XOR ((row & 3) << 2) keeps the four rows of a
 // ds_read_b64_tr_b16 group on distinct banks.  Needs M % 64 == 0 and no row maps (rows are never zero-filled).
@@ -1080,136 +984,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(GemmTN p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16* As = (bf16*)smem_raw;                         // [2][64*128]
-  bf16* Bs = As + 2 * TN_BMK * 128;                   // [2][64*128]
-
-  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = w >> 1, wk = w & 1;
-  const int ntn = (p.N + 127) / 128, ntk = (p.K + 127) / 128;
-  const int ntile = ntn * ntk;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  // splits == 1 (many tiles, few rows: e.g. the AdaLN weight gradient): one block per tile over all rows
-  const int split = p.splits == 1 ? 0 : xcd + 8 * (local / ntile);
-  const int bid = p.splits == 1 ? xcd_remap(blockIdx.x, gridDim.x) : local % ntile;
-  const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
-  const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
-  const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
-  if (mbeg >= mend) return;
-  const int nsteps = (mend - mbeg) / TN_BMK;
-
-  // wave w stages rows [16w, 16w+16) of both tiles: 4 DMA pieces of 4 rows x 256 B each
-  const bf16 *ga[4], *gb[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int row = w * 16 + j * 4 + (l >> 4);
-    const int c = (l & 15) ^ ((row & 3) << 2);
-    const int ca = min(n0 + c * 8, p.a_cols - 8), cb = min(k0 + c * 8, p.b_cols - 8);   // clamped columns only feed unstored outputs
-    ga[j] = p.A + (size_t)(mbeg + row) * p.lda + ca;
-    gb[j] = p.B + (size_t)(mbeg + row) * p.ldb + cb;
-  }
-  const size_t stepA = (size_t)TN_BMK * p.lda, stepB = (size_t)TN_BMK * p.ldb;
-  auto issue = [&](int st, int buf) {                 // steps are issued in order: running pointers, one 64-bit add each
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      glds16(ga[j], As + buf * TN_BMK * 128 + (w * 16 + j * 4) * 128);
-      glds16(gb[j], Bs + buf * TN_BMK * 128 + (w * 16 + j * 4) * 128);
-      ga[j] += stepA; gb[j] += stepB;
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  issue(0, 0);
-  for (int st = 0; st < nsteps; st++) {
-    const int cur = st & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (st + 1 < nsteps) issue(st + 1, cur ^ 1);
-    const bf16* as = As + cur * TN_BMK * 128;
-    const bf16* bs = Bs + cur * TN_BMK * 128;
-    bf16x8 af[2][2], bfr[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) { af[0][i] = lds_tr8_swz(as, 8 * hi, 8 * hi + 4, wn * 64 + i * 32); bfr[0][i] = lds_tr8_swz(bs, 8 * hi, 8 * hi + 4, wk * 64 + i * 32); }
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const int c = ks & 1;
-      if (ks + 1 < 4) {
-        const int r0 = (ks + 1) * 16 + 8 * hi;
-#pragma unroll
-        for (int i = 0; i < 2; i++) { af[c ^ 1][i] = lds_tr8_swz(as, r0, r0 + 4, wn * 64 + i * 32); bfr[c ^ 1][i] = lds_tr8_swz(bs, r0, r0 + 4, wk * 64 + i * 32); }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bfr[c][j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (n >= p.N) continue;
-      const int no = p.rowmap ? p.rowmap[n] : n;
-      if (no < 0) continue;
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int k = k0 + wk * 64 + j * 32 + (l & 31);
-        if (k < p.k_valid) atomicAdd(p.C + (size_t)no * p.ldc + k, acc[i][j][r] * p.alpha);
-      }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static bool use_glds() {
+static bool use_glds() {             // TFX_GEMM_GLDS=0 forces the register-staged fallback kernels (used by the tests to cover them)
   static int v = -1;
   if (v < 0) { const char* e = getenv("TFX_GEMM_GLDS"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
 }
 
-static int tile256_mode() {          // TFX_GEMM_256: 0 = never, 1 = auto (default), 2 = always
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TFX_GEMM_256"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
 template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int smem = 2 * (BM * BK + BN * BK) * 2;
-  int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const int mode = tile256_mode();
+  const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
-  // 256x256 tiles when they still fill the chip (>= 2 tiles per CU); a ragged last N tile costs less than the 128x128 kernel loses (measured)
-  static const int rem_min = getenv("TFX_GEMM_256_REM") ? atoi(getenv("TFX_GEMM_256_REM")) : 8;
-  const bool want256 = mode == 2 || (mode == 1 && t256 >= 512 && (p.N % BN2 == 0 || p.N % BN2 >= rem_min || p.N >= 8 * BN2));
   const bool dma = use_glds() && (p.N & 3) == 0;      // the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups
-  if (dma && want256) {
-    static bool attr_set = false;
+  // 256x256 ping-pong tiles whenever they still fill the chip (>= 2 tiles per CU); a ragged last N tile costs less than the
+  // 128x128 kernel loses (measured on N = 1544 / 1408).  One tile per block: a persistent walk with cross-tile prefetch measured no faster.
+  if (dma && t256 >= 512) {
+    static bool attr_pp = false;
     const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_set = true; }
-    // one tile per block: walking several tiles per block (grid = #CUs, cross-tile prefetch) measured slower at large K
-    static int pp = -1;
-    if (pp < 0) { const char* e = getenv("TFX_NT_PP"); pp = e ? atoi(e) : 1; }
-    if (pp) {
-      static bool attr_pp = false;
-      if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
-      hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
-      return (int)hipGetLastError();
-    }
-    hipLaunchKernelGGL(gemm_nt_256_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
+    if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
+    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
     return (int)hipGetLastError();
   }
   if (dma) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
@@ -1244,14 +1039,8 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   q.splits = p.splits == 1 ? 1 : (p.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernel's block order)
   int grid = ((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
   const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
-  static int tnms = -1;
-  if (tnms < 0) { const char* e = getenv("TFX_TN_MS"); tnms = e ? atoi(e) : 1; }
-  if (dma_ok && tnms) {
-    hipLaunchKernelGGL(gemm_tn_ms_kernel, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
-    return (int)hipGetLastError();
-  }
   if (dma_ok)
-    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(grid), dim3(256), 2 * 2 * TN_BMK * 128 * 2, s, q);
+    hipLaunchKernelGGL(gemm_tn_ms_kernel, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
   else
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), smem, s, q);
   return (int)hipGetLastError();

@@ -1051,7 +1051,7 @@ using namespace tfx;
 extern "C" {
 
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
-static inline int grid_segs(int n_seg) { int g = (n_seg + 7) / 8; static const int cap = getenv("TFX_SEG_CAP") ? atoi(getenv("TFX_SEG_CAP")) : 1024; return g < cap ? (g < 1 ? 1 : g) : cap; }
+static inline int grid_segs(int n_seg) { int g = (n_seg + 7) / 8; return g < 1024 ? (g < 1 ? 1 : g) : 1024; }   // 8 segments (waves) per 512-thread block
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) {
   if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(512), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }

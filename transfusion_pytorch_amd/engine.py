@@ -42,7 +42,7 @@ def skip_sources(md: ModelDims):
     return src
 
 
-_TN_SPLIT_PRICE = float(os.environ.get('TFX_TN_SPLIT_PRICE', '0.03'))
+_TN_SPLIT_PRICE = 0.03      # cost of one more split (fp32 atomics onto cold gradient lines), in units of one full-M pass; tuned on the full step
 
 
 class Plan:
