@@ -40,7 +40,8 @@ def gemm_nt(**kw):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM NT
-@pytest.mark.parametrize('M,N,K', [(300, 200, 128), (128, 128, 64), (1000, 1544, 512), (4096, 512, 1408), (77, 390, 192)])
+# (33000, 1032, 128) and (65536, 512, 192): >= 512 tiles of 256x256 -> the ping-pong kernel (ragged M and N tiles in the first)
+@pytest.mark.parametrize('M,N,K', [(300, 200, 128), (128, 128, 64), (1000, 1544, 512), (4096, 512, 1408), (77, 390, 192), (33000, 1032, 128), (65536, 512, 192)])
 def test_gemm_nt_bf16_bias(M, N, K):
     torch.manual_seed(0)
     A, B = rnd(M, K), rnd(N, K, scale=K ** -0.5)
@@ -65,9 +66,10 @@ def test_gemm_nt_asymmetric_identity():
     assert torch.equal(C, B.float().T)
 
 
-def test_gemm_nt_split_a_rowmaps_resid():
+@pytest.mark.parametrize('M', [333, 66000])            # 66000 rows x 512 columns: 516 tiles of 256x256 -> ping-pong kernel (split-A, RESID)
+def test_gemm_nt_split_a_rowmaps_resid(M):
     torch.manual_seed(1)
-    M, N, K1, K2 = 333, 256, 128, 192
+    N, K1, K2 = (256 if M < 1000 else 512), 128, 192
     A1, A2 = rnd(M, K1), rnd(M, K2)
     B = rnd(N, K1 + K2, scale=(K1 + K2) ** -0.5)
     R = rnd(M, N)
@@ -77,7 +79,7 @@ def test_gemm_nt_split_a_rowmaps_resid():
     ref = torch.cat([A1, A2], 1).float() @ B.float().T + R.float()
     check('gemm_nt split-A + resid', C, ref, 6e-3)
     # gather A rows + scatter C rows (negative = drop) + residual read at the scattered row
-    Msrc, T = 500, 700
+    Msrc, T = 500, M + 367
     Asrc = rnd(Msrc, K1)
     amap = torch.randint(0, Msrc, (M,), device=DEV, dtype=torch.int32)
     omap = torch.randperm(T, device=DEV)[:M].to(torch.int32)
@@ -114,9 +116,10 @@ def geglu_perm(dip):
     return is_gate, feat
 
 
-def test_gemm_nt_geglu_fwd_bwd():
+@pytest.mark.parametrize('M', [300, 70000])            # 70000 rows: the ping-pong 256x256 kernel and its staged epilogues
+def test_gemm_nt_geglu_fwd_bwd(M):
     torch.manual_seed(3)
-    M, d, dip = 300, 128, 192
+    d, dip = 128, 192 if M < 1000 else 1024
     u = rnd(M, d)
     Wa, Wg = rnd(dip, d, scale=d ** -0.5), rnd(dip, d, scale=d ** -0.5)
     ba, bg = torch.randn(dip, device=DEV), torch.randn(dip, device=DEV)

@@ -8,7 +8,6 @@ list can be captured in a hipGraph.  Math follows SURVEY.md Appendix A (referenc
 from __future__ import annotations
 
 import ctypes
-import os
 
 import numpy as np
 import torch
