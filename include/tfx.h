@@ -216,8 +216,15 @@ typedef struct {
   float* acc;                                 /* acc[0] += sum of squared error */
   int32_t accumulate;                         /* != 0: dpred += gradient (a second target on the same prediction: the
                                                  velocity-consistency term T:3394-3418), else dpred = gradient */
+  /* model_output_clean (T:1297, MP:100-126): `pred` already holds (out - noised) / max(1 - t, clean_eps) (tfx_output_to_flow);
+   * the gradient wrt the model output carries the same 1 / max(1 - t, clean_eps).  row_inst NULL = off */
+  const int32_t* row_inst; const float* inst_time; float clean_eps;
 } tfx_mse_args;
 int tfx_mse_fwd_bwd(const tfx_mse_args* a, void* stream);
+/* model_output_clean: pred[r][c] <- (pred[r][c] - noised[r][c]) / max(1 - t_r, clean_eps), noised = eps ? x*t + eps*(1-t) : x,
+ * t_r = inst_time[row_inst[r]]   (get_model_output_to_flow_fn, MP:100-126) */
+int tfx_output_to_flow(float* pred, const float* x, const float* eps, const int32_t* row_inst, const float* inst_time,
+                       int32_t R, int32_t dl, float clean_eps, void* stream);
 
 /* ---- parameter plumbing ---------------------------------------------------------------------- */
 /* dst[r][c] (bf16, ld_dst, Rd rows, Cd cols) = src[rowmap ? rowmap[r] : r][c] or 0 when out of range / map < 0 */

@@ -40,6 +40,7 @@ def build_reference_model(cfg, sd, modality_default_shape=None):
         transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads),
         modality_processing='flat',     # never 'naive' (times bug MP:390) / 'auto' (timing dependent) - SURVEY §8c
         prob_uncond=0.,
+        model_output_clean=getattr(cfg, 'model_output_clean', False), eps=getattr(cfg, 'eps', 1e-2),
     )
     missing, unexpected = model.load_state_dict(sd, strict=True)
     return model

@@ -30,6 +30,8 @@ class OracleConfig:
     text_loss_weight: float = 1.
     flow_loss_weight: float = 1.
     ignore_index: int = -1
+    model_output_clean: bool = False      # T:1297: the model predicts the clean latent, flows are derived (MP:100-126)
+    eps: float = 1e-2                     # T:1319: floor of (1 - t) in that conversion
 
     # vocabulary layout, T:1420-1449, T:1503
     @property
@@ -292,7 +294,7 @@ def forward_train(sd, cfg: OracleConfig, modalities, times, noise, return_all=Fa
     d = cfg.dim
     # noising + latent_to_model  MP:617-689
     tokens_mod = torch.zeros(b, n1, d)
-    flows = {}
+    flows, projected = {}, {}
     inst_time = torch.stack([times[bi, m] for bi, m in zip(P.inst_b, P.inst_m)]) if P.inst_b else torch.zeros(0)
     for t, x in P.latents.items():
         tt = inst_time[P.inst_of_row[t]][:, None]
@@ -301,6 +303,7 @@ def forward_train(sd, cfg: OracleConfig, modalities, times, noise, return_all=Fa
         flows[t] = x - eps
         key = f'latent_to_model_projs.{t}.weight'
         proj = F.linear(xt, sd[key], sd[f'latent_to_model_projs.{t}.bias']) if key in sd else xt
+        projected[t] = proj
         r = 0
         for gi in P.inst_of_row[t].unique_consecutive().tolist():
             L = P.inst_len[gi]
@@ -330,7 +333,12 @@ def forward_train(sd, cfg: OracleConfig, modalities, times, noise, return_all=Fa
         for gi in P.inst_of_row[t].unique_consecutive().tolist():
             bi, off, L = P.inst_b[gi], P.inst_off[gi], P.inst_len[gi]
             rows.append(embed[bi, off:off + L])
-        pred[t] = F.linear(torch.cat(rows), sd[f'model_to_latent_projs.{t}.weight'])
+        out_rows = torch.cat(rows)
+        if cfg.model_output_clean:
+            # MP:786-792: in the interleaved path the conversion happens in MODEL space, against the PROJECTED noised tokens,
+            # before model_to_latent (forward_modality converts in latent space instead, T:2772-2810)
+            out_rows = (out_rows - projected[t]) / (1. - inst_time[P.inst_of_row[t]][:, None]).clamp_min(cfg.eps)
+        pred[t] = F.linear(out_rows, sd[f'model_to_latent_projs.{t}.weight'])
     # losses  T:3320-3376
     lab = labels.masked_fill(is_mod, cfg.ignore_index)
     lab = lab.masked_fill(lab == cfg.null_text_id, cfg.ignore_index)
@@ -397,6 +405,8 @@ def forward_modality(sd, cfg: OracleConfig, x, times, noise=None, modality_type=
     rot = torch.zeros(b, n, dtype=torch.long)                              # no rotary embedding is passed: position 0 = identity rotation
     embed = transformer_forward(sd, cfg, tok, times[:, None].expand(b, n), is_mod, kv_end, rot)
     pred = F.linear(embed, sd[f'model_to_latent_projs.{t}.weight']).reshape(x.shape)            # T:2808
+    if cfg.model_output_clean:                                             # T:2772-2773, T:2810
+        pred = (pred - xt) / (1. - times.reshape(b, *([1] * (x.ndim - 1)))).clamp_min(cfg.eps)
     if noise is None:
         return pred
     loss = F.mse_loss(pred, flow)                                          # T:2817

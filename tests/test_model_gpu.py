@@ -298,6 +298,39 @@ def test_velocity_consistency_matches_reference_golden():
     assert out.shape[0] == len(batch)
 
 
+def test_model_output_clean_forward_modality_matches_reference_golden():
+    """`model_output_clean=True` on the pure flow path (T:2772-2810): pred flow = (output - x_t) / max(1 - t, eps) in fp32, with the
+    eps floor active for one sample (t = 0.995); golden from the reference (tests/golden/clean1.pt).  The interleaved forward and
+    the sampler refuse the option loudly (model-space conversion)."""
+    from oracle.make_golden_clean import clean_case
+    from transfusion_pytorch_amd import Transfusion
+    cfg, sd, batch, times, noise, xm, tm, nm = clean_case()
+    g = torch.load(os.path.join(GOLDEN, 'clean1.pt'))
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents, model_output_clean=True, eps=cfg.eps,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads), prob_uncond=0.)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    model._noise_override = {1: nm.cuda()}
+    loss = model.forward_modality(xm, times=tm, modality_type=1)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f'  loss native {float(loss.detach()):.4f} reference {float(g["mod_loss"]):.4f}')
+    assert abs(float(loss.detach()) - float(g['mod_loss'])) <= 5e-3 * abs(float(g['mod_loss']))      # 1/(1-t) = 100 amplifies the bf16 floor
+    wsum = nsum = 0.
+    for k, p in model.named_parameters():
+        if k not in g['mod_grad_norms'] or g['mod_grad_norms'][k] < 1e-6:
+            continue
+        r = rel(p.grad.float().reshape(-1)[:1024], g['mod_grad_head'][k])
+        wsum += r * g['mod_grad_norms'][k]; nsum += g['mod_grad_norms'][k]
+    print(f'  gradients: norm-weighted mean rel {wsum / nsum:.3e}')
+    assert wsum / nsum <= 3e-2
+    with torch.no_grad():
+        pred = model.forward_modality(xm, times=tm, modality_type=1, return_loss=False)
+    assert rel(pred.cpu(), g['mod_pred_noloss']) <= 2e-2
+    with pytest.raises(NotImplementedError):
+        model(batch, times=times)
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

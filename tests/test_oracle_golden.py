@@ -129,3 +129,25 @@ def test_velocity_consistency_restatement_matches_reference_golden():
     for k, v in g['grad_norms'].items():
         gn = float(sdg[k].grad.double().norm())
         assert abs(gn - v) <= 1e-4 * max(v, 1e-6), k
+
+
+def test_model_output_clean_restatement_matches_reference_golden():
+    """model_output_clean (T:1297, MP:100-126, MP:786-792): interleaved step (model-space conversion) and forward_modality
+    (latent-space conversion, eps floor active for one instance) vs the reference's golden (oracle/make_golden_clean.py)"""
+    from oracle.cases import with_grad
+    from oracle.make_golden_clean import clean_case
+    from oracle.transfusion_oracle import forward_modality
+    cfg, sd, batch, times, noise, xm, tm, nm = clean_case()
+    g = torch.load(os.path.join(GOLDEN, 'clean1.pt'))
+    sdg = with_grad(sd)
+    loss = forward_train(sdg, cfg, batch, times, noise)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g['loss'])) < 2e-5 * max(1., float(g['loss']))
+    for k, v in g['grad_norms'].items():
+        assert abs(float(sdg[k].grad.double().norm()) - v) <= 1e-4 * max(v, 1e-6), k
+    sdg = with_grad(sd)
+    lm = forward_modality(sdg, cfg, xm, tm, nm, 1)
+    lm.backward()
+    assert abs(float(lm.detach()) - float(g['mod_loss'])) < 2e-5 * max(1., float(g['mod_loss']))
+    for k, v in g['mod_grad_norms'].items():
+        assert abs(float(sdg[k].grad.double().norm()) - v) <= 1e-4 * max(v, 1e-6), k

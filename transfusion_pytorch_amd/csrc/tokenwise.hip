@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256) void mse_k(tfx_mse_args p) {
     if (c < p.dl) {
       float df = p.pred[(size_t)r * p.ld_pred + c] - p.flow[(size_t)r * p.dl + c];
       s += df * df; g = df * p.grad_scale;
+      if (p.row_inst) g *= 1.f / fmaxf(1.f - p.inst_time[p.row_inst[r]], p.clean_eps);
     }
     p.dpred[i] = f2bf(p.accumulate ? g + bf2f(p.dpred[i]) : g);
   }
@@ -1027,6 +1028,16 @@ __global__ __launch_bounds__(256) void adam_k(tfx_adam_args p, float step_size, 
   }
 }
 
+__global__ __launch_bounds__(256) void output_to_flow_k(float* pred, const float* x, const float* eps, const int* row_inst, const float* inst_time,
+                                                        int R, int dl, float clean_eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * dl) return;
+  const int r = i / dl;
+  const float t = inst_time[row_inst[r]];
+  const float noised = eps ? x[i] * t + eps[i] * (1.f - t) : x[i];
+  pred[i] = (pred[i] - noised) / fmaxf(1.f - t, clean_eps);
+}
+
 __global__ __launch_bounds__(256) void ema_k(float* ema, const float* online, long long n, float decay) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 4 <= n) {
@@ -1159,6 +1170,12 @@ int tfx_adam_step(const tfx_adam_args* a, void* s) {
   const double bc1 = 1.0 - pow((double)a->beta1, (double)a->step), bc2 = 1.0 - pow((double)a->beta2, (double)a->step);
   const long long nthr = (a->n + 3) / 4;
   hipLaunchKernelGGL(adam_k, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ST(s), *a, (float)(a->lr / bc1), (float)(1.0 / sqrt(bc2))); RET();
+}
+int tfx_output_to_flow(float* pred, const float* x, const float* eps, const int32_t* row_inst, const float* inst_time,
+                       int32_t R, int32_t dl, float clean_eps, void* s) {
+  if (R <= 0 || dl <= 0) return 0;
+  if ((long long)R * dl >= (1ll << 31)) return -1;
+  hipLaunchKernelGGL(output_to_flow_k, dim3((unsigned)(((long long)R * dl + 255) / 256)), dim3(256), 0, ST(s), pred, x, eps, row_inst, inst_time, R, dl, clean_eps); RET();
 }
 int tfx_ema_update(float* ema, const float* online, int64_t n, float decay, void* s) {
   if (n <= 0) return 0;

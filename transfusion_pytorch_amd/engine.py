@@ -220,6 +220,13 @@ class Plan:
         for t, r in self.R.items():          # flow predictions first, so that a loss-free forward can stop at fwd_pred_end
             dl = md.dim_latents[t]; lt = self.lat[t]
             self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_tok[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
+        self._clean_launch = {}
+        if md.model_output_clean:            # pred <- (pred - noised) / max(1 - t, eps): the model predicts the clean latent (MP:100-126)
+            for t, r in self.R.items():
+                dl = md.dim_latents[t]; lt = self.lat[t]
+                self._clean_launch[t] = [lt['pred'].data_ptr(), lt['x'].data_ptr(), None, self.row_inst[t].data_ptr(), self.inst_time.data_ptr(),
+                                         r, dl, float(md.clean_eps)]
+                L.append((capi.lib().tfx_output_to_flow, self._clean_launch[t]))
         self.fwd_pred_end = len(L)
         self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
                                        dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
@@ -227,15 +234,17 @@ class Plan:
         self._mse_args = {}
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            clean = dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}
             self._mse_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['flow'], grad_scale=0.0,
-                                               dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + t))
+                                               dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + t), **clean)
             L.append(('tfx_mse_fwd_bwd', self._mse_args[t]))
         self._vel_args = {}
         for t, r in self.R.items():          # second target on the same prediction; dpred accumulates.  Run only when a teacher is given
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
             lt['vel'] = torch.zeros(r, dl, device=self.ps.device, dtype=torch.float32)
             self._vel_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['vel'], grad_scale=0.0,
-                                               dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + len(md.dim_latents) + t), accumulate=1)
+                                               dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + len(md.dim_latents) + t), accumulate=1,
+                                               **(dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}))
             self.vel.append(('tfx_mse_fwd_bwd', self._vel_args[t]))
 
     def _attn_kw(self, i, bwd=False):
@@ -262,6 +271,12 @@ class Plan:
         self.seg_start[:n_seg].copy_(seg_start); self.seg_len[:n_seg].copy_(seg_len)
         for a in self._seg_args:
             a.n_seg = n_seg
+
+    def set_noise(self, t: int, eps_ptr):
+        """noise source of modality type t for this run: a device pointer (training: x_t = t x + (1 - t) eps) or None (no noising)"""
+        self.noise_args[t].eps = eps_ptr
+        if t in getattr(self, '_clean_launch', {}):
+            self._clean_launch[t][2] = eps_ptr
 
     def set_ce_vocab(self, V: int):
         """number of logit columns the cross entropy runs over (the full vocabulary, or the text-only prefix for forward_text)"""

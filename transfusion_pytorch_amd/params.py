@@ -34,6 +34,8 @@ class ModelDims:
     dim_head: int
     dim_latents: tuple
     ff_expansion_factor: float = 4.
+    model_output_clean: bool = False      # T:1297: the model predicts the clean latent; flows are derived (MP:100-126)
+    clean_eps: float = 1e-2               # T:1319 `eps`: floor of (1 - t) in that conversion
 
     @property
     def num_modalities(self): return len(self.dim_latents)

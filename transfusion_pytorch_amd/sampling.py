@@ -372,7 +372,7 @@ class Sampler:
         for t in row_tok:
             p.row_tok[t].copy_(up(row_tok[t])); p.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
             p.row_inst[t].copy_(up(np.repeat(np.arange(B, dtype=np.int32), Lmax)))
-            p.noise_args[t].eps = None
+            p.set_noise(t, None)
 
     def _eval(self, p, states, group, Lmax, t, y, stream):
         """one model evaluation of the joint ODE state y (B, Lmax, dmax) at time t -> predicted flow, same layout (T:2468-2521)."""

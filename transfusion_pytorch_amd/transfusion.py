@@ -89,7 +89,7 @@ class Transfusion(nn.Module):
         assert modality_processing in PROCESSING_STRATEGIES, \
             f'unknown modality processing strategy `{modality_processing}`, available: {list(PROCESSING_STRATEGIES)}'      # MP:1254-1256
         self.modality_processing = modality_processing
-        unsupported = dict(model_output_clean=model_output_clean, channel_first_latent=any(cast_tuple(channel_first_latent)),
+        unsupported = dict(channel_first_latent=any(cast_tuple(channel_first_latent)),
                            add_pos_emb=any(cast_tuple(add_pos_emb)), modality_encoder=modality_encoder is not None,
                            modality_decoder=modality_decoder is not None, pre_post_transformer_enc_dec=pre_post_transformer_enc_dec is not None,
                            reconstruction_loss_weight=reconstruction_loss_weight > 0.)
@@ -125,10 +125,11 @@ class Transfusion(nn.Module):
         self.flow_loss_weight, self.text_loss_weight = flow_loss_weight, text_loss_weight
         self.velocity_consistency_loss_weight = velocity_consistency_loss_weight
         self.eps, self.prob_uncond = eps, prob_uncond
+        self.model_output_clean = bool(model_output_clean)
         self.odeint_kwargs = dict(odeint_kwargs)
 
         self.md = ModelDims(num_text_tokens=num_text_tokens, dim=dim, depth=transformer.depth, heads=transformer.heads,
-                            dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor)
+                            dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor, model_output_clean=bool(model_output_clean), clean_eps=float(eps))
         self.store = ParamStore(self.md, self)
         self._plans = {}
         self._struct_cache = {}
@@ -252,7 +253,7 @@ class Transfusion(nn.Module):
         for t in R:
             plan.row_tok[t].copy_(S['row_tok'][t]); plan.row_inst[t].copy_(S['row_inst'][t])
             plan.lat[t]['x'].copy_(torch.cat(latents[t]).to(dev, torch.float32))
-            plan.noise_args[t].eps = None
+            plan.set_noise(t, None)
         Plan.run(plan.fwd, stream, 0, plan.fwd_logits_end)
         return plan, S
 
@@ -284,6 +285,10 @@ class Transfusion(nn.Module):
                                          velocity_consistency_ema_model=velocity_consistency_ema_model, return_loss_breakdown=return_breakdown)
         if cache is not None or decoding_text_or_modality is not None or return_kv_cache or return_hiddens:
             raise NotImplementedError('kv-cache decoding / hiddens through forward() are not wired in the native path (use sample_many)')
+        if self.model_output_clean:
+            raise NotImplementedError('model_output_clean in the interleaved forward converts in MODEL space against the projected noised tokens '
+                                      '(MP:786-792): the difference of two O(1) bf16 activations scaled by 1/(1-t) - not representable at the '
+                                      'bf16 activation precision of the native path; forward_modality / generate_modality_only (latent-space, fp32) support it')
         ema = velocity_consistency_ema_model
         if ema is not None and hasattr(ema, 'ema_model'):                                  # EMA wrapper, T:2967-2969
             ema = ema.ema_model
@@ -347,7 +352,7 @@ class Transfusion(nn.Module):
                 else:
                     lt['eps'].normal_()                                                     # MP:654
             # without a loss there is no noising (MP:658-660): noise_mix with eps = NULL copies x
-            plan.noise_args[t].eps = lt['eps'].data_ptr() if return_loss else None
+            plan.set_noise(t, lt['eps'].data_ptr() if return_loss else None)
 
         if not return_loss:
             end = plan.fwd_embed_end if return_embed else plan.fwd_logits_end
@@ -521,14 +526,14 @@ class Transfusion(nn.Module):
         lt = plan.lat[t]
         lt['x'].copy_(x.reshape(rows, dl))
         if not return_loss:
-            plan.noise_args[t].eps = None                                                  # T:2759-2760: no noising
+            plan.set_noise(t, None)                                                  # T:2759-2760: no noising
             Plan.run(plan.fwd, stream, 0, plan.fwd_pred_end)
             return lt['pred'].view(x.shape).clone()
         if self._noise_override is not None:
             lt['eps'].copy_(self._noise_override[t].reshape(rows, dl))
         else:
             lt['eps'].normal_()                                                            # T:2753
-        plan.noise_args[t].eps = lt['eps'].data_ptr()
+        plan.set_noise(t, lt['eps'].data_ptr())
         plan.labels.fill_(-1)
         plan.set_loss_scales(0.0, {t: 2.0 / (rows * dl)})
         plan.set_ce_vocab(md.vocab)
@@ -596,6 +601,8 @@ class Transfusion(nn.Module):
                     force_modality_at_start=None, init_modality_noise=None, modality_steps=16, return_unprocessed_modalities=False,
                     cfg_scale=3.):
         from .sampling import Sampler
+        if self.model_output_clean:
+            raise NotImplementedError('sample_many with model_output_clean (the model-space flow conversion of T:2446-2456) is not wired in the native decoder')
         was_training = self.training
         self.eval()                                              # @temp_eval in the reference
         try:
