@@ -819,6 +819,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
   // (every slot is re-filled >= 2 phases after its last read: A1 read p3, B1 read p2, A0/B0 read p1 of the K-tile before).
   // One wait per K-tile: vmcnt(2) before p4's first barrier leaves only A0(kt+2) outstanding, i.e. certifies all of K-tile kt+1
   // one phase before its first read.
+#ifdef TFX_PP_TIMING
+  // debug build (tools/pp_timing.py): lane 0 of wave 0 stamps s_memtime into (uint64*)aux[blockIdx * 8 + i] for the block's LAST tile
+  // (EPI_BF16 does not use aux): 0 tile start, 1 head landed, 2 K loop done, 3 epilogue issued, 4 stores retired
+  unsigned long long* stamps = (unsigned long long*)p.aux + (size_t)blockIdx.x * 8;
+#define PP_STAMP(i) { if (t == 0) stamps[i] = __builtin_readcyclecounter(); }
+#else
+#define PP_STAMP(i)
+#endif
   int vt = blockIdx.x;
   setup(vt);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
@@ -849,10 +857,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   // the head of this tile was issued before the previous tile's epilogue: its stores are younger than those DMAs, so
   // later tiles drain everything (the DMAs landed long ago, the stores are the tail); the first tile keeps K-tile 1 in flight
+  PP_STAMP(0)
   if (first && nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   first = false;
   __builtin_amdgcn_s_barrier();
+  PP_STAMP(1)
   if (wr == 1) __builtin_amdgcn_s_barrier();                      // group 1 runs one barrier behind group 0 from here on
 
   for (int kt = 0; kt < nk; kt++) {
@@ -892,6 +902,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();                      // the groups meet again: every LDS read of this tile is retired
   // next tile: coordinates, pointers and the head of its DMA stream go out BEFORE this tile's epilogue, so the ~3 k cycles of
   // cold-load latency and the block relaunch of a one-tile-per-block grid hide under the epilogue's ~6 k cycles
+  PP_STAMP(2)
   const int m0c = m0, n0c = n0;
   if (vt + G < ntiles) {
     setup(vt + G);
@@ -900,7 +911,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
   }
   // staging: the A1 / B1 slots of K-tile buffer 1 are the two half-tiles the head does not touch (4 KiB per wave)
   nt_epilogue<EPI, 4>(p, acc, m0c + wr * 128, n0c + wc * 64, lds + (w < 4 ? 5 : 7) * HALF + (w & 3) * 2048);
+  PP_STAMP(3)
+#ifdef TFX_PP_TIMING
+  if (vt + G >= ntiles) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(4) }
+#endif
   }
+#undef PP_STAMP
 #undef PP_BAR
 #undef PP_MFMA
 }
