@@ -1,5 +1,5 @@
 """Per-block phase timing of the ping-pong NT kernel (needs a library built with TFX_HIPCC_EXTRA=-DTFX_PP_TIMING).
-   stamps (last tile of every block): 0 tile start, 1 head of the DMA stream landed, 2 K loop done, 3 epilogue stores issued, 4 stores retired."""
+   stamps: 0 block start, 1 first K-tile landed, 2 K loop done, 3 epilogue stores issued, 4 stores retired."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transfusion_pytorch_amd import capi
@@ -7,7 +7,7 @@ dev = 'cuda'; BF = torch.bfloat16
 for (M, N, K) in [(65536, 512, 512), (65536, 512, 2816)]:
     A = torch.randn(M, K, device=dev).to(BF); B = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
     C = torch.empty(M, N, device=dev, dtype=BF)
-    tiles = 256          # the kernel walks its tiles with 256 blocks: stamps are per block, for its last tile
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
     st = torch.zeros(tiles, 8, device=dev, dtype=torch.int64)
     a = capi.make_args('tfx_gemm_nt_args', A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS['TFX_EPI_BF16'], C=C, ldc=N, aux=st.data_ptr())
     for _ in range(3):

@@ -262,7 +262,7 @@ TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w
 #endif
 #pragma unroll
   for (int i = 0; i < NI; i++) {
-    bf16* s = st;                                              // one 4 KiB area, reused block after block (in-order LDS: WAR-safe)
+    bf16* s = st + (i & 1) * 2048;                             // two areas: block i+1 is written while block i's stores drain
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -321,24 +321,20 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
     const int c4 = l & 3;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-      bf16* s = st;                                            // 4 KiB: the [a|g] block; h re-uses its first 2 KiB after the flush
-      f32x4 hh[4];
+      bf16* s = st + (i & 1) * 3072;                           // [a|g] 2048 elements + h 1024 elements, double-buffered
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const int nl = 8 * g + 4 * hi;
         f32x4 a, gt, h;
 #pragma unroll
         for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e] + ba[g][e]; gt[e] = acc[i][1][4 * g + e] + bg[g][e]; h[e] = a[e] * gelu_erf(gt[e]); }
-        stage_put4(s, r, nl, a); stage_put4(s, r, 32 + nl, gt);
-        hh[g] = h;
+        stage_put4(s, r, nl, a); stage_put4(s, r, 32 + nl, gt); stage_put4_32(s + 2048, r, nl, h);
       }
       flush64(s, i, n_w, p.N);
 #pragma unroll
-      for (int g = 0; g < 4; g++) if (n_w + 8 * g + 4 * hi < p.N) stage_put4_32(s, r, 8 * g + 4 * hi, hh[g]);
-#pragma unroll
       for (int q = 0; q < 2; q++) {
         const int row = q * 16 + (l >> 2);
-        const bf16x8 v = *(const bf16x8*)(s + row * 32 + ((c4 ^ ((row >> 2) & 3)) << 3));
+        const bf16x8 v = *(const bf16x8*)(s + 2048 + row * 32 + ((c4 ^ ((row >> 2) & 3)) << 3));
         const int feat = (n_w >> 6) * 32 + c4 * 8;
         if (n_w < p.N && mo2[i][q] >= 0) *(bf16x8*)((bf16*)p.C2 + (size_t)mo2[i][q] * p.ldc2 + feat) = v;
       }
@@ -361,7 +357,7 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
       if (i + 1 < NI) load_aux((i + 1) & 1, i + 1);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        bf16* s = st;                                          // both 32-column halves go through the same 4 KiB area
+        bf16* s = st + j * 2048;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           f32x4 da, dg;
@@ -385,7 +381,7 @@ template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
   return ok;
 }
 // epilogue of the LDS-DMA kernels: staged stores where the layout allows, else the direct pipelined form.
-// `st` = this wave's private LDS staging area (4 KiB), valid once every wave has left the K loop.
+// `st` = this wave's private LDS staging area (>= 12 KiB), valid once every wave has left the K loop.
 template <int EPI, int NI>
 TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
   if constexpr (EPI == EPI_BF16) {
@@ -758,31 +754,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = w >> 2, wc = w & 3;
   const int ntn = (p.N + BN2 - 1) / BN2;
-  const int ntiles = ((p.M + BM2 - 1) / BM2) * ntn;
-  const int G = gridDim.x;                    // block b WALKS the tiles b, b+G, ... (G is a multiple of 8: a block stays on its XCD's tile chunk)
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM2, n0 = (bid % ntn) * BN2;
   const int nk = p.K / BK;
 
   // half-tile row r' (0..127):  A_h -> tile row (r' >> 6) * 128 + h * 64 + (r' & 63) ;  B_h -> tile col (r' >> 5) * 64 + h * 32 + (r' & 31)
   // wave w stages rows [16w, 16w+16) of every half-tile: 2 DMA pieces of 8 rows x 128 B
   const bf16 *gA[2][2], *gA2[2][2], *gB[2][2];
-  int m0 = 0, n0 = 0;
-  auto setup = [&](int vt) {                   // tile coordinates + this lane's DMA source pointers
-    const int bid = xcd_remap(vt, ntiles);
-    m0 = (bid / ntn) * BM2; n0 = (bid % ntn) * BN2;
 #pragma unroll
-    for (int h = 0; h < 2; h++)
+  for (int h = 0; h < 2; h++)
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int rp = w * 16 + j * 8 + (l >> 3);
-        const int c = (l & 7) ^ ((rp >> 1) & 7);
-        int rm = min(m0 + (rp >> 6) * 128 + h * 64 + (rp & 63), p.M - 1);
-        if (p.a_rowmap) rm = p.a_rowmap[rm];
-        const int rn = min(n0 + (rp >> 5) * 64 + h * 32 + (rp & 31), p.N - 1);
-        gA[h][j] = p.A + (size_t)rm * p.lda + c * 8;
-        gA2[h][j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
-        gB[h][j] = p.B + (size_t)rn * p.ldb + c * 8;
-      }
-  };
+    for (int j = 0; j < 2; j++) {
+      const int rp = w * 16 + j * 8 + (l >> 3);
+      const int c = (l & 7) ^ ((rp >> 1) & 7);
+      int rm = min(m0 + (rp >> 6) * 128 + h * 64 + (rp & 63), p.M - 1);
+      if (p.a_rowmap) rm = p.a_rowmap[rm];
+      const int rn = min(n0 + (rp >> 5) * 64 + h * 32 + (rp & 31), p.N - 1);
+      gA[h][j] = p.A + (size_t)rm * p.lda + c * 8;
+      gA2[h][j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
+      gB[h][j] = p.B + (size_t)rn * p.ldb + c * 8;
+    }
   auto issueA = [&](int kt, int h) {
     const int k0 = kt * BK;
     const bool second = p.A2 && k0 >= p.K1;
@@ -810,28 +801,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     return *(const bf16x8*)(lds + ((kt & 1) * 4 + 2 + h) * HALF + rb * BK + (((ks * 2 + hi) ^ ((rb >> 1) & 7)) << 3));
   };
 
-  // K-tile 0 completely and A0,B0 of K-tile 1: what the K loop expects to find issued when it starts
-  auto issue_head = [&]() {
-    issueA(0, 0); issueB(0, 0); issueA(0, 1); issueB(0, 1);
-    if (nk > 1) { issueA(1, 0); issueB(1, 0); }
-  };
-  // DMA schedule, 2 pieces per wave and phase, issued inside the MFMA blocks:  p1: A1(kt+1)  p2: B1(kt+1)  p3: A0(kt+2)  p4: B0(kt+2)
-  // (every slot is re-filled >= 2 phases after its last read: A1 read p3, B1 read p2, A0/B0 read p1 of the K-tile before).
-  // One wait per K-tile: vmcnt(2) before p4's first barrier leaves only A0(kt+2) outstanding, i.e. certifies all of K-tile kt+1
-  // one phase before its first read.
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
 #ifdef TFX_PP_TIMING
-  // debug build (tools/pp_timing.py): lane 0 of wave 0 stamps s_memtime into (uint64*)aux[blockIdx * 8 + i] for the block's LAST tile
-  // (EPI_BF16 does not use aux): 0 tile start, 1 head landed, 2 K loop done, 3 epilogue issued, 4 stores retired
+  // debug build: wave 0 / lane 0 of every block stamps s_memtime into (uint64*)aux[blockIdx * 8 + i] (EPI_BF16 does not use aux)
   unsigned long long* stamps = (unsigned long long*)p.aux + (size_t)blockIdx.x * 8;
 #define PP_STAMP(i) { if (t == 0) stamps[i] = __builtin_readcyclecounter(); }
 #else
 #define PP_STAMP(i)
 #endif
-  int vt = blockIdx.x;
-  setup(vt);
+  PP_STAMP(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
-  issue_head();
-  bool first = true;
+  // DMA schedule, 2 pieces per wave and phase, issued inside the MFMA blocks:  p1: A1(kt+1)  p2: B1(kt+1)  p3: A0(kt+2)  p4: B0(kt+2)
+  // (every slot is re-filled >= 2 phases after its last read: A1 read p3, B1 read p2, A0/B0 read p1 of the K-tile before).
+  // One wait per K-tile: vmcnt(2) before p4's first barrier leaves only A0(kt+2) outstanding, i.e. certifies all of K-tile kt+1
+  // one phase before its first read.
+  issueA(0, 0); issueB(0, 0); issueA(0, 1); issueB(0, 1);
+  if (nk > 1) {
+    issueA(1, 0); issueB(1, 0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // all of K-tile 0 landed, A0,B0 of K-tile 1 in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  PP_STAMP(1)
+  if (wr == 1) __builtin_amdgcn_s_barrier();                      // group 1 runs one barrier behind group 0 from here on
 
 #define PP_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 // MFMA block of one phase; the phase's two LDS-DMA pieces are issued BETWEEN its MFMAs (after k-steps 0 and 2), where their
@@ -846,24 +846,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
   }                                                                                                           \
   __builtin_amdgcn_s_setprio(0);                                                                              \
   asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));   /* pin: LLVM may sink pure MFMAs past the barrier */
-
-  for (; vt < ntiles; vt += G) {
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  // the head of this tile was issued before the previous tile's epilogue: its stores are younger than those DMAs, so
-  // later tiles drain everything (the DMAs landed long ago, the stores are the tail); the first tile keeps K-tile 1 in flight
-  PP_STAMP(0)
-  if (first && nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  first = false;
-  __builtin_amdgcn_s_barrier();
-  PP_STAMP(1)
-  if (wr == 1) __builtin_amdgcn_s_barrier();                      // group 1 runs one barrier behind group 0 from here on
 
   for (int kt = 0; kt < nk; kt++) {
     bf16x8 a[2][4], b0[4], b1[4];
@@ -899,26 +881,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
     PP_MFMA(2, 0, a, b0, if (n2) issueB1(kt + 2, 0, 0), if (n2) issueB1(kt + 2, 0, 1))
     PP_BAR()
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();                      // the groups meet again: every LDS read of this tile is retired
-  // next tile: coordinates, pointers and the head of its DMA stream go out BEFORE this tile's epilogue, so the ~3 k cycles of
-  // cold-load latency and the block relaunch of a one-tile-per-block grid hide under the epilogue's ~6 k cycles
-  PP_STAMP(2)
-  const int m0c = m0, n0c = n0;
-  if (vt + G < ntiles) {
-    setup(vt + G);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_head();
-  }
-  // staging: the A1 / B1 slots of K-tile buffer 1 are the two half-tiles the head does not touch (4 KiB per wave)
-  nt_epilogue<EPI, 4>(p, acc, m0c + wr * 128, n0c + wc * 64, lds + (w < 4 ? 5 : 7) * HALF + (w & 3) * 2048);
-  PP_STAMP(3)
-#ifdef TFX_PP_TIMING
-  if (vt + G >= ntiles) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(4) }
-#endif
-  }
-#undef PP_STAMP
 #undef PP_BAR
 #undef PP_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  PP_STAMP(2)
+  nt_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 8192);   // all of LDS is free after the last barrier: 16 KiB per wave
+  PP_STAMP(3)
+#ifdef TFX_PP_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_STAMP(4)
+#endif
+#undef PP_STAMP
 }
 
 // TN, 4-stage ring of 32-row slabs (16 KiB per stage, 64 KiB per block -> 2 blocks per CU), three slabs in flight.
@@ -1026,13 +999,12 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
   const bool dma = use_glds() && (p.N & 3) == 0;      // the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups
   // 256x256 ping-pong tiles whenever they still fill the chip (>= 2 tiles per CU); a ragged last N tile costs less than the
-  // 128x128 kernel loses (measured on N = 1544 / 1408).
+  // 128x128 kernel loses (measured on N = 1544 / 1408).  One tile per block: a persistent walk with cross-tile prefetch measured no faster.
   if (dma && t256 >= 512) {
     static bool attr_pp = false;
     const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
     if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
-    // 256 blocks (one per CU) walk the tiles: the head of the next tile's DMA stream is issued before the epilogue (+4 % in the step)
-    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(256), dim3(512), smem2, s, p);
+    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
     return (int)hipGetLastError();
   }
   if (dma) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
