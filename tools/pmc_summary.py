@@ -1,6 +1,6 @@
 """Aggregate rocprofv3 --pmc counter_collection csv per kernel (short names).
     python tools/pmc_summary.py <counter_collection.csv> [--steps N]"""
-import csv, re, sys
+import csv, sys
 from collections import defaultdict
 sys.path.insert(0, __file__.rsplit('/', 1)[0])
 from prof_summary import short

@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes
 
-import numpy as np
 import torch
 
 from . import capi

@@ -9,7 +9,7 @@ rows are right-padded with -1; `total_tokens` = sum of packed lengths; positions
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import torch

@@ -16,12 +16,11 @@ modality are those of the LAST conditional ODE evaluation (T:2531-2533); past mo
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import torch
 
-from . import capi
 from .engine import Plan
 
 

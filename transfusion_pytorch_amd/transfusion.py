@@ -15,7 +15,7 @@ from torch import nn
 
 from . import capi
 from .engine import Plan
-from .packing import PackedBatch, fast_signature, is_int_tensor, scan_batch, token_maps, token_segments
+from .packing import fast_signature, is_int_tensor, scan_batch, token_maps, token_segments
 from .params import ModelDims, ParamStore
 
 
