@@ -51,25 +51,23 @@ def f_core_per_sample(d=512, D=8, h=8, dh=64, n=1024, n_inst=32, L=4):
     return 6 * n * D * (p_attn + p_ff + sdpa)
 
 
-def timed_run(plan_cls, launches, stream, family, events):
-    """Plan.run with HIP events (torch events on the launch stream) around every launch of `family`."""
-    from transfusion_pytorch_amd import capi
-    lib = capi.lib()
-    sp = ctypes.c_void_p(stream)
-    for fn, a in launches:
-        if isinstance(fn, str):
-            if fn == family:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = getattr(lib, fn)(ctypes.byref(a), sp)
-                e1.record()
-                events.append((e0, e1, getattr(a, '_algo_flops', 0.0)))
-            else:
-                rc = getattr(lib, fn)(ctypes.byref(a), sp)
-        else:
-            rc = fn(*a, sp)
-        if rc != 0:
-            raise RuntimeError(f'{fn} failed with code {rc}')
+def timed_run(orig_run, launches, stream, lo, hi, family, events):
+    """Plan.run with HIP events (torch events on the launch stream) around every launch of `family`; the launches in between
+    are replayed natively (tfx_run_list), exactly as the product path does."""
+    n = len(launches)
+    hi = n if hi is None else min(hi, n)
+    seg = lo
+    for k in range(lo, hi):
+        fn, a = launches[k]
+        if fn == family:
+            orig_run(launches, stream, seg, k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_run(launches, stream, k, k + 1)
+            e1.record()
+            events.append((e0, e1, getattr(a, '_algo_flops', 0.0)))
+            seg = k + 1
+    orig_run(launches, stream, seg, hi)
 
 
 def cpu_baseline(budget_s=25.0):
@@ -119,9 +117,16 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # keep stdout for the ONE JSON line: libraries print banners there (RCCL's version block at communicator init), so everything
+    # else this process writes to fd 1 goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    use_pg = world > 1 or bool(os.environ.get('TFX_BENCH_FORCE_PG'))   # the env flag exercises the RCCL path on a 1-GPU box (world 1)
+    if use_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)      # "nccl" is RCCL on ROCm
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # "nccl" is RCCL on ROCm
 
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.engine import Plan
@@ -131,6 +136,7 @@ def main():
     model = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,),
                         transformer=dict(dim=args.dim, depth=args.depth)).to(dev).train()
     opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
+    opt.always_sync = use_pg
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     torch.manual_seed(7 + rank)                               # per-rank noise / times / CFG streams
     batch = canonical_batch(args.batch, dev, gen)
@@ -145,7 +151,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -154,7 +160,7 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     orig_run = Plan.run
     def run(launches, stream_, lo=0, hi=None):
-        timed_run(Plan, launches[lo:hi], stream_, args.roofline_kernel, events)
+        timed_run(orig_run, launches, stream_, lo, hi, args.roofline_kernel, events)
     Plan.run = staticmethod(run)
     host_t = 0.0
     prof = None
@@ -172,14 +178,14 @@ def main():
         import pstats
         pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(18)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     Plan.run = orig_run
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -207,7 +213,7 @@ def main():
                                    f'per-GPU batch {args.batch} x seq 1024 (32 x [24 text tokens + (4,384) latent] per sample); '
                                    'step = pack + fwd + bwd + grad all-reduce + clip(0.5) + Adam(3e-4)',
                        'global_batch': world * args.batch, 'seq_len': 1024, 'parallelism': f'dp{world}'},
-            'loss': float(loss),
+            'loss': float(loss.detach()),
             'model_flops_utilization': value / world * fcore / (PEAK_BF16_TFLOPS * 1e12),
             'f_core_gflop_per_sample': fcore / 1e9,
             'host_ms_per_step': host_t / args.steps * 1e3,
@@ -217,8 +223,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    if use_pg:
         dist.destroy_process_group()
 
 

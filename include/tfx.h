@@ -264,6 +264,23 @@ int tfx_adam_step(const tfx_adam_args* a, void* stream);
  * Transfusion.create_ema T:1681-1699) */
 int tfx_ema_update(float* ema, const float* online, int64_t n, float decay, void* stream);
 
+/* ---- launch lists ------------------------------------------------------------------------------
+ * The step is a STATIC list of launches over persistent buffers (engine.Plan), so the host replays it with ONE call instead of one
+ * FFI round trip per kernel: `tfx_run_list` walks `n` items in order on `stream` and stops at the first non-zero return code
+ * (its index is written to *failed_at).  `args` of a struct entry point is that entry point's args struct; entry points with
+ * positional arguments take a `tfx_raw_args`: pointers fill p0.., integers i0.., floats f0 in declaration order. */
+typedef struct { const void *p0, *p1, *p2, *p3, *p4; int64_t i0, i1, i2, i3; float f0; int32_t reserved; } tfx_raw_args;
+enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_BWD = 3, TFX_OP_ADALN_PRE_FWD = 4, TFX_OP_ADALN_PRE_BWD = 5,
+       TFX_OP_ADALN_POST_FWD = 6, TFX_OP_ADALN_POST_BWD = 7, TFX_OP_QK_NORM_ROPE_FWD = 8, TFX_OP_QK_NORM_ROPE_BWD = 9, TFX_OP_ATTNRES_FWD = 10,
+       TFX_OP_ATTNRES_BWD = 11, TFX_OP_RMSNORM_FWD = 12, TFX_OP_RMSNORM_BWD = 13, TFX_OP_EMBED_FWD = 14, TFX_OP_EMBED_BWD = 15,
+       TFX_OP_NOISE_MIX = 16, TFX_OP_FOURIER = 17, TFX_OP_CE_FWD_BWD = 18, TFX_OP_MSE_FWD_BWD = 19, TFX_OP_CAST_ROWS = 20, TFX_OP_CAST_ROWS_T = 21,
+       TFX_OP_ADAM_STEP = 22,
+       /* positional entry points (args = tfx_raw_args) */
+       TFX_OP_OUTPUT_TO_FLOW = 32, TFX_OP_GATHER_F32 = 33, TFX_OP_ONEHOT_BF16 = 34, TFX_OP_SCATTER_ROWS_BF16 = 35, TFX_OP_F32_TO_BF16 = 36,
+       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40 };
+typedef struct { int32_t op; int32_t reserved; const void* args; } tfx_launch;
+int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* failed_at);
+
 const char* tfx_version(void);
 
 #ifdef __cplusplus

@@ -26,6 +26,40 @@ def test_c_abi_library_exports_every_declared_symbol():
         assert ctypes.sizeof(S) % 8 == 0 or all(t is not ctypes.c_void_p for _, t in S._fields_), name
 
 
+def test_launch_list_image_and_runner_error_paths():
+    """host logic of the launch-list replay (no kernel is launched): the native image mirrors the Python list (op codes, args
+    by address, positional arguments packed in declaration order) and tfx_run_list reports the failing index."""
+    from transfusion_pytorch_amd.engine import LaunchList, raw_args
+    lib = capi.lib()
+    L = LaunchList()
+    a = capi.make_args('tfx_gemm_nt_args', M=1, N=2, K=3)
+    L.append(('tfx_gemm_nt', a))
+    live = [16, 32, None, 48, 64, 5, 6, 0.25]
+    L.append((lib.tfx_output_to_flow, live))
+    L.append((lib.tfx_scatter_rows_bf16, (8, 1, 2, 24, 3, None, 4)))
+    arr = L.native()
+    assert [arr[k].op for k in range(3)] == [capi.ENUMS['TFX_OP_GEMM_NT'], capi.ENUMS['TFX_OP_OUTPUT_TO_FLOW'], capi.ENUMS['TFX_OP_SCATTER_ROWS_BF16']]
+    assert arr[0].args == ctypes.addressof(a)
+    R = capi.STRUCTS['tfx_raw_args']
+    r1 = R.from_address(arr[1].args); r2 = R.from_address(arr[2].args)
+    assert (r1.p0, r1.p1, r1.p2, r1.p3, r1.p4, r1.i0, r1.i1, r1.f0) == (16, 32, None, 48, 64, 5, 6, 0.25)
+    assert (r2.p0, r2.i0, r2.i1, r2.p1, r2.i2, r2.p2, r2.i3) == (8, 1, 2, 24, 3, None, 4)
+    live[2] = 128                                  # a mutable positional list is re-packed on the next replay
+    assert L.native() is arr and R.from_address(arr[1].args).p2 == 128
+    L.append(('tfx_gemm_tn', capi.make_args('tfx_gemm_tn_args')))
+    assert len(L.native()) == 4                    # appended launches rebuild the image
+    assert raw_args('tfx_colsum_f32', (8, 1, 2, 3, 16)).p1 == 16
+    # runner: empty list is a no-op, unknown op / NULL args stop at their index
+    failed = ctypes.c_int32(-1)
+    assert lib.tfx_run_list(None, 0, None, ctypes.byref(failed)) == 0
+    bad = (capi.STRUCTS['tfx_launch'] * 2)()
+    bad[0].op = 999; bad[0].args = ctypes.addressof(a)
+    assert lib.tfx_run_list(bad, 1, None, ctypes.byref(failed)) == -100 and failed.value == 0
+    bad[0].op = capi.ENUMS['TFX_OP_GEMM_NT']; bad[0].args = None
+    assert lib.tfx_run_list(bad, 1, None, ctypes.byref(failed)) == -2 and failed.value == 0
+    assert lib.tfx_run_list(None, 3, None, ctypes.byref(failed)) == -1
+
+
 def _native(cfg):
     dl = cfg.dim_latents if len(cfg.dim_latents) > 1 else cfg.dim_latents[0]
     return Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=dl,

@@ -331,6 +331,28 @@ def test_model_output_clean_forward_modality_matches_reference_golden():
         model(batch, times=times)
 
 
+def test_native_list_replay_equals_per_launch_calls():
+    """tfx_run_list (one call per list, the product path) against one C-ABI call per launch on the same plan: same launches in the
+    same order, so loss and gradients agree to fp32-atomic ordering noise."""
+    from transfusion_pytorch_amd.engine import LaunchList, Plan
+    outs = []
+    orig = Plan.run
+    for per_launch in (False, True):
+        if per_launch:
+            Plan.run = staticmethod(lambda launches, stream, lo=0, hi=None: orig(list(launches), stream, lo, hi))
+        try:
+            cfg, model, out = run_native('small2')
+        finally:
+            Plan.run = orig
+        assert isinstance(model._live[0].fwd, LaunchList) and model._live[0].fwd._image is not None or per_launch
+        outs.append(out)
+    a, b = outs
+    assert abs(a['loss'] - b['loss']) <= 1e-5 * max(1., abs(b['loss']))
+    assert rel(a['logits'], b['logits']) <= 1e-6
+    for k in a['grads']:
+        assert rel(a['grads'][k], b['grads'][k]) <= 1e-3, k
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

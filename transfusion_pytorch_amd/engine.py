@@ -43,6 +43,58 @@ def skip_sources(md: ModelDims):
 _TN_SPLIT_PRICE = 0.03      # cost of one more split (fp32 atomics onto cold gradient lines), in units of one full-M pass; tuned on the full step
 
 
+_LAUNCH = capi.STRUCTS['tfx_launch']
+_RAW = capi.STRUCTS['tfx_raw_args']
+
+
+def raw_args(fn_name: str, values):
+    """pack the positional arguments of `fn_name` (without the stream) into a tfx_raw_args: pointers fill p0.., integers i0..,
+    floats f0, in declaration order (include/tfx.h "launch lists")."""
+    argt = capi.FUNCTIONS[fn_name][1][:-1]
+    assert len(argt) == len(values), f'{fn_name}: {len(values)} arguments for {len(argt)} parameters'
+    r = _RAW()
+    np_, ni, nf = 0, 0, 0
+    for ty, v in zip(argt, values):
+        if ty is ctypes.c_void_p:
+            setattr(r, f'p{np_}', v); np_ += 1
+        elif ty is ctypes.c_float:
+            assert nf == 0
+            r.f0 = v; nf += 1
+        else:
+            setattr(r, f'i{ni}', v); ni += 1
+    return r
+
+
+class LaunchList(list):
+    """a launch list plus its native image (array of tfx_launch) for `tfx_run_list`.  Items are (entry point name, args struct) or
+    (positional entry point, argument tuple); args structs are referenced by address, so in-place updates of their fields
+    (grad scales, segment counts, noise pointers) are seen by the next replay.  A MUTABLE argument list (e.g. the
+    model_output_clean launch) is re-packed on every replay."""
+    _image = None
+
+    def native(self):
+        if self._image is None or self._image[0] != len(self):
+            arr = (_LAUNCH * max(len(self), 1))()
+            keep, live = [], []
+            for k, (fn, a) in enumerate(self):
+                if isinstance(fn, str):
+                    arr[k].op = capi.ENUMS['TFX_OP_' + fn[4:].upper()]
+                    arr[k].args = ctypes.addressof(a)
+                else:
+                    name = fn.__name__
+                    r = raw_args(name, a)
+                    keep.append(r)
+                    if isinstance(a, list):
+                        live.append((name, a, r))
+                    arr[k].op = capi.ENUMS['TFX_OP_' + name[4:].upper()]
+                    arr[k].args = ctypes.addressof(r)
+            self._image = (len(self), arr, keep, live)
+        for name, a, r in self._image[3]:
+            fresh = raw_args(name, a)
+            ctypes.memmove(ctypes.addressof(r), ctypes.addressof(fresh), ctypes.sizeof(_RAW))
+        return self._image[1]
+
+
 class Plan:
     def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None):
         """cache: None, or a KV cache tensor [depth, b, maxlen, 2*heads*64] (k~ | v per token).  With a cache the plan is a
@@ -84,9 +136,9 @@ class Plan:
             self.lat[t] = dict(x=e(r, dl, dtype=torch.float32), eps=e(r, dl, dtype=torch.float32), xt=z(r, dlp),
                                flow=e(r, dl, dtype=torch.float32), pred=e(r, dl, dtype=torch.float32), dpred=z(r, dlp))
         self.acc = z(max(8, 2 + 2 * len(md.dim_latents)), dtype=torch.float32)      # [ce sum, ce count, flow sse per type..., velocity sse per type...]
-        self.vel = []                         # optional launches: velocity-consistency MSE against an EMA teacher's flows (T:3394-3418)
+        self.vel = LaunchList()                         # optional launches: velocity-consistency MSE against an EMA teacher's flows (T:3394-3418)
         self.cos_tab = self.sin_tab = None
-        self.fwd, self.bwd = [], []
+        self.fwd, self.bwd = LaunchList(), LaunchList()
         self.noise_args = {}
         self.loaded_structure = None
         self._seg_args = []
@@ -389,8 +441,23 @@ class Plan:
     # ------------------------------------------------------------------------------------ run
     @staticmethod
     def run(launches, stream, lo=0, hi=None):
+        """replay launches[lo:hi] on `stream`: one `tfx_run_list` call for a LaunchList (the product path), a per-launch loop for a
+        plain list (tools that bracket individual launches)."""
         lib = capi.lib()
         sp = ctypes.c_void_p(stream)
+        if isinstance(launches, LaunchList):
+            n = len(launches)
+            lo = max(0, lo if lo >= 0 else n + lo)
+            hi = n if hi is None else min(n, hi if hi >= 0 else n + hi)
+            if hi <= lo:
+                return
+            arr = launches.native()
+            failed = ctypes.c_int32(-1)
+            rc = lib.tfx_run_list(ctypes.byref(arr, lo * ctypes.sizeof(_LAUNCH)), hi - lo, sp, ctypes.byref(failed))
+            if rc != 0:
+                fn = launches[lo + failed.value][0] if failed.value >= 0 else 'tfx_run_list'
+                raise capi.TfxError(f'{fn if isinstance(fn, str) else fn.__name__} failed with code {rc}')
+            return
         for item in launches[lo:hi]:
             fn, a = item
             if isinstance(fn, str):

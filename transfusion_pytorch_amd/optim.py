@@ -20,6 +20,7 @@ class FusedAdam:
         self.group = process_group
         self.average = average_grads
         self.step_count = 0
+        self.always_sync = False        # run the collective even at world size 1 (exercises the RCCL path on a 1-GPU box)
         self.m = self.v = self.sumsq = None
 
     def _world(self):
@@ -30,7 +31,7 @@ class FusedAdam:
     def sync_grads(self):
         """the ONE collective of a data-parallel step: all-reduce(sum) of the flat gradient buffer (RCCL over xGMI)."""
         world = self._world()
-        if world > 1:
+        if world > 1 or (self.always_sync and dist.is_initialized()):
             dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM, group=self.group)
         return world
 
