@@ -41,7 +41,8 @@ def gemm_nt(**kw):
 
 # ---------------------------------------------------------------------------------------------- GEMM NT
 # (33000, 1032, 128) and (65536, 512, 192): >= 512 tiles of 256x256 -> the ping-pong kernel (ragged M and N tiles in the first)
-@pytest.mark.parametrize('M,N,K', [(300, 200, 128), (128, 128, 64), (1000, 1544, 512), (4096, 512, 1408), (77, 390, 192), (33000, 1032, 128), (65536, 512, 192)])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 128), (128, 128, 64), (1000, 1544, 512), (4096, 512, 1408), (77, 390, 192), (33000, 1032, 128), (65536, 512, 192),
+                                   (64, 1544, 512), (1, 512, 64), (37, 2816, 1408), (512, 520, 1024), (256, 128, 768)])   # M <= 512: the skinny deep-ring kernel
 def test_gemm_nt_bf16_bias(M, N, K):
     torch.manual_seed(0)
     A, B = rnd(M, K), rnd(N, K, scale=K ** -0.5)

@@ -710,6 +710,90 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
   nt_epilogue<EPI, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, As + w * 8192);   // 16 KiB per wave of the 64 KiB ring
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny NT (decode steps, time-conditioning MLPs: M <= 512 rows).  With a handful of 64-row blocks the 2-stage kernel
+// above is pure latency: every K-tile waits one full memory round trip (12.9 us for M = 64, K = 512).  Here a block owns a
+// 64 x 128 tile and keeps SK_ST - 1 K-tiles of LDS-DMA in flight (a 6-slot ring of 24 KiB stages = the whole K = 512 panel
+// is requested up front), one wave per 32 x 64 sub-tile, same LDS layout / fragments / epilogues as the kernel above.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_BM = 64, SK_BN = 128, SK_ST = 6;
+constexpr int SK_STAGE = (SK_BM + SK_BN) * BK;          // elements per ring slot: A [64][64] then B [128][64]
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_skinny_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* ring = (bf16*)smem_raw;
+
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = (p.N + SK_BN - 1) / SK_BN;
+  const int m0 = (blockIdx.x / ntn) * SK_BM, n0 = (blockIdx.x % ntn) * SK_BN;
+  const int nk = p.K / BK;
+
+  // wave w stages rows [16w, 16w+16) of the A slot (2 DMA pieces of 8 rows x 128 B) and rows [32w, 32w+32) of the B slot (4 pieces)
+  const bf16 *ga[2], *ga2[2], *gb[4];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int row = w * 16 + j * 8 + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    int rm = min(m0 + row, p.M - 1);
+    if (p.a_rowmap) rm = p.a_rowmap[rm];
+    ga[j] = p.A + (size_t)rm * p.lda + c * 8;
+    ga2[j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int row = w * 32 + j * 8 + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    gb[j] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + c * 8;
+  }
+  auto issue = [&](int kt) {                               // 6 DMA instructions per wave and K-tile
+    const int k0 = kt * BK;
+    bf16* slot = ring + (kt % SK_ST) * SK_STAGE;
+    const bool second = p.A2 && k0 >= p.K1;
+#pragma unroll
+    for (int j = 0; j < 2; j++) glds16_asm(second ? ga2[j] + (k0 - p.K1) : ga[j] + k0, slot + (w * 16 + j * 8) * BK);
+#pragma unroll
+    for (int j = 0; j < 4; j++) glds16_asm(gb[j] + k0, slot + SK_BM * BK + (w * 32 + j * 8) * BK);
+  };
+
+  f32x16 acc[1][2];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][j][r] = 0.f;
+
+  for (int kt = 0; kt < min(SK_ST - 1, nk); kt++) issue(kt);
+  const int arow = wm * 32 + (l & 31), brow0 = wn * 64 + (l & 31);
+  auto ldfrag = [&](const bf16* base, int r, int ks) { return *(const bf16x8*)(base + r * BK + (((ks * 2 + hi) ^ ((r >> 1) & 7)) << 3)); };
+  for (int kt = 0; kt < nk; kt++) {
+    // K-tiles kt+1 .. kt+ahead of this wave are still allowed in flight (6 instructions each, in-order counter)
+    const int ahead = min(SK_ST - 2, nk - 1 - kt);
+    switch (ahead) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();                            // tile kt has landed for everyone, and everyone finished reading slot (kt - 1) % SK_ST
+    if (kt + SK_ST - 1 < nk) issue(kt + SK_ST - 1);          // refill the slot read in the previous iteration
+    const bf16* as = ring + (kt % SK_ST) * SK_STAGE;
+    const bf16* bs = as + SK_BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const bf16x8 af = ldfrag(as, arow, ks);
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(bs, brow0 + j * 32, ks), af, acc[0][j], 0, 0, 0);
+    }
+  }
+
+  __builtin_amdgcn_s_barrier();                                  // the ring becomes staging space: 16 KiB per wave
+  nt_epilogue<EPI, 1>(p, acc, m0 + wm * 32, n0 + wn * 64, ring + w * 8192);
+}
+
 constexpr int BM2 = 256, BN2 = 256;     // tile of the ping-pong kernel below
 
 // TN with LDS-DMA: unpadded [64][128] tiles, 16-byte chunk index XOR ((row & 3) << 2) keeps the four rows of a
@@ -995,6 +1079,14 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
   const bool dma = use_glds() && (p.N & 3) == 0;      // the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups
+  if (dma && p.M <= 512) {                              // few row blocks: latency-bound, deep DMA ring (see gemm_nt_skinny_kernel)
+    static bool attr_sk = false;
+    const int smem_sk = SK_ST * SK_STAGE * 2;
+    if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk); attr_sk = true; }
+    const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
+    hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(grid_sk), dim3(256), smem_sk, s, p);
+    return (int)hipGetLastError();
+  }
   // 256x256 ping-pong tiles whenever they still fill the chip (>= 2 tiles per CU); a ragged last N tile costs less than the
   // 128x128 kernel loses (measured on N = 1544 / 1408).  One tile per block: a persistent walk with cross-tile prefetch measured no faster.
   if (dma && t256 >= 512) {
