@@ -61,7 +61,7 @@ int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
 
 /* C[rowmap[n]][k] += alpha * sum_m A[m][n] * B[m][k]   (fp32 C, ALWAYS accumulates: split-M partial sums are
  * added with fp32 atomics, the caller zeroes C when it wants a plain product; `accumulate` is ignored).
- * a_cols/b_cols: number of readable columns of A/B (multiples of 8); k_valid: columns of C written. */
+ * a_cols/b_cols: number of readable columns of A/B (multiples of 8); k_valid: columns of the product that are written. */
 typedef struct {
   const tfx_bf16* A; int32_t lda; int32_t a_cols;
   const tfx_bf16* B; int32_t ldb; int32_t b_cols;
@@ -74,6 +74,8 @@ typedef struct {
   float alpha;
   const int32_t* a_rowmap;    /* gather rows of A / B (row index = map[m]); NULL = identity */
   const int32_t* b_rowmap;
+  int32_t k_group;            /* 0 = off; else the K columns come in groups of 64 of which the first k_group are written, compacted:
+                                 C column = (k / 64) * k_group + k % 64  (per-head padded operand -> unpadded weight gradient) */
 } tfx_gemm_tn_args;
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
 
@@ -136,7 +138,7 @@ int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* stream);
 int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* stream);
 
 typedef struct {
-  int32_t T, H;                               /* dim_head == 64 */
+  int32_t T, H;                               /* kernel layout: 64 columns per head; dim_head < 64 = zero columns past dim_head */
   const tfx_bf16* qkv; int32_t ld_qkv;        /* q at col h*64, k at col H*64 + h*64 (pre-norm) */
   tfx_bf16* qk; int32_t ld_qk;                /* post norm+rope(+q scale), same column layout */
   const float* gamma_q; const float* gamma_k; /* [64] */
@@ -147,6 +149,7 @@ typedef struct {
   const tfx_bf16* dqk; int32_t ld_dqk;        /* grad wrt post-norm q,k */
   tfx_bf16* dqkv; int32_t ld_dqkv;            /* grad wrt pre-norm q,k (written) */
   float* dgamma_q; float* dgamma_k;           /* atomic accumulate */
+  float norm_scale;                           /* sqrt(dim_head), the RMSNorm scale T:779-786; 0 = 8 (dim_head 64) */
 } tfx_qk_norm_rope_args;
 int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* stream);
 int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* stream);

@@ -15,6 +15,7 @@ CASES = {
     'tiny1':   (dict(num_text_tokens=256, dim=64,  depth=2, dim_latents=(48,),      heads=2, dim_head=64), 'ragged', 4),
     'small2':  (dict(num_text_tokens=256, dim=128, depth=4, dim_latents=(32, 16),   heads=2, dim_head=64), 'ragged', 4),
     'mid2':    (dict(num_text_tokens=256, dim=256, depth=4, dim_latents=(384, 192), heads=4, dim_head=64), 'two_modality', 2),
+    'head8':   (dict(num_text_tokens=256, dim=128, depth=2, dim_latents=(16,),      heads=4, dim_head=8),  'ragged', 3),   # dim_head of train_toy.py / the reference's tests
     'canon512': (dict(num_text_tokens=256, dim=512, depth=8, dim_latents=(384,),    heads=8, dim_head=64), 'canonical', 2),
 }
 

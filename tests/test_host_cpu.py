@@ -66,7 +66,7 @@ def _native(cfg):
                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
 
 
-@pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'canon512'])
+@pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'head8', 'canon512'])
 def test_packer_matches_reference_layout(name):
     cfg, sd, batch, times, noise = build_case(name)
     m = _native(cfg)

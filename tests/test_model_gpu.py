@@ -59,7 +59,7 @@ def compare_losses(out, g):
         assert abs(a - r) <= 2e-3 * max(1., abs(r)), nm
 
 
-@pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'canon512'])
+@pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'head8', 'canon512'])
 def test_training_step_matches_reference_golden(name):
     g = torch.load(os.path.join(GOLDEN, f'{name}.pt'), weights_only=False)
     cfg, model, out = run_native(name)
@@ -124,14 +124,16 @@ def test_tiny_matches_live_oracle_and_updates():
         assert torch.allclose(rp, p.detach(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('dim,depth,heads,dls', [(192, 3, 3, (40,)), (320, 5, 2, (24, 72)), (576, 2, 1, (8,)), (64, 1, 4, (16,))])
-def test_odd_configurations_match_live_oracle(dim, depth, heads, dls):
+@pytest.mark.parametrize('dim,depth,heads,dls,dim_head', [(192, 3, 3, (40,), 64), (320, 5, 2, (24, 72), 64), (576, 2, 1, (8,), 64), (64, 1, 4, (16,), 64),
+                                                          (128, 2, 4, (16,), 8), (192, 3, 2, (24, 40), 32), (64, 2, 8, (8,), 16), (128, 1, 3, (16,), 48)])
+def test_odd_configurations_match_live_oracle(dim, depth, heads, dls, dim_head):
     """shapes off the golden grid - odd depth (U-Net skip pairing, T:1206-1219), heads * 64 != dim, dim not a multiple of 128 /
-    above 512 (two column chunks per lane), tiny latents - against the CPU oracle (pinned to the reference) on the same inputs."""
+    above 512 (two column chunks per lane), tiny latents, dim_head 8 (train_toy.py, the reference's tests) / 16 / 32 (its image
+    examples) / 48 run zero-padded to the kernels' 64 columns per head - against the CPU oracle (pinned to the reference) on the same inputs."""
     from oracle import detdata as D
     from oracle.transfusion_oracle import OracleConfig
-    cfg = OracleConfig(num_text_tokens=96, dim=dim, depth=depth, dim_latents=dls, heads=heads, dim_head=64)
-    tag = f'odd/{dim}/{depth}/{heads}'
+    cfg = OracleConfig(num_text_tokens=96, dim=dim, depth=depth, dim_latents=dls, heads=heads, dim_head=dim_head)
+    tag = f'odd/{dim}/{depth}/{heads}' + (f'/{dim_head}' if dim_head != 64 else '')
     batch = D.ragged_batch(f'{tag}/b', 3, cfg.num_text_tokens, cfg.dim_latents)
     times = D.det_times(f'{tag}/t', batch); noise = D.det_noise(f'{tag}/n', batch, cfg.num_modalities)
     sd = D.det_state_dict(cfg.state_dict_shapes(), tag=tag)
@@ -144,7 +146,7 @@ def test_odd_configurations_match_live_oracle(dim, depth, heads, dls):
     loss = model(batch, times=times)
     loss.backward()
     torch.cuda.synchronize()
-    print(f'  dim {dim} depth {depth} heads {heads}: loss native {float(loss.detach()):.6f} oracle {float(ref["loss"].detach()):.6f}')
+    print(f'  dim {dim} depth {depth} heads {heads} dim_head {dim_head}: loss native {float(loss.detach()):.6f} oracle {float(ref["loss"].detach()):.6f}')
     assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-3 * max(1., abs(float(ref['loss'].detach())))
     plan = model._live[0]
     assert rel(plan.logits.view(plan.b, plan.n, -1)[..., :cfg.vocab].float().cpu(), ref['logits'].detach()) <= 1.5e-2

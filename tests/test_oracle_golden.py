@@ -9,7 +9,7 @@ from oracle.cases import CASES, build_case, default_shapes, input_checksum, with
 from oracle.transfusion_oracle import forward_train, naive_mask
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
-FAST = ['tiny1', 'small2', 'mid2']
+FAST = ['tiny1', 'small2', 'mid2', 'head8']
 
 
 def load_golden(name):

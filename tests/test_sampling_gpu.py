@@ -130,3 +130,21 @@ def test_generate_text_only_matches_reference_greedy():
     lg = model.forward_text(full[:, :-1], return_loss=False)[:, prompt.shape[1] - 1:]
     agree = (lg.argmax(-1).cpu() == gen).float().mean()
     assert agree >= 0.95, agree
+
+
+def test_small_heads_cached_decode_is_consistent_with_the_full_forward():
+    """dim_head 8 (train_toy.py / the reference's tests) runs zero-padded to 64 columns per head: the KV cache, the rotary tables
+    and the decode plans must agree with the full forward - every greedy token decoded with the cache is the full forward's argmax
+    (0.05 logit slack for bf16 near-ties)."""
+    import torch
+    from transfusion_pytorch_amd import Transfusion
+    torch.manual_seed(0)
+    m = Transfusion(num_text_tokens=64, dim_latent=16, transformer=dict(dim=128, depth=2, dim_head=8, heads=4)).cuda().eval()
+    prompt = torch.randint(0, 64, (3, 9), device='cuda')
+    gen = m.generate_text_only(prompt, 9 + 14, temperature=0.)
+    seq = torch.cat([prompt, gen], dim=1)
+    logits = m.forward_text(seq, return_loss=False)
+    assert logits.shape[:2] == seq.shape
+    for b in range(seq.shape[0]):
+        for i in range(prompt.shape[1] - 1, seq.shape[1] - 1):
+            assert logits[b, i, seq[b, i + 1]].item() >= logits[b, i].max().item() - 0.05, (b, i)

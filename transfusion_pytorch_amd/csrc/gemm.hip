@@ -515,6 +515,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 constexpr int TN_BMK = 64;      // contraction rows per LDS tile
 constexpr int TN_LD = 136;      // padded LDS row stride (elements); 136 keeps 2 blocks/CU resident (69.6 KB LDS each)
 
+// output column of product column k: identity, or the compaction of per-head padded columns (tfx.h `k_group`)
+TFX_DEV int tn_out_col(const GemmTN& p, int k) {
+  if (p.k_group <= 0) return k;
+  const int c = k & 63;
+  return c < p.k_group ? (k >> 6) * p.k_group + c : -1;
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* As = (bf16*)smem_raw;                         // [2][64*160]
@@ -613,7 +620,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
         const int k = k0 + wk * 64 + j * 32 + (l & 31);
         if (k < p.k_valid) {
           float v = acc[i][j][r] * p.alpha;
-          atomicAdd(p.C + (size_t)no * p.ldc + k, v);
+          const int ko = tn_out_col(p, k);
+          if (ko >= 0) atomicAdd(p.C + (size_t)no * p.ldc + ko, v);
         }
       }
     }
@@ -1060,7 +1068,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int k = k0 + wk * 64 + j * 32 + (l & 31);
-        if (k < p.k_valid) atomicAdd(p.C + (size_t)no * p.ldc + k, acc[i][j][r] * p.alpha);
+        if (k < p.k_valid) {
+          const int ko = tn_out_col(p, k);
+          if (ko >= 0) atomicAdd(p.C + (size_t)no * p.ldc + ko, acc[i][j][r] * p.alpha);
+        }
       }
     }
 }

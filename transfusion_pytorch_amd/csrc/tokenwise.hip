@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args 
 #pragma unroll
   for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
   q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-  const float r = 8.f / fmaxf(sqrtf(q), 1e-12f) * (which == 0 ? p.q_scale : 1.f);
+  const float r = (p.norm_scale > 0.f ? p.norm_scale : 8.f) / fmaxf(sqrtf(q), 1e-12f) * (which == 0 ? p.q_scale : 1.f);
   const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
   const int pos = p.rot_pos[t];
   const f32x4 cs = *(const f32x4*)(p.cos_tab + (size_t)pos * 32 + sub * 4);
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args 
     for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
     q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
     const float nrm = fmaxf(sqrtf(q), 1e-12f), inv = 1.f / nrm;
-    const float sc = (which == 0 ? p.q_scale : 1.f) * 8.f;
+    const float sc = (which == 0 ? p.q_scale : 1.f) * (p.norm_scale > 0.f ? p.norm_scale : 8.f);
     const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
     const int pos = p.rot_pos[t];
     const f32x4 cs = *(const f32x4*)(p.cos_tab + (size_t)pos * 32 + sub * 4);

@@ -106,7 +106,7 @@ class Plan:
         self.ps, self.md, self.b, self.n, self.I, self.R = ps, md, b, n, I, dict(R)
         self.T = T = b * n
         dev = ps.device
-        d, hd, D, dip, ldq, nt3 = md.dim, md.hd, md.depth, md.dip, md.ldq, md.nt3
+        d, hd, D, dip, ldq, nt3 = md.dim, md.hdk, md.depth, md.dip, md.ldq, md.nt3
         z = lambda *s, dtype=BF16: torch.zeros(*s, device=dev, dtype=dtype)
         e = lambda *s, dtype=BF16: torch.empty(*s, device=dev, dtype=dtype)
         I1 = max(I, 1)
@@ -197,7 +197,7 @@ class Plan:
     # ------------------------------------------------------------------------------------ forward
     def _build_forward(self):
         ps, md, T, I = self.ps, self.md, self.T, self.I
-        d, hd, D, dip, ldq, nt3, H = md.dim, md.hd, md.depth, md.dip, md.ldq, md.nt3, md.heads
+        d, hd, D, dip, ldq, nt3, H = md.dim, md.hdk, md.depth, md.dip, md.ldq, md.nt3, md.heads
         S = ps.shadows
         L = self.fwd
         pp = ps.ptr
@@ -231,10 +231,11 @@ class Plan:
             ta, _ = self._tab(i, 0); tf, _ = self._tab(i, 1)
             self._k(L, 'tfx_adaln_pre_fwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, u=self.ua[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
                     gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i))
-            self._nt(L, A=self.ua[i], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nq, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[i], ldc=ldq)
+            self._nt(L, algo_n=md.nq, A=self.ua[i], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[i], ldc=ldq)
+            gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, qk=self.qkr[i], ld_qk=2 * hd,
-                    gamma_q=pp(f'{p}.1.fn.q_norm.gamma'), gamma_k=pp(f'{p}.1.fn.k_norm.gamma'), rot_pos=self.rot_pos,
-                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5)
+                    gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
+                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5)
             self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
             if self.cache is not None:
                 lib = capi.lib()
@@ -242,7 +243,7 @@ class Plan:
                 self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkr, i) + 2 * hd, 2 * hd, hd, ck.data_ptr(), 2 * hd, self.cache_pos.data_ptr(), T)
                 self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkvg, i) + 2 * 2 * hd, ldq, hd, ck.data_ptr() + 2 * hd, 2 * hd, self.cache_pos.data_ptr(), T)
             self._k(L, 'tfx_attn_fwd', 'tfx_attn_args', **self._attn_kw(i))
-            self._nt(L, A=self.og[i], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[i], ldc=d)
+            self._nt(L, algo_k=md.hd, A=self.og[i], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[i], ldc=d)
             self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[i], out=self.xb[i], tok_inst=self.tok_inst,
                     table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
             self._k(L, 'tfx_adaln_pre_fwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], u=self.uf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
@@ -299,7 +300,7 @@ class Plan:
             self.vel.append(('tfx_mse_fwd_bwd', self._vel_args[t]))
 
     def _attn_kw(self, i, bwd=False):
-        md, hd, ldq = self.md, self.md.hd, self.md.ldq
+        md, hd, ldq = self.md, self.md.hdk, self.md.ldq
         kw = dict(q=self.qkr[i], k=_p(self.qkr, i) + 2 * hd, v=_p(self.qkvg, i) + 2 * 2 * hd, ld_q=2 * hd, ld_k=2 * hd, ld_v=ldq,
                   gate=_p(self.qkvg, i) + 2 * 3 * hd, ld_gate=ldq, kv_end=self.kv_end, q_start=self.q_start, out=self.og[i], ld_out=hd,
                   lse=self.lse[i], b=self.b, h=md.heads, n=self.n, softcap=50.0)
@@ -341,7 +342,7 @@ class Plan:
     # ------------------------------------------------------------------------------------ backward
     def _build_backward(self):
         ps, md, T, I = self.ps, self.md, self.T, self.I
-        d, hd, D, di, dip, ldq, nt3, H = md.dim, md.hd, md.depth, md.di, md.dip, md.ldq, md.nt3, md.heads
+        d, hd, D, di, dip, ldq, nt3, H = md.dim, md.hdk, md.depth, md.di, md.dip, md.ldq, md.nt3, md.heads
         S = ps.shadows
         L = self.bwd
         pp, gp = ps.ptr, ps.grad_ptr
@@ -391,14 +392,17 @@ class Plan:
                     layerscale=pp(f'{p}.1.layerscale'), g=G, dy=self.dy, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'),
                     seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
             self._seg_args.append(L[-1][1])
-            self._tn(L, T, d, hd, A=self.dy, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=hd)
-            self._nt(L, A=self.dy, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
+            self._tn(L, T, d, hd, A=self.dy, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=md.hd,
+                     k_group=0 if md.dim_head == 64 else md.dim_head)
+            self._nt(L, algo_n=md.hd, A=self.dy, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
             self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
-            self._k(L, 'tfx_qk_norm_rope_bwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, gamma_q=pp(f'{p}.1.fn.q_norm.gamma'),
-                    gamma_k=pp(f'{p}.1.fn.k_norm.gamma'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5,
+            gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
+            self._k(L, 'tfx_qk_norm_rope_bwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, gamma_q=gam('q'),
+                    gamma_k=gam('k'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5,
                     dqk=self.dqk, ld_dqk=2 * hd, dqkv=self.dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
             self._rope_args.append(L[-1][1])
-            self._tn(L, T, md.nq, d, A=self.dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d)
+            self._tn(L, T, md.nqk, d, algo_n=md.nq, A=self.dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d,
+                     rowmap=ps._maps['heads'] if md.dim_head != 64 else None)
             self._nt(L, algo_k=md.nq, A=self.dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, tok_inst=self.tok_inst, table=ta, ld_table=nt3,
                     gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i), du=self.du, dx=G,

@@ -50,9 +50,13 @@ class ModelDims:
     @property
     def vp(self): return pad_to(self.vocab, 64)
     @property
-    def nq(self): return 3 * self.hd + self.heads            # q | k | v | gate logits
+    def nq(self): return 3 * self.hd + self.heads            # q | k | v | gate logits (rows of the fused projection, T:877-916)
     @property
-    def ldq(self): return pad_to(self.nq, 64)
+    def hdk(self): return self.heads * 64                     # KERNEL layout: 64 columns per head; dim_head < 64 leaves zero columns
+    @property
+    def nqk(self): return 3 * self.hdk + self.heads           # q | k | v | gate logits in the kernel layout
+    @property
+    def ldq(self): return pad_to(self.nqk, 64)
     @property
     def kf(self): return pad_to(self.dim + 1, 64)            # fourier embedding width, padded
     @property
@@ -151,6 +155,15 @@ def geglu_phys_to_ref_rows(di: int, dip: int) -> np.ndarray:
     feat = blk * 32 + within % 32
     ref = np.where(within >= 32, di + feat, feat)
     return np.where(feat < di, ref, -1).astype(np.int32)
+
+
+def head_phys_to_ref_rows(heads: int, dim_head: int) -> np.ndarray:
+    """row of the fused [q | k | v | gates] projection (3 * heads * dim_head + heads rows) for each row of the kernel layout
+    (64 columns per head, 3 * heads * 64 + heads rows); -1 = zero padding."""
+    c = np.arange(3 * heads * 64)
+    part, h, e = c // (heads * 64), (c // 64) % heads, c % 64
+    ref = np.where(e < dim_head, part * heads * dim_head + h * dim_head + e, -1)
+    return np.concatenate([ref, 3 * heads * dim_head + np.arange(heads)]).astype(np.int32)
 
 
 class ParamStore:
@@ -295,15 +308,34 @@ class ParamStore:
         C(stream, self.ptr('transformer.layers.0.1.to_film.weight'), 4 * d, md.nt3, 4 * d, S('ada_t', 4 * d, md.nt3), transpose=True, n_rows_logical=md.nt3)
         C(stream, self.ptr('transformer.to_time_cond.1.weight'), d + 1, 4 * d, d + 1, S('time', 4 * d, md.kf))
         gmap = self._map('geglu', geglu_phys_to_ref_rows(di, dip))
+        dh = md.dim_head
+        if dh != 64:
+            qmap = self._map('heads', head_phys_to_ref_rows(md.heads, dh))
+            gam_map = self._map('gamma', np.where(np.arange(64) < dh, np.arange(64), -1))
         for i in range(D):
             p = f'transformer.layers.{i}'
             if md.has_skip(i):
                 C(stream, self.ptr(f'{p}.0.weight'), 2 * d, d, 2 * d, S(f'skip{i}', d, 2 * d))
                 C(stream, self.ptr(f'{p}.0.weight'), 2 * d, d, 2 * d, S(f'skip_t{i}', 2 * d, d), transpose=True, n_rows_logical=d)
-            C(stream, self.ptr(f'{p}.1.fn.to_qk.0.weight'), d, md.nq, d, S(f'qkvg{i}', md.nq, d))
-            C(stream, self.ptr(f'{p}.1.fn.to_qk.0.weight'), d, md.nq, d, S(f'qkvg_t{i}', d, md.ldq), transpose=True, n_rows_logical=md.nq)
-            C(stream, self.ptr(f'{p}.1.fn.to_out.1.weight'), hd, d, hd, S(f'out{i}', d, hd))
-            C(stream, self.ptr(f'{p}.1.fn.to_out.1.weight'), hd, d, hd, S(f'out_t{i}', hd, d), transpose=True, n_rows_logical=d)
+            if dh == 64:
+                C(stream, self.ptr(f'{p}.1.fn.to_qk.0.weight'), d, md.nq, d, S(f'qkvg{i}', md.nq, d))
+                C(stream, self.ptr(f'{p}.1.fn.to_qk.0.weight'), d, md.nq, d, S(f'qkvg_t{i}', d, md.ldq), transpose=True, n_rows_logical=md.nq)
+                C(stream, self.ptr(f'{p}.1.fn.to_out.1.weight'), hd, d, hd, S(f'out{i}', d, hd))
+                C(stream, self.ptr(f'{p}.1.fn.to_out.1.weight'), hd, d, hd, S(f'out_t{i}', hd, d), transpose=True, n_rows_logical=d)
+            else:             # dim_head < 64: every head is zero-padded to the kernels' 64 columns
+                hdk = md.hdk
+                C(stream, self.ptr(f'{p}.1.fn.to_qk.0.weight'), d, md.nq, d, S(f'qkvg{i}', md.nqk, d), rowmap=qmap)
+                C(stream, self.ptr(f'{p}.1.fn.to_qk.0.weight'), d, md.nq, d, S(f'qkvg_t{i}', d, md.ldq), rowmap=qmap, transpose=True, n_rows_logical=md.nqk)
+                wo = self.ptr(f'{p}.1.fn.to_out.1.weight')            # [d, heads * dh] seen as [(d * heads), dh] -> [(d * heads), 64]
+                C(stream, wo, dh, d * md.heads, dh, S(f'out{i}', d, hdk).view(d * md.heads, 64))
+                ot = S(f'out_t{i}', hdk, d)
+                for h in range(md.heads):                            # head h: columns [h dh, (h+1) dh) of to_out -> rows [64 h, 64 h + dh)
+                    C(stream, wo + 4 * h * dh, hd, d, dh, ot[h * 64:(h + 1) * 64], transpose=True, n_rows_logical=d)
+                for nm in ('q', 'k'):                                 # RMSNorm gammas padded to 64 (the kernels index 64 per head)
+                    key = f'g{nm}{i}'
+                    if key not in self.shadows:
+                        self.shadows[key] = torch.zeros(64, device=self.device)
+                    capi.check(capi.lib().tfx_gather_f32(self.ptr(f'{p}.1.fn.{nm}_norm.gamma'), gam_map.data_ptr(), self.shadows[key].data_ptr(), 64, stream), 'gather_f32')
             C(stream, self.ptr(f'{p}.2.fn.net.0.weight'), d, 2 * di, d, S(f'ff1{i}', 2 * dip, d), rowmap=gmap)
             C(stream, self.ptr(f'{p}.2.fn.net.0.weight'), d, 2 * di, d, S(f'ff1_t{i}', d, 2 * dip), rowmap=gmap, transpose=True, n_rows_logical=2 * dip)
             C(stream, self.ptr(f'{p}.2.fn.net.3.weight'), di, d, di, S(f'ff2{i}', d, dip))

@@ -149,10 +149,10 @@ class Sampler:
 
     # ------------------------------------------------------------------ caches
     def _alloc_cache(self, B, maxlen):
-        return torch.zeros(self.md.depth, B, maxlen, 2 * self.md.hd, device=self.dev, dtype=torch.bfloat16)
+        return torch.zeros(self.md.depth, B, maxlen, 2 * self.md.hdk, device=self.dev, dtype=torch.bfloat16)
 
     def _fill_cache(self, cache, plan, B, n):
-        D, hd, ldq = self.md.depth, self.md.hd, self.md.ldq
+        D, hd, ldq = self.md.depth, self.md.hdk, self.md.ldq
         cache[:, :, :n, :hd].copy_(plan.qkr.view(D, B, n, 2 * hd)[..., hd:])
         cache[:, :, :n, hd:].copy_(plan.qkvg.view(D, B, n, ldq)[..., 2 * hd:3 * hd])
 

@@ -48,8 +48,9 @@ class Transformer:
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f'Transformer options not supported by the native MI355X path: {bad}')
-        if dim_head != 64:
-            raise NotImplementedError('the native attention kernels are specialised to dim_head = 64')
+        if dim_head > 64 or dim_head % 2 or dim_head < 2:
+            raise NotImplementedError('the native attention kernels hold 64 columns per head: dim_head must be even and <= 64 '
+                                      '(smaller heads run zero-padded)')
         if dim % 64 != 0:
             raise NotImplementedError('the native kernels need dim to be a multiple of 64')
         self.dim, self.depth, self.dim_head, self.heads, self.ff_expansion_factor = dim, depth, dim_head, heads, ff_expansion_factor
@@ -173,7 +174,9 @@ class Transfusion(nn.Module):
             P = max(2048, 1 << (max_pos + 1).bit_length())
             freqs = self.store.rot_param.detach().float().cpu()
             ang = torch.arange(P, dtype=torch.float32)[:, None] * freqs[None, :]      # rotary_embedding_torch: pos * freq, fp32
-            self._rope = (ang.cos().to(self.device).contiguous(), ang.sin().to(self.device).contiguous())
+            cos, sin = torch.ones(P, 32), torch.zeros(P, 32)                           # kernel tables: 32 pairs per head; identity past dim_head / 2
+            cos[:, :freqs.numel()] = ang.cos(); sin[:, :freqs.numel()] = ang.sin()
+            self._rope = (cos.to(self.device).contiguous(), sin.to(self.device).contiguous())
         return self._rope
 
     def _plan(self, b, n, I, R, training):
