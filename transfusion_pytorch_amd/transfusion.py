@@ -43,8 +43,9 @@ class Transformer:
 
     def __init__(self, dim, *, depth, dim_head=64, heads=8, dropout=0., ff_expansion_factor=4, attn_kwargs: dict = dict(),
                  ff_kwargs: dict = dict(), attn_laser=False, unet_skips=True, use_flex_attn=False, qk_rmsnorm=True, use_value_residual=False):
+        # use_flex_attn only selects the reference's attention BACKEND (same scores, same mask, T:998-1027): accepted, the native kernel runs
         unsupported = dict(dropout=dropout != 0., attn_kwargs=bool(attn_kwargs), ff_kwargs=bool(ff_kwargs), attn_laser=attn_laser,
-                           unet_skips=not unet_skips, use_flex_attn=use_flex_attn, qk_rmsnorm=not qk_rmsnorm, use_value_residual=use_value_residual)
+                           unet_skips=not unet_skips, qk_rmsnorm=not qk_rmsnorm, use_value_residual=use_value_residual)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f'Transformer options not supported by the native MI355X path: {bad}')
