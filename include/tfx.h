@@ -74,6 +74,8 @@ typedef struct {
   float alpha;
   const int32_t* a_rowmap;    /* gather rows of A / B (row index = map[m]); NULL = identity */
   const int32_t* b_rowmap;
+  float* colsum;              /* optional: colsum[rowmap[n]] += sum_m A[m][n] - the bias gradient that belongs to this weight gradient,
+                                 folded into the GEMM (one extra MFMA against a ones operand in the blocks of the first K tile) */
   int32_t k_group;            /* 0 = off; else the K columns come in groups of 64 of which the first k_group are written, compacted:
                                  C column = (k / 64) * k_group + k % 64  (per-head padded operand -> unpadded weight gradient) */
 } tfx_gemm_tn_args;

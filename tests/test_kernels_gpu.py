@@ -172,6 +172,30 @@ def test_gemm_tn(M, N, K, splits):
     check(f'gemm_tn {M}x{N}x{K} splits={splits}', C, ref, 5e-3)
 
 
+@pytest.mark.parametrize('M,N,K,splits,kg', [(4096, 1544, 512, 8, 0), (1000, 200, 136, 4, 0), (2048, 128, 256, 8, 8), (2048, 384, 192, 16, 32)])
+def test_gemm_tn_folded_bias_gradient_and_head_compaction(M, N, K, splits, kg):
+    """`colsum`: the bias gradient (column sums of A through the row map) rides on the weight-gradient GEMM - LDS-DMA kernel (M % 64 == 0)
+    and the register-staged fallback; `k_group`: per-head padded product columns are compacted into the unpadded gradient."""
+    torch.manual_seed(6)
+    lda = (N + 7) // 8 * 8
+    A = rnd(M, lda, scale=0.5); B = rnd(M, K, scale=0.5)
+    rowmap = torch.randperm(N, device=DEV).to(torch.int32)
+    rowmap[3] = -1
+    Kout = K if not kg else K // 64 * kg
+    C = torch.zeros(N, Kout, device=DEV); bias = torch.full((N,), 2.0, device=DEV)
+    a = capi.make_args('tfx_gemm_tn_args', A=A, lda=lda, a_cols=lda, B=B, ldb=K, b_cols=K, M=M, N=N, K=K, C=C, ldc=Kout, rowmap=rowmap, k_valid=K,
+                       splits=splits, accumulate=1, alpha=1.0, colsum=bias, k_group=kg)
+    capi.call('tfx_gemm_tn', a, stream())
+    prod = A[:, :N].float().T @ B.float()
+    if kg:
+        prod = prod.view(N, K // 64, 64)[:, :, :kg].reshape(N, Kout)
+    keep = rowmap >= 0
+    ref = torch.zeros(N, Kout, device=DEV); ref[rowmap[keep].long()] = prod[keep]
+    bref = torch.full((N,), 2.0, device=DEV); bref[rowmap[keep].long()] += A[:, :N].float().sum(0)[keep]
+    check(f'gemm_tn colsum/k_group weight grad {M}x{N}x{K}', C, ref, 5e-3)
+    check(f'gemm_tn colsum/k_group bias grad {M}x{N}x{K}', bias, bref, 5e-3)
+
+
 # ---------------------------------------------------------------------------------------------- attention
 def make_kv_end(b, n, seed=0):
     g = torch.Generator().manual_seed(seed)

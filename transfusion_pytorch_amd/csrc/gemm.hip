@@ -1032,6 +1032,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  // bias gradient folded in: the waves that own the first K tile also multiply their A fragments with a ones operand
+  const bool do_sum = p.colsum != nullptr && k0 == 0 && wk == 0;       // wave-uniform
+  f32x16 accs[2];
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = f2bf(1.f);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) accs[i][r] = 0.f;
+
   const int pre = min(nst, MS_NST - 1);
   for (int s0 = 0; s0 < pre; s0++) issue(s0);
   for (int st = 0; st < nst; st++) {
@@ -1055,6 +1066,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    if (do_sum) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], ones, accs[i], 0, 0, 0);
+    }
   }
 
 #pragma unroll
@@ -1065,6 +1082,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
       if (n >= p.N) continue;
       const int no = p.rowmap ? p.rowmap[n] : n;
       if (no < 0) continue;
+      if (do_sum && (l & 31) == 0) atomicAdd(p.colsum + no, accs[i][r]);      // every column of A^T x ones holds the row sum
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const int k = k0 + wk * 64 + j * 32 + (l & 31);
@@ -1141,8 +1159,11 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
   if (dma_ok)
     hipLaunchKernelGGL(gemm_tn_ms_kernel, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
-  else
+  else {
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), smem, s, q);
+    if (q.colsum)      // the register-staged fallback does not fold the bias gradient in
+      return tfx_colsum_bf16((const tfx_bf16*)q.A, q.lda, q.M, q.N, q.rowmap, q.a_rowmap, q.colsum, (void*)s);
+  }
   return (int)hipGetLastError();
 }
 

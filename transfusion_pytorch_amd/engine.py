@@ -379,9 +379,9 @@ class Plan:
             self._tn(L, T, d, di, A=self.dy, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
             self._nt(L, algo_n=di, A=self.dy, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=self.dag, ldc=2 * dip,
                      aux=self.ag[i], ldaux=2 * dip)
-            self._raw(L, lib.tfx_colsum_bf16, self.dag.data_ptr(), 2 * dip, T, 2 * dip, gmap.data_ptr(), None, gp(f'{p}.2.fn.net.0.bias'))
+            # weight gradient of net.0 with its bias gradient (column sums of d[a|g]) folded into the same GEMM
             self._tn(L, T, 2 * dip, d, algo_n=2 * di, A=self.dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
-                     C=gp(f'{p}.2.fn.net.0.weight'), ldc=d)
+                     C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias'))
             self._nt(L, algo_k=2 * di, A=self.dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                     gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
