@@ -985,6 +985,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
 
 // TN, 4-stage ring of 32-row slabs (16 KiB per stage, 64 KiB per block -> 2 blocks per CU), three slabs in flight.
 constexpr int MS_ROWS = 32, MS_NST = 4;
+template <bool SUM>
 __global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* As = (bf16*)smem_raw;                         // [4][32*128]
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // bias gradient folded in: the waves that own the first K tile also multiply their A fragments with a ones operand
-  const bool do_sum = p.colsum != nullptr && k0 == 0 && wk == 0;       // wave-uniform
+  const bool do_sum = SUM && k0 == 0 && wk == 0;                       // wave-uniform (SUM: p.colsum != NULL)
   f32x16 accs[2];
   bf16x8 ones;
 #pragma unroll
@@ -1158,7 +1159,10 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   int grid = ((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
   const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
   if (dma_ok)
-    hipLaunchKernelGGL(gemm_tn_ms_kernel, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
+  {
+    if (q.colsum) hipLaunchKernelGGL(gemm_tn_ms_kernel<true>, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
+    else hipLaunchKernelGGL(gemm_tn_ms_kernel<false>, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
+  }
   else {
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), smem, s, q);
     if (q.colsum)      // the register-staged fallback does not fold the bias gradient in
