@@ -833,11 +833,27 @@ TFX_DEV bf16x8 lds_tr8_swz(const bf16* tile, int rowA, int rowB, int c0) {
 // `s_waitcnt vmcnt(6)` before phase 4's first barrier, which certifies the next K-tile one phase before its first read.
 // (Schedule after the 8-phase template of cdna_hip_programming.md; DMAs are inline asm so hipcc does not drain them.)
 // ------------------------------------------------------------------------------------------------
+// De-phasing.  Every tile of a GEMM takes the same time, so all 256 CUs run their K loops together and reach their epilogues
+// together: the C tiles of a round (33 MB for 256 x 256 bf16 tiles) hit HBM as one burst and the chip's power draw swings
+// between an all-MFMA and an all-store phase.  Holding the odd blocks of the FIRST round back by `cycles` shader clocks shifts
+// half of the CUs by that much for the rest of the kernel.  Measured on three MI355X boxes (full training step, dim512/d8):
+// 18000 cycles (half a K = 512 tile) = -2.0 ... -3.4 % step time; the delayed blocks' tiles run faster (80 % of the inserted
+// wait is recovered inside the GEMM) and the kernels that FOLLOW (attention -6 %, TN -3 %) run at higher clocks - the GEMM
+// phase is power-limited (tools/clock_probe.hip) and the smoother draw leaves the controller more headroom.  The same delay
+// in the TN kernel measured no effect.
+TFX_DEV void dephase_first_round(int cycles, int first_round_blocks) {
+  if (cycles > 0 && (int)blockIdx.x < first_round_blocks && (blockIdx.x & 1)) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (unsigned long long)cycles) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p) {
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* lds = (bf16*)smem_raw;                                    // [2 K-tiles][A0, A1, B0, B1][128 rows x 64]
   constexpr int HALF = 128 * BK;
+  dephase_first_round(stagger, 256);
 
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1123,7 +1139,9 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
     static bool attr_pp = false;
     const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
     if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
-    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p);
+    static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
+    if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 18000; }
+    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p, stagger);
     return (int)hipGetLastError();
   }
   if (dma) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
