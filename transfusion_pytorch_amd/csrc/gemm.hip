@@ -844,7 +844,8 @@ TFX_DEV bf16x8 lds_tr8_swz(const bf16* tile, int rowA, int rowB, int c0) {
 TFX_DEV void dephase_first_round(int cycles, int first_round_blocks) {
   if (cycles > 0 && (int)blockIdx.x < first_round_blocks && (blockIdx.x & 1)) {
     const unsigned long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < (unsigned long long)cycles) __builtin_amdgcn_s_sleep(8);
+    // s_sleep 8 = 512 clocks; the trip count is bounded as well, should the counter ever tick slower than the shader clock
+    for (int it = 0; it < cycles / 512 + 8 && __builtin_readcyclecounter() - t0 < (unsigned long long)cycles; it++) __builtin_amdgcn_s_sleep(8);
   }
 }
 
