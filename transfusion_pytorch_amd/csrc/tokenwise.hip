@@ -107,6 +107,12 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_pre_fwd_k(tfx_ada
   if (t >= p.T) return;
   const int d = p.d;
   Row<NC> x; load_row(x, p.x + (size_t)t * d, d, lane);
+  // the instance id and the modulation rows are requested BEFORE the statistics: three dependent round trips (row, id, table) become two
+  // (a grid-stride form with next-row prefetch measured 4 % slower than this one-row-per-wave form)
+  const int inst = p.tok_inst[t];
+  Row<NC> g, b;
+  if (inst < 0) load_vec(g, p.gamma_text, d, lane);
+  else { load_vec(g, p.table + (size_t)inst * p.ld_table, d, lane); load_vec(b, p.table + (size_t)inst * p.ld_table + d, d, lane); }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NC; i++)
@@ -123,10 +129,6 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_pre_fwd_k(tfx_ada
   }
   const float rstd = rsqrtf(wave_sum(q) / d + 1e-5f);
   if (lane == 0) { p.mean[t] = mean; p.rstd[t] = rstd; }
-  const int inst = p.tok_inst[t];
-  Row<NC> g, b;
-  if (inst < 0) load_vec(g, p.gamma_text, d, lane);
-  else { load_vec(g, p.table + (size_t)inst * p.ld_table, d, lane); load_vec(b, p.table + (size_t)inst * p.ld_table + d, d, lane); }
 #pragma unroll
   for (int i = 0; i < NC; i++)
 #pragma unroll
