@@ -101,6 +101,7 @@ typedef struct {
   float* delta;                               /* [b, h, n] */
   tfx_bf16* dgate; int32_t ld_dgate;         /* grad wrt gate logits */
   tfx_bf16 *dq, *dk, *dv; int32_t ld_dq, ld_dk, ld_dv;
+  int32_t order;              /* set by the library (block order of the launch); callers leave it 0 */
 } tfx_attn_args;
 int tfx_attn_fwd(const tfx_attn_args* a, void* stream);
 int tfx_attn_bwd(const tfx_attn_args* a, void* stream);   /* prep + dK/dV kernel + dQ kernel */

@@ -150,13 +150,29 @@ TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
 // ------------------------------------------------------------------------------------------------
 // forward: block = 128 query rows (4 waves x 32), loop over 64-key tiles
 // ------------------------------------------------------------------------------------------------
+// Block order.  A block's work grows with its query tile (forward, dQ: keys 0 .. kv_end) or shrinks with its key block (dK/dV:
+// queries q_start .. n), 1 : 8 across a 1024-token sample.  The grid is (heads, samples, tiles) with the tile rank in the SLOWEST
+// dimension, decoded heaviest-first: the long blocks start first and the kernel ends on the short ones (no tail of lone 8-unit
+// blocks), and since workgroups go to the XCDs round-robin in linear order, every tile of one (head, sample) lands on the SAME XCD
+// whenever heads * samples is a multiple of 8 (its K / V stay in that XCD's L2).  `order` == 0 is the tile-fastest grid
+// (tiles, heads, samples) of the first version (env TFX_ATTN_ORDER=0, A/B).
+struct BlockId { int tile, h, b; };
+TFX_DEV BlockId decode_block(int order, int ntile, bool heavy_last_tile) {     // (scalars only: no reference to the kernel-argument struct)
+  BlockId o;
+  if (order == 0) { o.tile = blockIdx.x; o.h = blockIdx.y; o.b = blockIdx.z; return o; }
+  o.tile = heavy_last_tile ? ntile - 1 - (int)blockIdx.z : (int)blockIdx.z;
+  o.h = blockIdx.x; o.b = blockIdx.y;
+  return o;
+}
+
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(1024))) bf16 Ks[2][64 * 64];      // double-buffered LDS-DMA tiles (see swz_f)
   __shared__ __attribute__((aligned(1024))) bf16 Vs[2][64 * 64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
-  const int n = p.n, h = blockIdx.y, b = blockIdx.z;
+  const int n = p.n;
+  const BlockId bi = decode_block(p.order, (n + 127) / 128, true);
+  const int h = bi.h, b = bi.b, q0 = bi.tile * 128;
   const int nkv = p.n_kv > 0 ? p.n_kv : n;                       // KV-cache decode: keys live in a longer per-sample buffer
-  const int q0 = blockIdx.x * 128;
   const size_t tok0 = (size_t)b * n, tokk = (size_t)b * nkv;
   const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
   const bf16* kb_ = p.k + tokk * p.ld_k + h * DH;
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   }
 #ifdef TFX_ATTN_TIMING
   if (l == 0) {
-    unsigned long long* ob = (unsigned long long*)p.dq + ((((size_t)b * p.h + h) * gridDim.x + blockIdx.x) * 4 + w) * 5;
+    unsigned long long* ob = (unsigned long long*)p.dq + ((((size_t)b * p.h + h) * ((n + 127) / 128) + bi.tile) * 4 + w) * 5;
     for (int i = 0; i < 4; i++) ob[i] = tsec[i];
     ob[4] = nt;
   }
@@ -311,8 +327,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(16))) bf16 Ks[64 * LDT];
   __shared__ __attribute__((aligned(16))) bf16 Vs[64 * LDT];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
-  const int n = p.n, h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128;
+  const int n = p.n;
+  const BlockId bi = decode_block(p.order, (n + 127) / 128, true);
+  const int h = bi.h, b = bi.b, q0 = bi.tile * 128;
   const size_t tok0 = (size_t)b * n;
   const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
   const bf16* kb_ = p.k + tok0 * p.ld_k + h * DH;
@@ -410,8 +427,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(16))) float s_lse[64], s_dlt[64];
   __shared__ __attribute__((aligned(16))) int s_kve[64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
-  const int n = p.n, h = blockIdx.y, b = blockIdx.z;
-  const int k0 = blockIdx.x * 128;
+  const int n = p.n;
+  const BlockId bi = decode_block(p.order, (n + 127) / 128, false);
+  const int h = bi.h, b = bi.b, k0 = bi.tile * 128;
   const size_t tok0 = (size_t)b * n;
   const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
   const bf16* kb_ = p.k + tok0 * p.ld_k + h * DH;
@@ -515,11 +533,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   }
 }
 
+static int attn_order() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TFX_ATTN_ORDER"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+static dim3 attn_grid(const tfx_attn_args& q) {
+  const int ntile = (q.n + 127) / 128;
+  return q.order ? dim3(q.h, q.b, ntile) : dim3(ntile, q.h, q.b);
+}
 int attn_fwd(const tfx_attn_args& p, hipStream_t s) {
   if (p.n <= 0 || p.b <= 0 || p.h <= 0) return -1;
   if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out) & 7) return -2;
   if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;     // fixed-reference softmax needs exp2(cap*log2e) finite in fp32 sums
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
+  tfx_attn_args q = p; q.order = attn_order();
+  hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(q), dim3(256), 0, s, q);
   return (int)hipGetLastError();
 }
 int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
@@ -528,9 +556,10 @@ int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
   if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;
   long long nthreads = (long long)p.b * p.n * p.h * 8;
   if (nthreads >= (1ll << 31)) return -4;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.n + 127) / 128, p.h, p.b), dim3(256), 0, s, p);
+  tfx_attn_args q = p; q.order = attn_order();
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, q);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, attn_grid(q), dim3(256), 0, s, q);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, attn_grid(q), dim3(256), 0, s, q);
   return (int)hipGetLastError();
 }
 
