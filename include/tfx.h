@@ -272,7 +272,7 @@ int tfx_ema_update(float* ema, const float* online, int64_t n, float decay, void
 
 /* ---- launch lists ------------------------------------------------------------------------------
  * The step is a STATIC list of launches over persistent buffers (engine.Plan), so the host replays it with ONE call instead of one
- * FFI round trip per kernel: `tfx_run_list` walks `n` items in order on `stream` and stops at the first non-zero return code
+ * FFI round trip per kernel: `tfx_run_list` walks `n` items in order on `stream` (or the side stream, per item) and stops at the first non-zero return code
  * (its index is written to *failed_at).  `args` of a struct entry point is that entry point's args struct; entry points with
  * positional arguments take a `tfx_raw_args`: pointers fill p0.., integers i0.., floats f0 in declaration order. */
 typedef struct { const void *p0, *p1, *p2, *p3, *p4; int64_t i0, i1, i2, i3; float f0; int32_t reserved; } tfx_raw_args;
@@ -283,9 +283,19 @@ enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_
        TFX_OP_ADAM_STEP = 22,
        /* positional entry points (args = tfx_raw_args) */
        TFX_OP_OUTPUT_TO_FLOW = 32, TFX_OP_GATHER_F32 = 33, TFX_OP_ONEHOT_BF16 = 34, TFX_OP_SCATTER_ROWS_BF16 = 35, TFX_OP_F32_TO_BF16 = 36,
-       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40 };
-typedef struct { int32_t op; int32_t reserved; const void* args; } tfx_launch;
+       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40,
+       /* stream control (args = any non-NULL pointer; `stream` = event slot 0..63):
+          FORK: the library's side stream waits for everything enqueued so far on the caller's stream;
+          JOIN_RECORD: mark "everything enqueued so far on the side stream";  JOIN_WAIT: the caller's stream waits for that mark;
+          JOIN = JOIN_RECORD + JOIN_WAIT */
+       TFX_OP_FORK = 48, TFX_OP_JOIN = 49, TFX_OP_JOIN_RECORD = 50, TFX_OP_JOIN_WAIT = 51 };
+/* `stream`: 0 = the caller's stream, 1 = the library's side stream (a second HIP stream the weight-gradient GEMMs run on, next to
+ * the data-gradient chain); for FORK / JOIN the event slot. */
+typedef struct { int32_t op; int32_t stream; const void* args; } tfx_launch;
 int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* failed_at);
+/* on != 0: replay every item on the caller's stream (FORK / JOIN become no-ops) - same results, kernels one at a time (used to time a
+ * kernel family without its side-stream neighbours); returns the previous setting */
+int tfx_set_single_stream(int32_t on);
 
 const char* tfx_version(void);
 

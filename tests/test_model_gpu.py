@@ -355,6 +355,26 @@ def test_native_list_replay_equals_per_launch_calls():
         assert rel(a['grads'][k], b['grads'][k]) <= 1e-3, k
 
 
+def test_side_stream_weight_gradients_equal_single_stream():
+    """the weight-gradient GEMMs run on the library's side stream, one layer behind the data-gradient chain (fork / join events,
+    per-wrapper + parity-double-buffered operands).  Same plan replayed on ONE stream (tfx_set_single_stream): identical launches,
+    so loss and every gradient agree to fp32-atomic ordering noise - at the canonical size, where the two streams really overlap."""
+    from transfusion_pytorch_amd import capi
+    outs = []
+    for single in (1, 0, 0):
+        capi.lib().tfx_set_single_stream(single)
+        try:
+            cfg, model, out = run_native('canon512')
+        finally:
+            capi.lib().tfx_set_single_stream(0)
+        outs.append(out)
+    ref = outs[0]
+    for o in outs[1:]:
+        assert abs(o['loss'] - ref['loss']) <= 1e-6 * max(1., abs(ref['loss']))
+        for k in ref['grads']:
+            assert rel(o['grads'][k], ref['grads'][k]) <= 2e-3, k
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

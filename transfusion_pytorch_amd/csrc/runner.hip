@@ -1,6 +1,8 @@
 // Launch-list replay (include/tfx.h "launch lists"): the training / decode step is a static list of kernel launches over persistent
 // buffers, so the host hands the whole list to the library once per step instead of paying one FFI round trip per kernel.
 // Host code only; every case forwards to the public entry point of the same name.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "../../include/tfx.h"
 
 namespace {
@@ -58,14 +60,63 @@ inline int run_one(const tfx_launch& l, void* s) {
   }
 }
 
+// the side stream and its fork / join events: one set per process (one process drives one GPU), created on first use
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork_ev[64] = {}, join_ev[64] = {};
+  int ensure() {
+    if (stream) return 0;
+    // non-blocking: no implicit sync with the null stream.  LOWEST priority: the weight-gradient GEMMs fill what the data-gradient chain
+    // leaves idle instead of competing with it (env TFX_SIDE_PRIO=0: default priority, A/B)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest)
+    const char* e = getenv("TFX_SIDE_PRIO");
+    const bool low = !(e && e[0] == '0');
+    if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, low ? lo : 0) != hipSuccess) return -110;
+    for (int i = 0; i < 64; ++i)
+      if (hipEventCreateWithFlags(&fork_ev[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming) != hipSuccess) return -111;
+    return 0;
+  }
+};
+SideStream g_side;
+bool g_single_stream = false;
+
 }  // namespace
 
 extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* failed_at) {
   if (n < 0 || (n > 0 && !list)) return -1;
+  hipStream_t main_s = (hipStream_t)stream;
   for (int32_t i = 0; i < n; ++i) {
-    if (!list[i].args) { if (failed_at) *failed_at = i; return -2; }
-    int rc = run_one(list[i], stream);
+    const tfx_launch& l = list[i];
+    int rc = 0;
+    if (!l.args) rc = -2;
+    else if (l.op >= TFX_OP_FORK && l.op <= TFX_OP_JOIN_WAIT) {
+      if (l.stream < 0 || l.stream >= 64) rc = -3;
+      else if (g_single_stream) rc = 0;
+      else if ((rc = g_side.ensure()) == 0) {
+        if (l.op == TFX_OP_FORK) {
+          rc = (int)hipEventRecord(g_side.fork_ev[l.stream], main_s);
+          if (rc == 0) rc = (int)hipStreamWaitEvent(g_side.stream, g_side.fork_ev[l.stream], 0);
+        } else {
+          if (l.op != TFX_OP_JOIN_WAIT) rc = (int)hipEventRecord(g_side.join_ev[l.stream], g_side.stream);
+          if (rc == 0 && l.op != TFX_OP_JOIN_RECORD) rc = (int)hipStreamWaitEvent(main_s, g_side.join_ev[l.stream], 0);
+        }
+      }
+    } else if (l.stream == 1 && !g_single_stream) {
+      if ((rc = g_side.ensure()) == 0) rc = run_one(l, (void*)g_side.stream);
+    } else if (l.stream == 1) {
+      rc = run_one(l, stream);
+    } else if (l.stream == 0) {
+      rc = run_one(l, stream);
+    } else rc = -3;
     if (rc != 0) { if (failed_at) *failed_at = i; return rc; }
   }
   return 0;
+}
+
+extern "C" int tfx_set_single_stream(int32_t on) {
+  const int prev = g_single_stream ? 1 : 0;
+  g_single_stream = on != 0;
+  return prev;
 }

@@ -8,6 +8,7 @@ list can be captured in a hipGraph.  Math follows SURVEY.md Appendix A (referenc
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -65,6 +66,15 @@ def raw_args(fn_name: str, values):
     return r
 
 
+class Side(tuple):
+    """a launch that runs on the library's side stream (include/tfx.h `tfx_launch.stream` = 1): the weight-gradient GEMMs, next to
+    the data-gradient chain on the caller's stream.  Unpacks like any other (entry point, args) item."""
+
+
+_SYNC_OPS = {'tfx_fork': 'TFX_OP_FORK', 'tfx_join': 'TFX_OP_JOIN', 'tfx_join_record': 'TFX_OP_JOIN_RECORD', 'tfx_join_wait': 'TFX_OP_JOIN_WAIT'}
+_DUMMY = ctypes.c_int32(0)
+
+
 class LaunchList(list):
     """a launch list plus its native image (array of tfx_launch) for `tfx_run_list`.  Items are (entry point name, args struct) or
     (positional entry point, argument tuple); args structs are referenced by address, so in-place updates of their fields
@@ -76,7 +86,14 @@ class LaunchList(list):
         if self._image is None or self._image[0] != len(self):
             arr = (_LAUNCH * max(len(self), 1))()
             keep, live = [], []
-            for k, (fn, a) in enumerate(self):
+            for k, item in enumerate(self):
+                fn, a = item
+                if isinstance(fn, str) and fn in _SYNC_OPS:          # fork / join: `a` is the event slot
+                    arr[k].op = capi.ENUMS[_SYNC_OPS[fn]]
+                    arr[k].stream = int(a)
+                    arr[k].args = ctypes.addressof(_DUMMY)
+                    continue
+                arr[k].stream = 1 if isinstance(item, Side) else 0
                 if isinstance(fn, str):
                     arr[k].op = capi.ENUMS['TFX_OP_' + fn[4:].upper()]
                     arr[k].args = ctypes.addressof(a)
@@ -147,11 +164,16 @@ class Plan:
         self._build_forward()
         if training:
             self.dH = e(D + 1, T, d)
-            self.gx = e(T, d); self.dy = e(T, d); self.du = e(T, d)
+            self.gx = e(T, d); self.du = e(T, d)
+            # weight-gradient GEMMs run on a side stream one layer behind the data-gradient chain (TFX_SIDE_STREAM=0: one stream):
+            # the buffers they read are kept per wrapper and double-buffered by layer parity
+            self.side = os.environ.get('TFX_SIDE_STREAM', '1') != '0' and D <= 30
+            nb = 2 if self.side else 1
+            self.dy_f = [e(T, d) for _ in range(nb)]; self.dy_a = [e(T, d) for _ in range(nb)] if self.side else self.dy_f
             self.dskip = {j: e(T, d) for j in set(skip_sources(md).values())}
-            self.dqkvg = z(T, ldq); self.dqk = e(T, 2 * hd); self.dog = e(T, hd); self.do_eff = e(T, hd)
+            self.dqkvg_p = [z(T, ldq) for _ in range(nb)]; self.dqk = e(T, 2 * hd); self.dog = e(T, hd); self.do_eff = e(T, hd)
             self.delta = e(b, md.heads, n, dtype=torch.float32)
-            self.dag = e(T, 2 * dip); self.dembed = e(T, d); self.gfin = e(T, d); self.dx0 = e(T, d)
+            self.dag_p = [e(T, 2 * dip) for _ in range(nb)]; self.dembed = e(T, d); self.gfin = e(T, d); self.dx0 = e(T, d)
             self.dtables = z(I1, nt3, dtype=torch.float32); self.dtab_bf = e(I1, nt3)
             self.dcond = e(I1, 4 * d); self.dpre = e(I1, 4 * d)
             self.onehot = e(T, md.vp)
@@ -179,9 +201,10 @@ class Plan:
             splits = 1            # enough tiles to fill the chip: no split, no extra atomics
         kw.setdefault('k_valid', K)
         algo_n = kw.pop('algo_n', None)
+        side = kw.pop('side', False)
         a = capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, splits=splits, accumulate=1, alpha=1.0, **kw)
         a._algo_flops = 2.0 * M * (algo_n or N) * kw['k_valid']
-        lst.append(('tfx_gemm_tn', a))
+        lst.append(Side(('tfx_gemm_tn', a)) if side else ('tfx_gemm_tn', a))
 
     def _k(self, lst, fn, struct, **kw):
         lst.append((fn, capi.make_args(struct, **kw)))
@@ -308,9 +331,10 @@ class Plan:
             ck = self.cache[i]
             kw.update(k=ck.data_ptr(), v=ck.data_ptr() + 2 * hd, ld_k=2 * hd, ld_v=2 * hd, n_kv=int(ck.shape[1]))
         if bwd:
+            dqkvg = self.dqkvg_p[i % len(self.dqkvg_p)]
             kw.update(dout=self.dog, ld_dout=hd, do_eff=self.do_eff, ld_do=hd, delta=self.delta,
-                      dgate=self.dqkvg.data_ptr() + 2 * 3 * hd, ld_dgate=ldq, dq=self.dqk, dk=self.dqk.data_ptr() + 2 * hd,
-                      dv=self.dqkvg.data_ptr() + 2 * 2 * hd, ld_dq=2 * hd, ld_dk=2 * hd, ld_dv=ldq)
+                      dgate=dqkvg.data_ptr() + 2 * 3 * hd, ld_dgate=ldq, dq=self.dqk, dk=self.dqk.data_ptr() + 2 * hd,
+                      dv=dqkvg.data_ptr() + 2 * 2 * hd, ld_dq=2 * hd, ld_dk=2 * hd, ld_dv=ldq)
         return kw
 
     def set_rope_tables(self, cos_tab, sin_tab):
@@ -361,11 +385,19 @@ class Plan:
         src = skip_sources(md)
         pushed = set(src.values())
         g = self.gfin
+        side = self.side
+        def sync(op, slot):
+            if side:
+                L.append((op, slot))
         for i in range(D - 1, -1, -1):
             p = f'transformer.layers.{i}'
             x_in = self.xres[i]
             x_a = self.xa[i] if md.has_skip(i) else x_in
             (ta, dta), (tf, dtf) = self._tab(i, 0), self._tab(i, 1)
+            par = i % len(self.dag_p)
+            dy_f, dy_a, dag, dqkvg = self.dy_f[par], self.dy_a[par], self.dag_p[par], self.dqkvg_p[par]
+            if i + 2 <= D - 1:
+                sync('tfx_join_wait', i + 2)       # this layer reuses the buffers of layer i+2: its weight gradients must have read them
             g2 = self.dskip[i + 1] if (i + 1) in pushed else None
             self._k(L, 'tfx_attnres_bwd', 'tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
                     gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), g=g, g2=capi.ptr(g2), dhiddens=self.dH, stride_dh=T * d,
@@ -373,51 +405,58 @@ class Plan:
             G = self.dH[i + 1]
             # ---- feedforward wrapper
             self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.yf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
-                    layerscale=pp(f'{p}.2.layerscale'), g=G, dy=self.dy, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'),
+                    layerscale=pp(f'{p}.2.layerscale'), g=G, dy=dy_f, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'),
                     seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0, dbias=gp(f'{p}.2.fn.net.3.bias'))   # ff2 bias gradient = column sums of dy
             self._seg_args.append(L[-1][1])
-            self._tn(L, T, d, di, A=self.dy, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
-            self._nt(L, algo_n=di, A=self.dy, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=self.dag, ldc=2 * dip,
+            self._nt(L, algo_n=di, A=dy_f, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip,
                      aux=self.ag[i], ldaux=2 * dip)
-            # weight gradient of net.0 with its bias gradient (column sums of d[a|g]) folded into the same GEMM
-            self._tn(L, T, 2 * dip, d, algo_n=2 * di, A=self.dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
+            # the weight gradients of this wrapper go to the side stream (dy_f and d[a|g] are final); net.0 carries its bias gradient
+            # (column sums of d[a|g]) folded into the same GEMM
+            sync('tfx_fork', 2 * i)
+            self._tn(L, T, d, di, side=side, A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
+            self._tn(L, T, 2 * dip, d, side=side, algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
                      C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias'))
-            self._nt(L, algo_k=2 * di, A=self.dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
+            self._nt(L, algo_k=2 * di, A=dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                     gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
                     dtable=dtf, dgamma_text=gp(f'{p}.2.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
             self._seg_args.append(L[-1][1])
             # ---- attention wrapper
             self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.ya[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
-                    layerscale=pp(f'{p}.1.layerscale'), g=G, dy=self.dy, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'),
+                    layerscale=pp(f'{p}.1.layerscale'), g=G, dy=dy_a, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'),
                     seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
             self._seg_args.append(L[-1][1])
-            self._tn(L, T, d, hd, A=self.dy, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=md.hd,
-                     k_group=0 if md.dim_head == 64 else md.dim_head)
-            self._nt(L, algo_n=md.hd, A=self.dy, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
+            self._nt(L, algo_n=md.hd, A=dy_a, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
             self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             self._k(L, 'tfx_qk_norm_rope_bwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, gamma_q=gam('q'),
                     gamma_k=gam('k'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5,
-                    dqk=self.dqk, ld_dqk=2 * hd, dqkv=self.dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
+                    dqk=self.dqk, ld_dqk=2 * hd, dqkv=dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
             self._rope_args.append(L[-1][1])
-            self._tn(L, T, md.nqk, d, algo_n=md.nq, A=self.dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d,
-                     rowmap=ps._maps['heads'] if md.dim_head != 64 else None)
-            self._nt(L, algo_k=md.nq, A=self.dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
+            self._nt(L, algo_k=md.nq, A=dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, tok_inst=self.tok_inst, table=ta, ld_table=nt3,
                     gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i), du=self.du, dx=G,
                     dtable=dta, dgamma_text=gp(f'{p}.1.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
             self._seg_args.append(L[-1][1])
+            # weight gradients of the attention wrapper (dy_a, d[q|k|v|gates] and G = dH[i+1] are final) on the side stream
+            sync('tfx_fork', 2 * i + 1)
+            self._tn(L, T, d, hd, side=side, A=dy_a, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=md.hd,
+                     k_group=0 if md.dim_head == 64 else md.dim_head)
+            self._tn(L, T, md.nqk, d, side=side, algo_n=md.nq, A=dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d,
+                     rowmap=ps._maps['heads'] if md.dim_head != 64 else None)
             if md.has_skip(i):
                 sk = self.xres[src[i]]
-                self._tn(L, T, d, d, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
-                self._tn(L, T, d, d, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
+                self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
+                self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
+            sync('tfx_join_record', i)
+            if md.has_skip(i):
                 st = S[f'skip_t{i}']
                 self._nt(L, A=G, lda=d, B=st, ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.gx, ldc=d, R=G, ldr=d)
                 self._nt(L, A=G, lda=d, B=st[d:], ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_BF16'], C=self.dskip[src[i]], ldc=d)
                 g = self.gx
             else:
                 g = G
+        sync('tfx_join', 63)                       # every weight gradient is complete before the list returns
         # ---- gradient wrt the transformer input x0 = hid[0] = xres[0]
         self._raw(L, lib.tfx_add_bf16, g.data_ptr(), self.dH[0].data_ptr(), self.dx0.data_ptr(), T * d)
         if 0 in pushed:
@@ -464,6 +503,8 @@ class Plan:
             return
         for item in launches[lo:hi]:
             fn, a = item
+            if isinstance(fn, str) and fn in _SYNC_OPS:
+                continue                                           # one stream, in list order: forks / joins are no-ops
             if isinstance(fn, str):
                 rc = getattr(lib, fn)(ctypes.byref(a), sp)
             else:
