@@ -17,7 +17,6 @@ from .params import ModelDims, ParamStore, pad_to
 
 BF16 = torch.bfloat16
 E = capi.ENUMS
-TN_BLOCKS_PER_XCD = int(__import__('os').environ.get('TFX_TN_BLOCKS_PER_XCD', '128'))
 
 
 def _p(t, *idx):
