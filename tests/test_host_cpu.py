@@ -49,6 +49,16 @@ def test_launch_list_image_and_runner_error_paths():
     L.append(('tfx_gemm_tn', capi.make_args('tfx_gemm_tn_args')))
     assert len(L.native()) == 4                    # appended launches rebuild the image
     assert raw_args('tfx_colsum_f32', (8, 1, 2, 3, 16)).p1 == 16
+    # stream tags: Side items run on the library's side stream, fork / join items carry their event slot
+    from transfusion_pytorch_amd.engine import Side
+    L2 = LaunchList([('tfx_gemm_nt', a), ('tfx_fork', 5), Side(('tfx_gemm_tn', capi.make_args('tfx_gemm_tn_args'))), ('tfx_join_record', 2),
+                     ('tfx_join_wait', 2), ('tfx_join', 63)])
+    arr2 = L2.native()
+    assert [arr2[k].stream for k in range(6)] == [0, 5, 1, 2, 2, 63]
+    assert [arr2[k].op for k in range(6)] == [capi.ENUMS[n] for n in ('TFX_OP_GEMM_NT', 'TFX_OP_FORK', 'TFX_OP_GEMM_TN', 'TFX_OP_JOIN_RECORD',
+                                                                       'TFX_OP_JOIN_WAIT', 'TFX_OP_JOIN')]
+    assert all(arr2[k].args for k in range(6))
+    assert lib.tfx_set_single_stream(1) == 0 and lib.tfx_set_single_stream(0) == 1
     # runner: empty list is a no-op, unknown op / NULL args stop at their index
     failed = ctypes.c_int32(-1)
     assert lib.tfx_run_list(None, 0, None, ctypes.byref(failed)) == 0
