@@ -131,3 +131,18 @@ def test_unsupported_options_raise_and_no_cpu_fallback():
     m = Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1))
     with pytest.raises(capi.TfxError):
         m([[torch.randint(0, 8, (4,)), torch.randn(2, 16)]])
+
+
+def test_bench_workload_matches_the_survey_definition():
+    """bench.py's synthetic sample and flop count are the ones SURVEY.md section 8(d) defines: 64 parts alternating 24 text tokens /
+    a (4, 384) latent pack to 1025 tokens (n = 1024 after the last-token drop), F_core = 180.6 / 1624.5 GFLOP per sample."""
+    import bench
+    assert abs(bench.f_core_per_sample(512, 8) / 1e9 - 180.6) < 0.05
+    assert abs(bench.f_core_per_sample(1024, 24) / 1e9 - 1624.5) < 0.05
+    gen = torch.Generator().manual_seed(1234)
+    batch = bench.canonical_batch(2, 'cpu', gen)
+    assert len(batch[0]) == 64 and batch[0][1].shape == (4, 384) and batch[0][-2].numel() == 23
+    m = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=64, depth=1, heads=1))
+    P = scan_batch(batch, num_modalities=1, dim_latents=(384,), sos_id=m.sos_id, eos_id=m.eos_id, meta_id=m.meta_id, som_ids=m.som_ids,
+                   eom_ids=m.eom_ids, add_sos_eos=True)
+    assert P.n_full == 1025 and P.total_tokens == 2 * 1025 and P.positions[0][0] == (0, 28, 4)
