@@ -166,7 +166,11 @@ class Plan:
             self.gx = e(T, d); self.du = e(T, d)
             # weight-gradient GEMMs run on a side stream one layer behind the data-gradient chain (TFX_SIDE_STREAM=0: one stream):
             # the buffers they read are kept per wrapper and double-buffered by layer parity
-            self.side = os.environ.get('TFX_SIDE_STREAM', '1') != '0' and D <= 30
+            # measured (A/B on one box): dim 512 -2 % step time, dim 768 +2 %, dim 1024 +4 % - with wider models the GEMMs dominate and two
+            # GEMM kernels sharing the chip cost more than the token-wise overlap gains, so the side stream is used up to dim 512 only
+            # (TFX_SIDE_STREAM=1 forces it on, =0 off)
+            env = os.environ.get('TFX_SIDE_STREAM')
+            self.side = D <= 30 and (env == '1' or (env is None and md.dim <= 512))
             nb = 2 if self.side else 1
             self.dy_f = [e(T, d) for _ in range(nb)]; self.dy_a = [e(T, d) for _ in range(nb)] if self.side else self.dy_f
             self.dskip = {j: e(T, d) for j in set(skip_sources(md).values())}
