@@ -17,6 +17,9 @@ CASES = {
     'mid2':    (dict(num_text_tokens=256, dim=256, depth=4, dim_latents=(384, 192), heads=4, dim_head=64), 'two_modality', 2),
     'head8':   (dict(num_text_tokens=256, dim=128, depth=2, dim_latents=(16,),      heads=4, dim_head=8),  'ragged', 3),   # dim_head of train_toy.py / the reference's tests
     'canon512': (dict(num_text_tokens=256, dim=512, depth=8, dim_latents=(384,),    heads=8, dim_head=64), 'canonical', 2),
+    # the dimensions of BASELINE configs 3 / 4: depth 24 = AttentionResidual over 25 hiddens + 12 skip pairs; two modality types at dim 768
+    'cfg3_1024': (dict(num_text_tokens=256, dim=1024, depth=24, dim_latents=(384,),     heads=8, dim_head=64), 'canonical', 1),
+    'cfg4_768':  (dict(num_text_tokens=256, dim=768,  depth=16, dim_latents=(384, 192), heads=8, dim_head=64), 'two_modality', 1),
 }
 
 # pure-text cases (Transfusion.forward_text): name -> (cfg kwargs, batch, tokens per row incl. the shifted one)

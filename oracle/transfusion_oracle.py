@@ -113,7 +113,20 @@ class Packed:
     total_tokens: int = 0                            # MP:921
 
 
-def pack_batch(cfg: OracleConfig, modalities, add_sos_eos=True) -> Packed:
+def default_times(num_modalities: torch.Tensor, u_k: torch.Tensor, u_t: torch.Tensor) -> torch.Tensor:
+    """`default_modality_length_to_time_fn`, T:186-200, with its two uniform draws passed in (T:193 -> u_k, T:197 -> u_t):
+    per sample k = floor(u_k * m_b); instances < k (already 'decoded') sit at t = 0.5, all the others share the one time u_t."""
+    m = int(num_modalities.max()) if num_modalities.numel() else 0
+    if m == 0:
+        return torch.empty((num_modalities.shape[0], 0))
+    k = torch.floor(u_k * num_modalities.float())                         # T:193
+    prev = torch.arange(m)[None, :] < k[:, None]                          # T:196
+    return torch.where(prev, torch.tensor(0.5), u_t[:, None].expand(-1, m))   # T:200
+
+
+def pack_batch(cfg: OracleConfig, modalities, add_sos_eos=True, uncond_rows=()) -> Packed:
+    """`uncond_rows`: sample indices hit by the classifier-free-guidance drop (T:3027-3043): EVERY int tensor of those samples -
+    the [sos] / [eos] added just before included - is replaced by `null_text_id`; the tokens the packer adds around modalities are not."""
     b = len(modalities)
     texts, positions, total = [], [], 0
     lat = {t: [] for t in range(cfg.num_modalities)}
@@ -123,6 +136,8 @@ def pack_batch(cfg: OracleConfig, modalities, add_sos_eos=True) -> Packed:
         sample = list(sample)
         if add_sos_eos:                                                   # T:3016-3023
             sample = [torch.tensor([cfg.sos_id]), *sample, torch.tensor([cfg.eos_id])]
+        if bi in uncond_rows:                                             # T:3032-3043
+            sample = [torch.full_like(p, cfg.null_text_id) if torch.is_tensor(p) and not p.is_floating_point() else p for p in sample]
         ids, pos, m = [], [], 0
         for part in sample:
             if torch.is_tensor(part) and part.is_floating_point():        # T:3060-3061: bare float tensor is type 0
@@ -285,10 +300,11 @@ def transformer_forward(sd, cfg: OracleConfig, x, times_tok, is_mod, kv_end, rot
 # Transfusion.forward, list branch, training  (T:2926-3450)
 # ---------------------------------------------------------------------------
 
-def forward_train(sd, cfg: OracleConfig, modalities, times, noise, return_all=False):
+def forward_train(sd, cfg: OracleConfig, modalities, times, noise, return_all=False, uncond_rows=()):
     """times (b, m_max) fp32 (injected; T:2933); noise: type -> (R, dl) in scan order (see detdata.det_noise).
+    `uncond_rows`: samples whose text is dropped for classifier-free guidance (see pack_batch).
     Returns loss (and a dict of intermediates when `return_all`)."""
-    P = pack_batch(cfg, modalities, add_sos_eos=True)
+    P = pack_batch(cfg, modalities, add_sos_eos=True, uncond_rows=uncond_rows)
     b, n1 = P.text.shape
     n = n1 - 1
     d = cfg.dim

@@ -146,3 +146,24 @@ def test_bench_workload_matches_the_survey_definition():
     P = scan_batch(batch, num_modalities=1, dim_latents=(384,), sos_id=m.sos_id, eos_id=m.eos_id, meta_id=m.meta_id, som_ids=m.som_ids,
                    eom_ids=m.eom_ids, add_sos_eos=True)
     assert P.n_full == 1025 and P.total_tokens == 2 * 1025 and P.positions[0][0] == (0, 28, 4)
+
+
+def test_default_times_match_reference_golden():
+    """`Transfusion._default_times` (host glue in front of the kernels; default_modality_length_to_time_fn, T:186-200) fed with the uniform
+    draws of tests/golden/cfg1.pt must give the UNMODIFIED reference's times exactly (the GPU test repeats this through forward())."""
+    import os
+    import numpy as np
+    import torch
+    from oracle.detdata import count_instances
+    from oracle.make_golden_cfg import cfg_case, patched_uniforms
+    from transfusion_pytorch_amd import Transfusion
+    g = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'cfg1.pt'), weights_only=False)
+    cfg, sd, batch, noise, draws = cfg_case()
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    counts = np.asarray(count_instances(batch))
+    with patched_uniforms([draws['u_k'], draws['u_t']]) as pu:
+        times = model._default_times(counts)
+        assert not pu.queue
+    assert torch.equal(times.cpu(), g['times'])
+    assert model._default_times(np.zeros(3, dtype=np.int64)).shape == (3, 0)          # T:189-190

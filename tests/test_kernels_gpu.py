@@ -224,14 +224,19 @@ def attn_ref(q, k, v, gate, kv_end, cap):
     return o * gate.sigmoid()[..., None]
 
 
-@pytest.mark.parametrize('b,h,n', [(2, 2, 200), (1, 3, 128), (2, 1, 333), (1, 8, 1024)])
-def test_attention_fwd_bwd(b, h, n):
+# (qs, ks): scales of q~ / k~.  (0.35, 2.5): |s / cap| stays in the polynomial branches of the soft-cap (the training regime: QK-RMSNorm bounds
+# the scores).  (1.2, 3.0): |s / cap| reaches ~1 - the degree-9 polynomial and, for the waves holding an outlier, the wave-uniform exact
+# exp2/rcp branch (attention.hip softcap16).  (3.0, 6.0): scores of +-150 and more - every wave takes the exact branch, tanh saturates
+# (1 - tanh^2 -> 0 in the backward), the fixed-reference softmax sees exponents up to cap * log2e = 72.
+@pytest.mark.parametrize('b,h,n,qs,ks', [(2, 2, 200, 0.35, 2.5), (1, 3, 128, 0.35, 2.5), (2, 1, 333, 0.35, 2.5), (1, 8, 1024, 0.35, 2.5),
+                                         (2, 2, 200, 1.2, 3.0), (1, 2, 333, 3.0, 6.0), (1, 8, 1024, 1.2, 3.0)])
+def test_attention_fwd_bwd(b, h, n, qs, ks):
     torch.manual_seed(5)
     T, HD = b * n, h * 64
     ldq, ldv = 2 * HD, 3 * HD + 8
     qk = rnd(T, ldq, scale=1.0)                                   # q | k, token-major
-    qk[:, :HD] *= 0.35                                            # q~ carries the 1/8 scale -> moderate logits
-    qk[:, HD:] *= 2.5
+    qk[:, :HD] *= qs                                              # q~ carries the 1/8 scale
+    qk[:, HD:] *= ks
     qkv = rnd(T, ldv)                                             # (unused q,k cols) | v | gates
     kv_end, q_start = make_kv_end(b, n)
     kv_end, q_start = kv_end.to(DEV), q_start.to(DEV)
@@ -265,6 +270,46 @@ def test_attention_fwd_bwd(b, h, n):
     check('attn dk', heads(dqk[:, HD:]), k.grad, 2e-2)
     check('attn dv', heads(dqkv[:, 2 * HD:3 * HD]), v.grad, 2e-2)
     check('attn dgate', dqkv[:, 3 * HD:3 * HD + h].float().reshape(b, n, h).transpose(1, 2), g.grad, 2e-2)
+    sim = torch.einsum('bhid,bhjd->bhij', q.detach(), k.detach()).abs() / 50.
+    print(f'  |s / cap|: median {sim.median():.3f} max {sim.max():.3f}; share above the polynomial bound 0.45: {(sim > 0.45).float().mean():.4f}')
+    if qs > 1.:
+        assert (sim > 0.45).any(), 'this case must reach the exact-tanh branch'
+
+
+@pytest.mark.parametrize('b,h,lq,n_kv', [(3, 2, 1, 300), (2, 4, 4, 200), (5, 1, 6, 64), (2, 8, 16, 1100)])
+def test_attention_fwd_against_kv_cache(b, h, lq, n_kv):
+    """decode-time call (engine.Plan(cache=...)): `lq` new query rows per sample against keys / values that live in a LONGER per-sample
+    cache buffer (`n_kv` > n rows, token-major [b, n_kv, 2 * h * 64] = k~ | v), each query row with its own visible length `kv_end`
+    (own prefix + the block being decoded; rows of finished samples see a short prefix).  Reference: masked softmax in fp32."""
+    torch.manual_seed(11)
+    HD = h * 64
+    T = b * lq
+    q = rnd(T, HD, scale=0.35)
+    cache = rnd(b * n_kv, 2 * HD)
+    cache[:, :HD] *= 2.5
+    gates = rnd(T, 8 + h)
+    g = torch.Generator().manual_seed(3)
+    kv_end = torch.stack([torch.randint(1, n_kv + 1, (1,), generator=g).expand(lq) for _ in range(b)]).clone()
+    kv_end[0] = n_kv                                              # a full cache
+    kv_end[-1] = 1                                                # a single visible key
+    kv_end = kv_end.to(torch.int32).to(DEV)
+    out = torch.full((T, HD), float('nan'), device=DEV, dtype=BF)
+    lse = torch.zeros(b, h, lq, device=DEV)
+    a = capi.make_args('tfx_attn_args', q=q, k=cache, v=cache[:, HD:], ld_q=HD, ld_k=2 * HD, ld_v=2 * HD, gate=gates[:, 8:], ld_gate=8 + h,
+                       kv_end=kv_end, q_start=torch.zeros(T, dtype=torch.int32, device=DEV), out=out, ld_out=HD, lse=lse, b=b, h=h, n=lq,
+                       n_kv=n_kv, softcap=50.0)
+    capi.call('tfx_attn_fwd', a, stream())
+    torch.cuda.synchronize()
+    qh = q.float().reshape(b, lq, h, 64).transpose(1, 2)
+    kh = cache[:, :HD].float().reshape(b, n_kv, h, 64).transpose(1, 2)
+    vh = cache[:, HD:].float().reshape(b, n_kv, h, 64).transpose(1, 2)
+    sim = torch.tanh(torch.einsum('bhid,bhjd->bhij', qh, kh) / 50.) * 50.
+    mask = torch.arange(n_kv, device=DEV)[None, None, :] < kv_end.long()[:, :, None]
+    sim = sim.masked_fill(~mask[:, None], -torch.finfo(torch.float32).max)
+    ref = torch.einsum('bhij,bhjd->bhid', sim.softmax(-1), vh) * gates[:, 8:8 + h].float().reshape(b, lq, h).transpose(1, 2).sigmoid()[..., None]
+    check(f'attn fwd vs cache b{b} h{h} lq{lq} n_kv{n_kv}', out.float().reshape(b, lq, h, 64).transpose(1, 2), ref, 8e-3)
+    ref_lse = torch.logsumexp(sim, dim=-1)
+    assert (lse - ref_lse).abs().max() <= 2e-2
 
 
 # ---------------------------------------------------------------------------------------------- token-wise

@@ -2,12 +2,15 @@
 the UNMODIFIED reference produced (tests/golden/*.pt, fp32 CPU) and - for the small cases - the live oracle.
 
 Tolerances (bf16 vs fp32; the reference's own bf16-autocast floor is rel-Frobenius 4.9e-3 on logits):
-  loss / text loss / flow losses : |delta| <= 2e-3 * max(1, |ref|)
-  logits, final embed            : rel-Frobenius <= 1.5e-2
+  loss / text loss / flow losses : |delta| <= 2e-3 * max(1, |ref|)          (measured 7e-6 ... 4e-5: the north star's 1e-3 is met on the losses)
+  logits, final embed            : rel-Frobenius <= 1e-2 = LOGIT_TOL           (measured 5.9e-3 at dim512/depth8: bf16 activations cannot reach 1e-3 here -
+                                   the reference's own bf16-autocast run is at 4.9e-3)
   greedy token (argmax)          : identical wherever the reference's top-2 margin exceeds 0.05; >= 97.5% overall
                                    (near-ties of random-init logits flip under ANY bf16 rounding: the reference's own
                                    bf16-autocast run agrees with its fp32 run on 99.1%)
-  gradients                      : per-parameter rel-Frobenius <= 6e-2 (norm-weighted mean <= 2e-2)
+  gradients                      : per-parameter rel-Frobenius <= 4e-2 = GRAD_TOL (measured worst 3.3e-2), norm-weighted mean <= 1.2e-2 = GRAD_MEAN_TOL
+                                   (measured 7.1e-3); 1024-element HEAD slices of a gradient (big cases) <= 6e-2 = GRAD_HEAD_TOL
+Tolerances are ~1.5x the worst value measured on MI355X, so that a regression which doubles an error fails.
 """
 import os
 
@@ -20,6 +23,7 @@ from oracle.cases import build_case, with_grad          # noqa: E402
 from oracle.transfusion_oracle import forward_train     # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+LOGIT_TOL, GRAD_TOL, GRAD_MEAN_TOL, GRAD_HEAD_TOL = 1e-2, 4e-2, 1.2e-2, 6e-2
 
 
 def build_native(cfg, sd):
@@ -59,8 +63,10 @@ def compare_losses(out, g):
         assert abs(a - r) <= 2e-3 * max(1., abs(r)), nm
 
 
-@pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'head8', 'canon512'])
+@pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'head8', 'canon512', 'cfg4_768', 'cfg3_1024'])
 def test_training_step_matches_reference_golden(name):
+    """`cfg4_768` / `cfg3_1024`: the model dimensions of BASELINE configs 4 and 3 (dim768/depth16 with two modality types, dim1024/depth24:
+    AttentionResidual over 25 hiddens, 12 U-Net skip pairs), one canonical 1024-token sample each, golden from the unmodified reference."""
     g = torch.load(os.path.join(GOLDEN, f'{name}.pt'), weights_only=False)
     cfg, model, out = run_native(name)
     print(f'[{name}]')
@@ -75,7 +81,7 @@ def test_training_step_matches_reference_golden(name):
     safe = margin > 0.05
     agree_safe = (am_n == am_r)[safe].float().mean().item()
     print(f'  logits rel-fro {e_log:.3e}  embed rel-fro {e_emb:.3e}  argmax agreement {agree:.4f} (margin>0.05: {agree_safe:.4f}, {safe.float().mean():.3f} of positions)')
-    assert e_log <= 1.5e-2 and e_emb <= 1.5e-2
+    assert e_log <= LOGIT_TOL and e_emb <= LOGIT_TOL
     assert agree_safe == 1.0 and agree >= 0.975
     worst, num, den = (None, 0.), 0., 0.
     for k, gn in g['grad_norms'].items():
@@ -91,9 +97,49 @@ def test_training_step_matches_reference_golden(name):
         num += e * gn; den += gn
         if e > worst[1]:
             worst = (k, e)
-        assert e <= 6e-2, f'gradient {k}: rel err {e:.3e}'
+        assert e <= GRAD_TOL, f'gradient {k}: rel err {e:.3e}'
     print(f'  gradients: norm-weighted mean rel err {num / den:.3e}; worst {worst[0]} {worst[1]:.3e}')
-    assert num / den <= 2e-2
+    assert num / den <= GRAD_MEAN_TOL
+
+
+def test_default_times_and_cfg_drop_match_reference_golden():
+    """The DEFAULT training call - `model(batch)` with no `times=` and the CFG text drop active - is what bench.py times.  Golden
+    `cfg1.pt` (oracle/make_golden_cfg.py): the reference's own call with its three uniform draws replaced by fixed vectors.  The native
+    path draws the same three vectors (times first: T:193, T:197; then the drop mask, T:3030) and must reproduce the reference's
+    `times` EXACTLY (default_modality_length_to_time_fn, T:186-200) and its loss / gradients (dropped rows: every user token, [sos],
+    [eos] -> null id, T:3032-3043; null labels ignored, T:3322-3323) within the usual tolerances."""
+    from oracle.make_golden_cfg import cfg_case, patched_uniforms
+    g = torch.load(os.path.join(GOLDEN, 'cfg1.pt'), weights_only=False)
+    cfg, sd, batch, noise, draws = cfg_case()
+    from transfusion_pytorch_amd import Transfusion
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads), prob_uncond=g['prob_uncond'])
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    model._noise_override = {t: v.cuda() for t, v in noise.items()}
+    with patched_uniforms([draws['u_k'], draws['u_t'], draws['u_cfg']]) as pu:
+        loss, bd, times = model(batch, return_breakdown=True, return_times=True)
+        assert not pu.queue, 'the native forward must consume exactly the reference\'s three uniform draws'
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(times.cpu(), g['times']), (times, g['times'])
+    out = dict(loss=float(loss), text=float(bd.text), flow=[float(f) for f in bd.flow])
+    compare_losses(out, g)
+    worst, wsum, nsum = 0., 0., 0.
+    for k, p in model.named_parameters():
+        if k not in g['grad_norms'] or g['grad_norms'][k] < 1e-7:
+            continue
+        r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
+        gn = float(p.grad.double().norm())
+        assert abs(gn - g['grad_norms'][k]) <= GRAD_TOL * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
+    print(f'  gradients: worst head rel {worst:.3e}, norm-weighted mean {wsum / nsum:.3e}')
+    assert worst <= GRAD_HEAD_TOL and wsum / nsum <= GRAD_MEAN_TOL
+    # eval(): no drop (T:3029 is gated on self.training) - the loss changes
+    model.eval()
+    with patched_uniforms([draws['u_k'], draws['u_t']]):
+        loss_eval = model(batch)
+    assert abs(float(loss_eval) - float(g['loss'])) > 1e-2
 
 
 def test_tiny_matches_live_oracle_and_updates():
@@ -107,7 +153,7 @@ def test_tiny_matches_live_oracle_and_updates():
     assert abs(out['loss'] - float(ref['loss'])) <= 2e-3 * max(1., abs(float(ref['loss'])))
     for k, p in sdg.items():
         if p.requires_grad:
-            assert rel(out['grads'][k], p.grad) <= 6e-2, k
+            assert rel(out['grads'][k], p.grad) <= GRAD_TOL, k
     # fused optimizer step vs torch.optim.Adam + clip_grad_norm_ on the SAME (native) gradients
     from transfusion_pytorch_amd.optim import FusedAdam
     params = [p for p in model.parameters() if p.requires_grad]
@@ -149,16 +195,16 @@ def test_odd_configurations_match_live_oracle(dim, depth, heads, dls, dim_head):
     print(f'  dim {dim} depth {depth} heads {heads} dim_head {dim_head}: loss native {float(loss.detach()):.6f} oracle {float(ref["loss"].detach()):.6f}')
     assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-3 * max(1., abs(float(ref['loss'].detach())))
     plan = model._live[0]
-    assert rel(plan.logits.view(plan.b, plan.n, -1)[..., :cfg.vocab].float().cpu(), ref['logits'].detach()) <= 1.5e-2
+    assert rel(plan.logits.view(plan.b, plan.n, -1)[..., :cfg.vocab].float().cpu(), ref['logits'].detach()) <= LOGIT_TOL
     wsum = nsum = 0.
     for k, p in model.named_parameters():
         gr = sdg[k].grad if sdg[k].requires_grad else None
         if gr is None or float(gr.norm()) < 1e-7:
             continue
         r = rel(p.grad, gr)
-        assert r <= 8e-2, (k, r)
+        assert r <= GRAD_HEAD_TOL, (k, r)
         wsum += r * float(gr.norm()); nsum += float(gr.norm())
-    assert wsum / nsum <= 2e-2
+    assert wsum / nsum <= GRAD_MEAN_TOL
 
 
 def test_identity_latent_projection_matches_live_oracle():
@@ -183,7 +229,7 @@ def test_identity_latent_projection_matches_live_oracle():
     assert abs(float(loss.detach()) - float(ref['loss'])) <= 2e-3 * max(1., abs(float(ref['loss'])))
     for k, p in model.named_parameters():
         if sdg[k].requires_grad and sdg[k].grad is not None and float(sdg[k].grad.norm()) > 1e-7:
-            assert rel(p.grad, sdg[k].grad) <= 6e-2, k
+            assert rel(p.grad, sdg[k].grad) <= GRAD_TOL, k
 
 
 def test_forward_text_matches_reference_golden():
@@ -201,7 +247,7 @@ def test_forward_text_matches_reference_golden():
     assert abs(float(loss) - float(g['loss'])) <= 2e-3 * max(1., abs(float(g['loss'])))
     plan = model._live[0]
     embed = plan.embed.view(plan.b, plan.n, -1).float().cpu()
-    assert rel(embed, g['embed']) <= 1.5e-2
+    assert rel(embed, g['embed']) <= LOGIT_TOL
     worst, wsum, nsum = 0., 0., 0.
     for k, p in model.named_parameters():
         if k not in g['grad_norms'] or g['grad_norms'][k] < 1e-7:
@@ -209,13 +255,13 @@ def test_forward_text_matches_reference_golden():
         assert p.grad is not None, k
         r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
         gn = float(p.grad.double().norm())
-        assert abs(gn - g['grad_norms'][k]) <= 6e-2 * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        assert abs(gn - g['grad_norms'][k]) <= GRAD_TOL * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
         worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
     print(f'  gradients: worst head rel {worst:.3e}, norm-weighted mean {wsum / nsum:.3e}')
-    assert worst <= 8e-2 and wsum / nsum <= 2e-2
+    assert worst <= GRAD_HEAD_TOL and wsum / nsum <= GRAD_MEAN_TOL
     with torch.no_grad():
         logits = model(text[:, :-1].cuda(), return_loss=False)             # tensor input routes to forward_text (T:2967)
-    assert rel(logits.float().cpu(), g['logits']) <= 1.5e-2
+    assert rel(logits.float().cpu(), g['logits']) <= LOGIT_TOL
 
 
 def test_forward_modality_matches_reference_golden():
@@ -241,13 +287,13 @@ def test_forward_modality_matches_reference_golden():
         assert p.grad is not None, k
         r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
         gn = float(p.grad.double().norm())
-        assert abs(gn - g['grad_norms'][k]) <= 6e-2 * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        assert abs(gn - g['grad_norms'][k]) <= GRAD_TOL * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
         worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
     print(f'  gradients: worst head rel {worst:.3e}, norm-weighted mean {wsum / nsum:.3e}')
-    assert worst <= 8e-2 and wsum / nsum <= 2e-2
+    assert worst <= GRAD_HEAD_TOL and wsum / nsum <= GRAD_MEAN_TOL
     with torch.no_grad():
         pred = model(x.cuda(), times=times, modality_type=ty, return_loss=False)          # float tensor routes to forward_modality (T:2989)
-    assert pred.shape == x.shape and rel(pred.cpu(), g['pred_noloss']) <= 1.5e-2
+    assert pred.shape == x.shape and rel(pred.cpu(), g['pred_noloss']) <= LOGIT_TOL
     model._gen_noise_override = gen_noise('flow1', 2, shape, cfg.dim_latents[ty])
     gen = model.generate_modality_only(batch_size=2, modality_type=ty, fixed_modality_shape=tuple(shape), modality_steps=g['gen_steps'])
     r = rel(gen.cpu(), g['gen'])
@@ -280,10 +326,10 @@ def test_velocity_consistency_matches_reference_golden():
             continue
         r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
         gn = float(p.grad.double().norm())
-        assert abs(gn - g['grad_norms'][k]) <= 6e-2 * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        assert abs(gn - g['grad_norms'][k]) <= GRAD_TOL * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
         worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
     print(f'  gradients: worst head rel {worst:.3e}, norm-weighted mean {wsum / nsum:.3e}')
-    assert worst <= 8e-2 and wsum / nsum <= 2e-2
+    assert worst <= GRAD_HEAD_TOL and wsum / nsum <= GRAD_MEAN_TOL
     # EMA wrapper: after the warm-up copy, update() is ema = d*ema + (1-d)*online in one fused launch
     ema = student.create_ema()
     ema.update_after_step, ema.update_every = 0, 1
@@ -373,6 +419,25 @@ def test_side_stream_weight_gradients_equal_single_stream():
         assert abs(o['loss'] - ref['loss']) <= 1e-6 * max(1., abs(ref['loss']))
         for k in ref['grads']:
             assert rel(o['grads'][k], ref['grads'][k]) <= 2e-3, k
+
+
+def test_upstream_gradient_scales_seeds_once_and_second_backward_raises():
+    """`(loss / 3).backward()`: the upstream gradient reaches the loss seeds as an fp32 device scalar (tfx_scale_bf16_dev) - every gradient is
+    exactly the plain one / 3 up to bf16 rounding of the seeds; a second backward of the same forward raises instead of double-scaling."""
+    cfg, sd, batch, times, noise = build_case('small2')
+    grads = []
+    for div in (1., 3.):
+        model = build_native(cfg, sd).train()
+        model._noise_override = {t: v.cuda() for t, v in noise.items()}
+        loss = model(batch, times=times)
+        (loss / div).backward(retain_graph=True)
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None})
+        with pytest.raises(RuntimeError, match='second time'):
+            loss.backward()
+    for k in grads[0]:
+        if float(grads[0][k].norm()) > 1e-7:
+            assert rel(grads[1][k] * 3., grads[0][k]) <= 6e-3, k
 
 
 def test_no_fallback_on_cpu():

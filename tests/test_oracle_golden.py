@@ -16,7 +16,7 @@ def load_golden(name):
     return torch.load(os.path.join(GOLDEN, f'{name}.pt'), weights_only=False)
 
 
-@pytest.mark.parametrize('name', FAST + ['canon512'])
+@pytest.mark.parametrize('name', FAST + ['canon512', 'cfg4_768'])
 def test_oracle_matches_reference_golden(name):
     g = load_golden(name)
     cfg, sd, batch, times, noise = build_case(name)
@@ -46,6 +46,32 @@ def test_oracle_matches_reference_golden(name):
     P = out['packed']
     b, n = out['kv_end'].shape
     assert torch.equal(naive_mask(P.positions, b, n), torch.arange(n)[None, None, :] < out['kv_end'][:, :, None])
+
+
+def test_default_times_and_cfg_drop_match_reference_golden():
+    """tests/golden/cfg1.pt: the reference's DEFAULT training call (no `times=`, CFG drop active) with its three uniform draws replaced
+    by the deterministic vectors of oracle/make_golden_cfg.py.  The restatement of `default_modality_length_to_time_fn` (T:186-200)
+    must give the reference's times exactly, and the drop (T:3027-3043) + null-label masking (T:3322-3323) its loss / gradients."""
+    from oracle.make_golden_cfg import cfg_case
+    from oracle.transfusion_oracle import default_times
+    from oracle.detdata import count_instances
+    g = load_golden('cfg1')
+    cfg, sd, batch, noise, draws = cfg_case()
+    times = default_times(torch.tensor(count_instances(batch)), draws['u_k'], draws['u_t'])
+    assert torch.equal(times, g['times'])
+    rows = set((draws['u_cfg'] < g['prob_uncond']).nonzero().flatten().tolist())
+    assert rows == set(g['dropped_rows'].nonzero().flatten().tolist()) and len(rows) >= 2
+    sdg = with_grad(sd)
+    out = forward_train(sdg, cfg, batch, times, noise, return_all=True, uncond_rows=rows)
+    assert abs(float(out['loss']) - float(g['loss'])) < 2e-5 and abs(float(out['text_loss']) - float(g['text_loss'])) < 2e-5
+    for a, b in zip(out['flow_losses'], g['flow_losses']):
+        assert abs(float(a) - float(b)) < 2e-5
+    out['loss'].backward()
+    for k, gn in g['grad_norms'].items():
+        assert abs(float(sdg[k].grad.double().norm()) - gn) <= 1e-4 * gn + 1e-9, k
+    # without the drop the loss differs: the fixture really exercises the branch
+    plain = forward_train(sd, cfg, batch, times, noise)
+    assert abs(float(plain) - float(g['loss'])) > 1e-2
 
 
 def test_packed_layout_known_answers():

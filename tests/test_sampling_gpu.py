@@ -2,7 +2,8 @@
 produced (oracle/make_golden_sampling.py: deterministic weights, prompts and initial noise, greedy text).
 
 bf16 vs fp32 cannot promise identical greedy tokens at near-ties on random-like weights, so the test pins:
-  * the sampled token sequence up to the first reference near-tie (in practice: the whole sequence, see printed report),
+  * EVERY greedy decision whose reference top-2 margin (recorded in the golden, oracle/make_golden_sampling.py) is >= 0.05, and every
+    forced / prompt token: identical; the native path may leave the reference's only AT a recorded near-tie,
   * every decoded modality (midpoint ODE with / without CFG) while the two histories still agree: rel-Frobenius <= 5e-2,
   * sample_one == sample_many for one prompt (the reference's own equivalence test, tests/test_transfusion.py:758-808),
   * self-consistency of the KV cache: teacher-forced full-sequence logits reproduce every cached greedy decision.
@@ -17,11 +18,12 @@ pytestmark = pytest.mark.gpu
 from oracle.make_golden_sampling import sampling_case      # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'sampling.pt')
+GOLDEN_DEEP = os.path.join(os.path.dirname(__file__), 'golden', 'sampling_deep.pt')
 
 
-def native_model():
+def native_model(deep=False):
     from transfusion_pytorch_amd import Transfusion
-    cfg, sd, prompts, noise = sampling_case()
+    cfg, sd, prompts, noise = sampling_case(deep)
     m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents[0], modality_default_shape=(4,),
                     transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
     m.load_state_dict(sd)
@@ -32,48 +34,65 @@ def plain(sample):
     return [('mod', int(p[0]), p[1].float().cpu()) if isinstance(p, tuple) else ('text', p.cpu().long()) for p in sample]
 
 
-def compare(native, ref):
-    """returns (tokens compared, tokens equal before first divergence, list of modality rel errors while histories agree, diverged?)"""
-    n_tok = n_eq = 0
+NEAR_TIE = 0.05        # reference top-2 logit margin below which a bf16 path may legitimately pick the other token
+
+
+def walk(native, ref, margins):
+    """token-by-token comparison of one sample against the reference's greedy path.  `margins`: {(part, position): reference top-2
+    margin} for every token the reference DECIDED (prompt / forced tokens are absent).  Returns (decisive steps verified, near-tie
+    steps passed, modality rel errors, None | (part, pos, margin) of the near-tie at which the native path left the reference's).
+    A mismatch anywhere else - a decisive step, a forced token, the part structure before a divergence - raises."""
+    n_dec = n_tie = 0
     mod_errs = []
-    for pn, pr in zip(native, ref):
-        if pn[0] != pr[0]:
-            return n_tok, n_eq, mod_errs, True
+    for pi, (pn, pr) in enumerate(zip(native, ref)):
+        assert pn[0] == pr[0], f'part {pi}: kind {pn[0]} vs reference {pr[0]}'
         if pn[0] == 'mod':
-            if pn[2].shape != pr[2].shape:
-                return n_tok, n_eq, mod_errs, True
+            assert pn[2].shape == pr[2].shape, f'part {pi}: modality shape'
             mod_errs.append(((pn[2] - pr[2]).norm() / pr[2].norm()).item())
             continue
         a, b = pn[1].tolist(), pr[1].tolist()
-        for x, y in zip(a, b):
-            n_tok += 1
-            if x != y:
-                return n_tok, n_eq, mod_errs, True
-            n_eq += 1
-        if len(a) != len(b):
-            return n_tok, n_eq, mod_errs, True
-    return n_tok, n_eq, mod_errs, len(native) != len(ref)
+        for pos, y in enumerate(b):
+            mg = margins.get((pi, pos))
+            if pos >= len(a) or a[pos] != y:
+                assert mg is not None and mg < NEAR_TIE, \
+                    f'part {pi} pos {pos}: native {a[pos] if pos < len(a) else None} != reference {y} on a decisive step (margin {mg})'
+                return n_dec, n_tie, mod_errs, (pi, pos, mg)
+            if mg is not None:
+                n_dec += mg >= NEAR_TIE; n_tie += mg < NEAR_TIE
+        assert len(a) == len(b), f'part {pi}: native continues past the reference'
+    assert len(native) == len(ref)
+    return n_dec, n_tie, mod_errs, None
 
 
-@pytest.mark.parametrize('run,kw', [('free', {}), ('forced', dict(force_modality_at_start=0)), ('forced_nocfg', dict(force_modality_at_start=0, cfg_scale=1.))])
-def test_sample_many_matches_reference_golden(run, kw):
-    g = torch.load(GOLDEN, weights_only=False)
-    m, prompts, noise = native_model()
-    kwargs = dict(max_length=12, text_temperature=0., init_modality_noise=noise, modality_steps=4, fixed_modality_shape=(4,), cfg_scale=3.)
+RUNS = [('free', {}), ('forced', dict(force_modality_at_start=0)), ('forced_nocfg', dict(force_modality_at_start=0, cfg_scale=1.))]
+
+
+@pytest.mark.parametrize('run,kw', RUNS)
+@pytest.mark.parametrize('deep', [False, True])
+def test_sample_many_matches_reference_golden(run, kw, deep):
+    """every greedy decision whose reference top-2 margin is >= 0.05 must be identical; the native path may leave the reference's
+    only AT a recorded near-tie (after which the two histories differ and nothing more can be compared for that sample).  `deep`:
+    dim256 / depth 8, max_length 64, 16 ODE grid points (the reference default)."""
+    from oracle.make_golden_sampling import DEEP_KW
+    g = torch.load(GOLDEN_DEEP if deep else GOLDEN, weights_only=False)
+    m, prompts, noise = native_model(deep)
+    kwargs = dict(DEEP_KW, init_modality_noise=noise) if deep else \
+        dict(max_length=12, text_temperature=0., init_modality_noise=noise, modality_steps=4, fixed_modality_shape=(4,), cfg_scale=3.)
     kwargs.update(kw)
     outs = m.sample_many([p if not isinstance(p, list) else list(p) for p in prompts], **kwargs)
-    total = eq = 0
-    n_div = 0
-    for i, (o, r) in enumerate(zip(outs, g['runs'][run])):
-        n_tok, n_eq, errs, div = compare(plain(o), r)
-        print(f'[{run}] sample {i}: {n_eq}/{n_tok} tokens identical before first divergence; modality rel errs {["%.2e" % e for e in errs]}; diverged={div}')
-        total += n_tok; eq += n_eq; n_div += int(div)
+    tot_dec = tot_all = n_mod = 0
+    for i, (o, r, mg) in enumerate(zip(outs, g['runs'][run], g['margins'][run])):
+        margins = {(pi, pos): v for pi, pos, v in mg}
+        n_dec, n_tie, errs, div = walk(plain(o), r, margins)
+        all_dec = sum(v >= NEAR_TIE for v in margins.values())
+        print(f'[{run}{"/deep" if deep else ""}] sample {i}: {n_dec}/{all_dec} decisive steps identical (+{n_tie} near-ties passed); modality rel errs '
+              f'{["%.2e" % e for e in errs]}; left the reference path at {div}')
+        tot_dec += n_dec; tot_all += all_dec; n_mod += len(errs)
         for e in errs:
             assert e <= 5e-2
-        if run != 'free':
-            assert len(errs) >= 1, 'the forced modality must have been decoded and compared'
-    # random-like weights give near-uniform logits: allow at most one sample of the four to leave the reference's greedy path
-    assert n_div <= 1, f'{n_div} of 4 samples diverged from the reference greedy path'
+    if run != 'free':
+        assert n_mod >= 4, 'the forced modalities must have been decoded and compared'
+    assert tot_dec >= 0.5 * tot_all, f'only {tot_dec} of {tot_all} decisive steps could be compared before near-tie divergences'
 
 
 def test_sample_one_equals_sample_many_and_cache_is_consistent():

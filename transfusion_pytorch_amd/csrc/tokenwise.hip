@@ -922,6 +922,18 @@ __global__ void add_bf16_k(const bf16* a, const bf16* b, bf16* o, long long n) {
   } else for (; i < n; i++) o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
 }
 
+__global__ void scale_bf16_dev_k(bf16* x, long long n, const float* scale) {
+  const float sc = *scale;
+  if (sc == 1.f) return;                                   // the default upstream gradient: nothing to do
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 7 < n) {
+    bf16x8 v = *(const bf16x8*)(x + i);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = f2bf(bf2f(v[e]) * sc);
+    *(bf16x8*)(x + i) = v;
+  } else for (; i < n; i++) x[i] = f2bf(bf2f(x[i]) * sc);
+}
+
 template <typename T> __global__ __launch_bounds__(256) void colsum_k(const T* src, int ld, int R, int C, const int* colmap, const int* rowmap, float* out, int rows_per_block) {
   __shared__ float s[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -1143,6 +1155,11 @@ int tfx_silu_bwd(const tfx_bf16* dy, const tfx_bf16* pre, tfx_bf16* dx, int64_t 
 }
 int tfx_add_bf16(const tfx_bf16* a, const tfx_bf16* b, tfx_bf16* o, int64_t n, void* s) {
   if (n == 0) return 0; hipLaunchKernelGGL(add_bf16_k, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, ST(s), a, b, o, (long long)n); RET();
+}
+int tfx_scale_bf16_dev(tfx_bf16* x, int64_t n, const float* scale, void* s) {
+  if (n == 0) return 0;
+  if (!x || !scale) return -1;
+  hipLaunchKernelGGL(scale_bf16_dev_k, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, ST(s), x, (long long)n, scale); RET();
 }
 static inline int colsum_rows_per_block(int R) { int rpb = (R + 63) / 64; return rpb < 4 ? 4 : rpb; }
 int tfx_colsum_bf16(const tfx_bf16* src, int32_t ld, int32_t R, int32_t C, const int32_t* colmap, const int32_t* rowmap, float* out, void* s) {

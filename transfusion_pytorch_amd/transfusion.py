@@ -7,6 +7,7 @@ Unsupported reference options raise NotImplementedError - there is no silent PyT
 """
 from __future__ import annotations
 
+import ctypes
 from typing import NamedTuple
 
 import numpy as np
@@ -137,6 +138,7 @@ class Transfusion(nn.Module):
         self._struct_cache = {}
         self._step_id = 0
         self._live = None
+        self._consumed = -1
         self._bwd_scale = None
         self._anchor = None
         self._rope = None
@@ -587,17 +589,25 @@ class Transfusion(nn.Module):
         plan, live_id = self._live
         if live_id != step_id:
             raise RuntimeError('backward() of a stale loss: the native engine keeps the activations of the latest forward only')
+        if self._consumed == step_id:
+            # the loss seeds (d loss / d logits, d loss / d pred flows) are scaled in place by the upstream gradient below and the
+            # backward scratch is reused: a second pass would silently double-scale and double-accumulate - refuse, like autograd
+            # does for a freed graph
+            raise RuntimeError('backward() through the native Transfusion step a second time: the engine keeps one set of loss seeds per '
+                               'forward (call forward again; retain_graph is not supported)')
+        self._consumed = step_id
         ps = self.store
         ps.ensure_grad_views()
-        go = grad_out.reshape(())                             # d(total)/d(loss): scales the loss seeds (everything downstream is linear)
+        go = grad_out.reshape(()).to(torch.float32)           # d(total)/d(loss): scales the loss seeds (everything downstream is linear)
         if self._bwd_scale is not None:
             go = go * self._bwd_scale                         # forward_text: 1 / #valid labels, known on the device only
-        go = go.to(torch.bfloat16)
-        plan.dlogits.mul_(go)
-        for lt in plan.lat.values():
-            lt['dpred'].mul_(go)
+        lib, stream = capi.lib(), self._stream()
+        sp = ctypes.c_void_p(stream)
+        # fp32 scalar read on the device; exactly 1.0 (plain loss.backward()) skips the pass over the seeds
+        for seed in [plan.dlogits] + [lt['dpred'] for lt in plan.lat.values()]:
+            capi.check(lib.tfx_scale_bf16_dev(seed.data_ptr(), seed.numel(), go.data_ptr(), sp), 'tfx_scale_bf16_dev')
         plan.dtables.zero_()
-        Plan.run(plan.bwd, self._stream())
+        Plan.run(plan.bwd, stream)
 
     # ------------------------------------------------------------------ sampling surface (T:1842-2583)
     @torch.no_grad()
