@@ -7,7 +7,8 @@ dev = 'cuda'; BF = torch.bfloat16
 b, h, n = 64, 8, 1024
 HD = h * 64; T = b * n
 torch.manual_seed(0)
-qk = (torch.randn(T, 2 * HD, device=dev) * 1.0).to(BF); v = torch.randn(T, HD, device=dev).to(BF)
+qk = torch.randn(T, 2 * HD, device=dev); qk[:, :HD] *= 0.125; qk = qk.to(BF)      # |q~| = 1, |k~| = 8: the statistics QK-RMSNorm gives
+v = torch.randn(T, HD, device=dev).to(BF)
 gate = torch.randn(T, h, device=dev).to(BF)
 # canonical structure: 32 x [24 text + 4 latent]; latent tokens see their whole instance
 pos = torch.arange(n, device=dev)
@@ -31,7 +32,7 @@ e0.record(); capi.call('tfx_attn_fwd', a, st); e1.record(); torch.cuda.synchroni
 print(f'attn_fwd b{b} h{h} n{n}: {e0.elapsed_time(e1) * 1e3:.1f} us')
 s = stamps.view(-1, 5).cpu().double()
 tiles = s[:, 4].sum()
-names = ['wait+barrier+dma issue', 'S=K.Q^T (mfma+frag reads)', 'softcap+exp (valu)', 'P.V (mfma+tr reads)']
+names = ['wait+barrier+dma issue', 'S=K.Q^T (mfma+frag reads)', 'softcap+exp (valu)', 'P.V (mfma+tr reads)'] if os.environ.get('TFX_ATTN_PIPE') == '0' else ['vmcnt wait + barrier', 'DMA issue', 'stage A: soft-cap (2 units)', 'stage B: exp/pack + 16 MFMA (2 units)']
 tot = s[:, :4].sum()
 for i in range(4):
     print(f'  {names[i]:28s} {float(s[:, i].sum() / tiles):8.0f} ticks per wave-tile  ({100 * float(s[:, i].sum() / tot):4.1f} %)')

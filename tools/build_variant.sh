@@ -1,0 +1,24 @@
+#!/bin/bash
+# build a second copy of the library for same-box A/B runs (TFX_LIB=<path>): tools/build_variant.sh <name> [git-rev|WORK] [extra hipcc flags...]
+# output: transfusion_pytorch_amd/lib/libtfx_<name>.so (git-ignored, travels with gpurun)
+set -e
+NAME=$1; REV=${2:-WORK}; shift; shift || true
+R=$(cd $(dirname $0)/.. && pwd)
+W=$(mktemp -d)
+mkdir -p $W/pkg/csrc $W/include          # the sources include "../../include/tfx.h" relative to csrc
+if [ "$REV" = WORK ]; then
+  cp $R/transfusion_pytorch_amd/csrc/* $W/pkg/csrc/; cp $R/include/tfx.h $W/include/
+else
+  for f in gemm.hip attention.hip tokenwise.hip runner.hip tfx_common.h tfx_kernels.h; do git -C $R show $REV:transfusion_pytorch_amd/csrc/$f > $W/pkg/csrc/$f; done
+  git -C $R show $REV:include/tfx.h > $W/include/tfx.h
+fi
+OBJS=""
+for s in gemm attention tokenwise runner; do
+  FF=""; [ $s = attention ] && [ "$REV" = WORK ] && FF="-fno-slp-vectorize"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $FF "$@" -c $W/pkg/csrc/$s.hip -o $W/$s.o &
+  OBJS="$OBJS $W/$s.o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $R/transfusion_pytorch_amd/lib/libtfx_$NAME.so
+rm -rf $W
+echo built $R/transfusion_pytorch_amd/lib/libtfx_$NAME.so

@@ -18,6 +18,10 @@ HEADERS = [os.path.join(CSRC, 'tfx_common.h'), os.path.join(CSRC, 'tfx_kernels.h
            os.path.join(os.path.dirname(HERE), 'include', 'tfx.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result'] + os.environ.get('TFX_HIPCC_EXTRA', '').split()   # e.g. -DTFX_PP_TIMING (tools/pp_timing.py)
 
+# per-file flags.  attention.hip: hipcc's SLP vectoriser packs adjacent fp32 adds / multiplies into v_pk_*_f32, which issue in 6.5 clocks per
+# wave against 2 x 2.7 for the scalar pair on gfx950 (tools/valu_probe.hip): the attention kernels are VALU-bound, keep them scalar
+FILE_FLAGS = {'attention.hip': ['-fno-slp-vectorize']}
+
 
 def _hipcc() -> str:
     for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
@@ -43,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for s in SOURCES:
         o = os.path.join(LIBDIR, s.replace('.hip', '.o'))
-        cmd = [hipcc, *FLAGS, '-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(s, []), '-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), s))

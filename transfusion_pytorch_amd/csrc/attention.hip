@@ -104,40 +104,27 @@ TFX_DEV void softcap16(f32x16& s, const SoftCap& c) {
     for (int r = 0; r < 16; r++) s[r] = c.cap2 * tanh_exact(s[r] * c.icap);
     return;
   }
-  // the polynomial degree follows the wave's largest |s/cap|: x^3 below 0.12 (error < 4e-6), x^5 below 0.28 (< 8e-6), else x^9
+  // the polynomial degree follows the wave's largest |s/cap|: x^3 below 0.12 (error < 4e-6), x^5 below 0.28 (< 8e-6), else x^9.
+  // SCALAR fma forms: a wave64 v_fma_f32 issues in 2.7 clocks, v_pk_fma_f32 / v_pk_mul_f32 in 6.5 (tools/valu_probe.hip) - the packed forms
+  // are slower than the two scalar instructions they replace (the file is built with -fno-slp-vectorize so hipcc does not re-pack them)
   if (!__any(amax > c.slo)) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const f32x2 v = {s[2 * i], s[2 * i + 1]};
-      const f32x2 o = v * pk_fma(v * v, bc2(c.k3), bc2(c.k1));
-      s[2 * i] = o[0]; s[2 * i + 1] = o[1];
-    }
+    for (int r = 0; r < 16; r++) s[r] = s[r] * fmaf(s[r] * s[r], c.k3, c.k1);
   } else if (!__any(amax > c.smid)) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const f32x2 v = {s[2 * i], s[2 * i + 1]};
-      const f32x2 u = v * v;
-      const f32x2 o = v * pk_fma(u, pk_fma(u, bc2(c.k5), bc2(c.k3)), bc2(c.k1));
-      s[2 * i] = o[0]; s[2 * i + 1] = o[1];
-    }
+    for (int r = 0; r < 16; r++) { const float u = s[r] * s[r]; s[r] = s[r] * fmaf(u, fmaf(u, c.k5, c.k3), c.k1); }
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const f32x2 v = {s[2 * i], s[2 * i + 1]};
-      const f32x2 u = v * v;
-      f32x2 q = pk_fma(u, bc2(c.k9), bc2(c.k7));
-      q = pk_fma(u, q, bc2(c.k5));
-      q = pk_fma(u, q, bc2(c.k3));
-      q = pk_fma(u, q, bc2(c.k1));
-      const f32x2 o = v * q;
-      s[2 * i] = o[0]; s[2 * i + 1] = o[1];
+    for (int r = 0; r < 16; r++) {
+      const float u = s[r] * s[r];
+      s[r] = s[r] * fmaf(u, fmaf(u, fmaf(u, fmaf(u, c.k9, c.k7), c.k5), c.k3), c.k1);
     }
   }
 }
-TFX_DEV float wave_min_i(int v) {
+TFX_DEV int wave_min_i(int v) {                  // wave-uniform result, returned in an SGPR so that tests on it are scalar branches
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);
 }
 TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
   bf16x8 o;
@@ -165,7 +152,10 @@ TFX_DEV BlockId decode_block(int order, int ntile, bool heavy_last_tile) {     /
   return o;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
+#ifndef TFX_ATTN_FWD_WAVES
+#define TFX_ATTN_FWD_WAVES 3          // waves per SIMD the forward is compiled for (166 VGPRs fit three; 32 KiB of LDS per block)
+#endif
+__global__ __launch_bounds__(256, TFX_ATTN_FWD_WAVES) void attn_fwd_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(1024))) bf16 Ks[2][64 * 64];      // double-buffered LDS-DMA tiles (see swz_f)
   __shared__ __attribute__((aligned(1024))) bf16 Vs[2][64 * 64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
@@ -200,7 +190,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
   const SoftCap sc_ = make_softcap(p.softcap);
   const int kve_min = wave_min_i(kve);
 
-  // the Q fragments / kv_end loads above are compiler-visible VMEM: retire them before the counted DMA waits
+  // The Q fragments / kv_end loads above are compiler-visible VMEM.  They must be CONSUMED (not just waited for in asm) before the
+  // loop: otherwise hipcc's scoreboard still carries them into the loop header and it emits its own `s_waitcnt vmcnt(3..0)` in front
+  // of the first S MFMAs of every tile - which also drains the LDS-DMA of tile j + 1 issued a few instructions earlier (the prefetch
+  // then overlaps nothing).  The empty asm reads the registers, so the compiler's wait lands here, once.
+  asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   tile_dma(kb_, p.ld_k, 0, nkv, Ks[0]);
   tile_dma(vb, p.ld_v, 0, nkv, Vs[0]);
@@ -235,19 +229,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
     for (int kb = 0; kb < 2; kb++) {
       softcap16(s[kb], sc_);
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        f32x2 e = {__builtin_amdgcn_exp2f(s[kb][2 * i]), __builtin_amdgcn_exp2f(s[kb][2 * i + 1])};
-        if (need_mask) {
+      for (int r = 0; r < 16; r++) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
+      if (need_mask) {                                          // ONE scalar branch per 32-key block (boundary tiles only)
+        const int key0 = j * 64 + kb * 32 + 4 * hi;
 #pragma unroll
-          for (int t = 0; t < 2; t++) {
-            const int r = 2 * i + t;
-            const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            e[t] = key < kve ? e[t] : 0.f;
-          }
-        }
-        s[kb][2 * i] = e[0]; s[kb][2 * i + 1] = e[1];
-        lsum2 += e;
+        for (int r = 0; r < 16; r++) s[kb][r] = key0 + (r & 3) + 8 * (r >> 2) < kve ? s[kb][r] : 0.f;
       }
+#pragma unroll
+      for (int i = 0; i < 8; i++) { const f32x2 e = {s[kb][2 * i], s[kb][2 * i + 1]}; lsum2 += e; }
     }
 #ifdef TFX_ATTN_TIMING
     asm volatile("" : "+v"(s[0]), "+v"(s[1]));
@@ -291,6 +280,197 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(tfx_attn_args p) {
         *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
       }
     if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = __log2f(lsum) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, software-pipelined form (the product kernel; TFX_ATTN_PIPE=0 selects the plain loop above)
+// ------------------------------------------------------------------------------------------------
+// Measured on gfx950 (tools/valu_probe.hip, tools/overlap_probe.hip): a wave64 v_fma_f32 issues in 2.7 clocks, the PACKED f32 forms in 6.5
+// (slower than two scalar ops), v_exp_f32 in 8.5, v_cvt_pk_bf16_f32 in 4.6 - and one v_mfma_f32_32x32x16_bf16 occupies the SIMD's matrix
+// pipe for 32 clocks during which the SAME wave can issue ~10 independent vector instructions for free (MFMA + 8 v_fma: 44 clocks vs
+// 32 + 42 serial).  The soft-capped softmax costs ~24 VALU clocks per score against 16 MFMA clocks per score (S and P.V), so the kernel is
+// VALU-bound and the matrix work only hides if it is issued INSIDE the vector stream.  The plain loop cannot do that: S(j) -> softmax(j) ->
+// P.V(j) is one dependency chain per tile.  Here the chain is cut in 32-key UNITS u = 0, 1, ...  and phase u runs
+//       vector: soft-cap + exp2 + row sums + bf16 packing of unit u            (16 scores per lane, 8 chunks of 2)
+//       matrix: P.V of unit u - 1 (4 MFMAs)  and  S of unit u + 1 (4 MFMAs)    (one MFMA issued after each chunk)
+// - three independent streams, so every MFMA has ~40 clocks of vector work to hide behind.  K / V tiles arrive by LDS-DMA into rings of
+// three 64-key tiles (K two tiles ahead, V one), ONE barrier per tile.  A wave stops at its own last unit (causal diagonal), so the
+// fully masked units of the upper waves of a block are never computed.
+// accumulate IN PLACE: the asm form ties destination and C operand (the builtin may pick a second register set and copy).  Its only readers are further MFMAs on the same accumulator (no wait
+// states needed for an accumulate chain) and the epilogue, which pads the MFMA -> VALU hazard itself (cdna_hip_programming.md 5.7).
+#define MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc), "+v"(a), "+v"(b))
+// s_cur: this unit's scores, already soft-capped into the log2 domain (and -inf where masked) by the caller: the matrix work of the phase
+// hides under exp2 / row sums / packing, ONE straight-line variant (branchy code around accumulators that live across it makes hipcc
+// shuffle them between register sets)
+TFX_DEV void fwd_phase(const f32x16& s_cur, f32x16& s_nxt, u32x4 (&p_prev)[2], u32x4 (&p_cur)[2], f32x16 (&o)[2], const bf16x8 (&qf)[4],
+                       const bf16* Kt_nxt, int kb_nxt, const bf16* Vt_prev, int kb_prev, float (&lsum)[2]) {
+  const int hi = (threadIdx.x >> 5) & 1;
+  // operand of MFMA m: 0..3 = K fragments of unit u + 1 (ks = m), 4..7 = V^T fragments of unit u - 1 (tt = (m - 4) >> 1, db = m & 1).
+  // S first: its result is read by vector code at the start of the next phase - the four P.V MFMAs behind it are the hazard distance
+  // (all MFMAs of the phase are asm volatile: program order is issue order, and hipcc pads nothing for asm results)
+  bf16x8 frag[2];
+  auto fetch = [&](int m) -> bf16x8 {
+    if (m < 4) return dma_rowfrag(Kt_nxt, kb_nxt * 32, m);
+    const int ra = kb_prev * 32 + 16 * ((m - 4) >> 1) + 4 * hi;
+    return dma_tr8(Vt_prev, ra, ra + 8, (m & 1) * 32);
+  };
+  frag[0] = fetch(0);
+#pragma unroll
+  for (int ch = 0; ch < 8; ch++) {
+    if (ch < 7) frag[(ch + 1) & 1] = fetch(ch + 1);               // LDS reads of the NEXT MFMA's operand fly under this chunk's vector work
+    float e0 = __builtin_amdgcn_exp2f(s_cur[2 * ch]), e1 = __builtin_amdgcn_exp2f(s_cur[2 * ch + 1]);
+    // the chunk's exponentials are operands of the MFMA statement: they are computed BEFORE it, their consumers (row sums, packing) after
+    // The A / B operands are in-out ("+v") although the MFMA only reads them: hipcc would otherwise hand a dead operand register to the very
+    // next vector instruction, and a VALU write in the first cycles after the issue corrupts the operand the MFMA is still reading (seen:
+    // wrong O columns, timing dependent).  Kept "live", they are next written by the LDS reads / packing two chunks later.
+    if (ch == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, 0" : "=&v"(s_nxt), "+v"(e0), "+v"(e1), "+v"(frag[0]) : "v"(qf[0]));
+    else if (ch < 4) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0" : "+v"(s_nxt), "+v"(e0), "+v"(e1), "+v"(frag[ch & 1]) : "v"(qf[ch]));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0" : "+v"(o[ch & 1]), "+v"(e0), "+v"(e1), "+v"(frag[ch & 1]), "+v"(p_prev[(ch - 4) >> 1]));
+    lsum[0] += e0; lsum[1] += e1;
+    bf16x2 pk2; pk2[0] = f2bf(e0); pk2[1] = f2bf(e1);
+    uint32_t pk = __builtin_bit_cast(uint32_t, pk2);
+    asm volatile("" : "+v"(lsum[0]), "+v"(lsum[1]), "+v"(pk));      // ... and before the next chunk's MFMA (volatile statements keep their order)
+    p_cur[ch >> 2][ch & 3] = pk;
+    __builtin_amdgcn_sched_barrier(0);                              // keep one MFMA per chunk: the matrix pipe stays busy under the vector stream
+  }
+}
+
+// soft-cap of the unit (polynomial degree by the wave's largest |score|, see softcap16), mask where the unit crosses kv_end, then the phase
+TFX_DEV void fwd_phase_any(f32x16& s_cur, f32x16& s_nxt, u32x4 (&p_prev)[2], u32x4 (&p_cur)[2], f32x16 (&o)[2], const bf16x8 (&qf)[4],
+                           const bf16* Kt_nxt, int kb_nxt, const bf16* Vt_prev, int kb_prev, float (&lsum)[2], const SoftCap& c, int key0, int kve,
+                           bool mask, unsigned long long* ts = nullptr) {
+#ifdef TFX_ATTN_TIMING
+  unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+  softcap16(s_cur, c);
+  if (mask) {                                                       // boundary units only (one or two per wave): exp2(-inf) = 0
+#pragma unroll
+    for (int r = 0; r < 16; r++) s_cur[r] = key0 + (r & 3) + 8 * (r >> 2) < kve ? s_cur[r] : -__builtin_inff();
+  }
+#ifdef TFX_ATTN_TIMING
+  asm volatile("" : "+v"(s_cur));
+  unsigned long long t1 = __builtin_readcyclecounter();
+#endif
+  fwd_phase(s_cur, s_nxt, p_prev, p_cur, o, qf, Kt_nxt, kb_nxt, Vt_prev, kb_prev, lsum);
+#ifdef TFX_ATTN_TIMING
+  asm volatile("" : "+v"(s_nxt), "+v"(o[0]), "+v"(o[1]));
+  ts[2] += t1 - t0; ts[3] += __builtin_readcyclecounter() - t1;
+#endif
+}
+
+TFX_DEV void fwd_drain(u32x4 (&p_prev)[2], f32x16 (&o)[2], const bf16* Vt_prev, int kb_prev) {
+  const int hi = (threadIdx.x >> 5) & 1;
+  bf16x8 vt[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) { const int ra = kb_prev * 32 + 16 * (m >> 1) + 4 * hi; vt[m] = dma_tr8(Vt_prev, ra, ra + 8, (m & 1) * 32); }
+#pragma unroll
+  for (int m = 0; m < 4; m++) MFMA_ACC(o[m & 1], vt[m], p_prev[m >> 1]);
+  asm volatile("s_nop 7" : "+v"(vt[0]), "+v"(vt[1]), "+v"(vt[2]), "+v"(vt[3]), "+v"(p_prev[0]), "+v"(p_prev[1]));     // operands stay untouched while the last MFMA reads them
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) {
+  __shared__ __attribute__((aligned(1024))) bf16 Ks[3][64 * 64];      // rings of LDS-DMA tiles (see swz_f): K(j), K(j+1), K(j+2) / V(j-1), V(j), V(j+1)
+  __shared__ __attribute__((aligned(1024))) bf16 Vs[3][64 * 64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
+  const int n = p.n;
+  const BlockId bi = decode_block(p.order, (n + 127) / 128, true);
+  const int h = bi.h, b = bi.b, q0 = bi.tile * 128;
+  const int nkv = p.n_kv > 0 ? p.n_kv : n;
+  const size_t tok0 = (size_t)b * n, tokk = (size_t)b * nkv;
+  const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
+  const bf16* kb_ = p.k + tokk * p.ld_k + h * DH;
+  const bf16* vb = p.v + tokk * p.ld_v + h * DH;
+  const int qrow = q0 + w * 32 + (l & 31);
+  const int qc = min(qrow, n - 1);
+  const int kve = p.kv_end[tok0 + qc];
+  const int kv_limit = p.kv_end[tok0 + min(q0 + 127, n - 1)];     // kv_end is non-decreasing in the query index
+  const int nt = (kv_limit + 63) / 64;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks);
+  const SoftCap sc_ = make_softcap(p.softcap);
+  const int kve_min = wave_min_i(kve);
+  asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));     // consume the compiler-visible loads before the counted DMA waits
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tile_dma(kb_, p.ld_k, 0, nkv, Ks[0]);
+  tile_dma(vb, p.ld_v, 0, nkv, Vs[0]);
+  if (nt > 1) tile_dma(kb_, p.ld_k, 64, nkv, Ks[1]);
+
+  f32x16 o[2], sA, sB;
+  u32x4 pA[2], pB[2];                                             // P^T of a unit as MFMA operands: 4 packed bf16 pairs per 16 keys
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[i][r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; e++) { pA[i][e] = 0u; pB[i][e] = 0u; }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) { sA[r] = 0.f; sB[r] = 0.f; }
+  float lsum[2] = {0.f, 0.f};
+  int kslot = 0, vslot = 0;                                       // ring slots of K(j) / V(j)
+#ifdef TFX_ATTN_TIMING
+  unsigned long long tsec[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define AT_MARK(i) { const unsigned long long tn = __builtin_readcyclecounter(); tsec[i] += tn - tprev; tprev = tn; }
+#define TS_ARG , tsec
+#else
+#define AT_MARK(i)
+#define TS_ARG
+#endif
+  for (int j = 0; j < nt; j++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of K(j + 1), V(j) have landed
+    __builtin_amdgcn_s_barrier();                                 // ... everyone's have, and everyone is done with K(j - 1), V(j - 2)
+    AT_MARK(0)
+    const int kslot1 = kslot == 2 ? 0 : kslot + 1, kslot2 = kslot1 == 2 ? 0 : kslot1 + 1;
+    const int vslot1 = vslot == 2 ? 0 : vslot + 1, vprev = vslot == 0 ? 2 : vslot - 1;
+    if (j + 2 < nt) tile_dma(kb_, p.ld_k, (j + 2) * 64, nkv, Ks[kslot2]);
+    if (j + 1 < nt) tile_dma(vb, p.ld_v, (j + 1) * 64, nkv, Vs[vslot1]);
+    AT_MARK(1)
+    if (j == 0) {                                                 // pipeline fill: S of unit 0
+      sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dma_rowfrag(Ks[0], 0, 0), qf[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ks++) sA = MFMA(dma_rowfrag(Ks[0], 0, ks), qf[ks], sA);
+    }
+    // even unit u = 2j: softmax of sA -> pA; P.V of unit 2j - 1 (pB, second half of V(j - 1); p = 0 for j = 0); S of unit 2j + 1 -> sB.
+    // Units past a wave's last visible key run fully masked (p = 0): no per-wave control flow around the accumulators.
+    int u = 2 * j;
+    fwd_phase_any(sA, sB, pB, pA, o, qf, Ks[kslot], 1, j == 0 ? Vs[vslot] : Vs[vprev], 1, lsum, sc_, u * 32 + 4 * hi, kve, (u + 1) * 32 > kve_min TS_ARG);
+    // odd unit u = 2j + 1: softmax of sB -> pB; P.V of unit 2j (pA, first half of V(j)); S of unit 2j + 2 -> sA (first half of K(j + 1))
+    u = 2 * j + 1;
+    fwd_phase_any(sB, sA, pA, pB, o, qf, Ks[kslot1], 0, Vs[vslot], 0, lsum, sc_, u * 32 + 4 * hi, kve, (u + 1) * 32 > kve_min TS_ARG);
+    kslot = kslot1; vslot = vslot1;
+#ifdef TFX_ATTN_TIMING
+    tprev = __builtin_readcyclecounter();
+#endif
+  }
+#ifdef TFX_ATTN_TIMING
+  if (l == 0) {
+    unsigned long long* ob = (unsigned long long*)p.dq + ((((size_t)b * p.h + h) * ((n + 127) / 128) + bi.tile) * 4 + w) * 5;
+    for (int i = 0; i < 4; i++) ob[i] = tsec[i];
+    ob[4] = nt;
+  }
+#endif
+#undef AT_MARK
+#undef TS_ARG
+  fwd_drain(pB, o, Vs[vslot == 0 ? 2 : vslot - 1], 1);                        // P.V of the very last unit
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(o[0]), "+v"(o[1]));              // the asm MFMAs' results are read by vector code from here on
+  float ls = lsum[0] + lsum[1];
+  ls += __shfl_xor(ls, 32, 64);
+  if (qrow < n) {
+    const float g = sigmoidf_(bf2f(p.gate[(tok0 + qrow) * p.ld_gate + h]));
+    const float sc = g * __builtin_amdgcn_rcpf(ls);
+    bf16* op = p.out + (tok0 + qrow) * p.ld_out + h * DH;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = f2bf(o[db][rg * 4 + e] * sc);
+        *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
+      }
+    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = __log2f(ls) * LN2;
   }
 }
 
@@ -378,23 +558,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
       }
       softcap16(s, sc_);                                             // s = s2 = cap*log2e*tanh(s/cap)
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const f32x2 a2 = {s[2 * i], s[2 * i + 1]};
-        const f32x2 arg = a2 - bc2(lse2);
-        f32x2 pr = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-        if (need_mask) {
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            const int r = 2 * i + t;
-            const int key = j * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            pr[t] = key < kve ? pr[t] : 0.f;
-          }
-        }
-        const f32x2 dth = pk_fma(a2 * a2, bc2(-sc_.g2), bc2(1.f));  // 1 - tanh^2
-        const f32x2 dpp = {dp[2 * i], dp[2 * i + 1]};
-        const f32x2 ds = pr * (dpp - bc2(dlt)) * dth;                // dS_raw^T
-        s[2 * i] = ds[0]; s[2 * i + 1] = ds[1];
+      for (int r = 0; r < 16; r++) {
+        const float dth = fmaf(s[r] * s[r], -sc_.g2, 1.f);           // 1 - tanh^2
+        dp[r] = (dp[r] - dlt) * dth;
+        s[r] = __builtin_amdgcn_exp2f(s[r] - lse2);                   // P^T
       }
+      if (need_mask) {                                               // one scalar branch per 32-key block (boundary tiles only)
+        const int key0 = j * 64 + kb * 32 + 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = key0 + (r & 3) + 8 * (r >> 2) < kve ? s[r] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] *= dp[r];                     // dS_raw^T
 #pragma unroll
       for (int tt = 0; tt < 2; tt++) {
         const bf16x8 dsf = pack8(s, tt);
@@ -415,6 +590,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
         for (int e = 0; e < 4; e++) v[e] = f2bf(dq[db][rg * 4 + e]);
         *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
       }
+  }
+}
+
+// dK/dV kernel: from s = soft-capped scores (log2 domain) and dp = dP of one 32-query x 32-key block: pr = P (masked when MASK), s <- dS_raw.
+// Streams register pairs (the kernel sits at the 256-VGPR limit); the mask test is hoisted into the template parameter so that interior
+// tiles carry no compare / select at all.
+template <bool MASK>
+TFX_DEV void dkv_scores(f32x16& s, const f32x16& dp, f32x16& pr, const float* s_lse, const float* s_dlt, const int* s_kve, int ql0, int krow, float g2) {
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    const int ql = ql0 + 8 * rg;
+    const f32x4 ls4 = *(const f32x4*)(s_lse + ql), dl4 = *(const f32x4*)(s_dlt + ql);
+    const int* kv4 = s_kve + ql;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      const int r = rg * 4 + e;
+      const f32x2 a2 = {s[r], s[r + 1]};
+      const f32x2 l2 = {ls4[e], ls4[e + 1]}, d2 = {dl4[e], dl4[e + 1]};
+      const f32x2 arg = a2 - l2;
+      f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+      if (MASK) {
+        pv[0] = krow < kv4[e] ? pv[0] : 0.f;
+        pv[1] = krow < kv4[e + 1] ? pv[1] : 0.f;
+      }
+      const f32x2 dth = pk_fma(a2 * a2, bc2(-g2), bc2(1.f));           // 1 - tanh^2
+      const f32x2 dpp = {dp[r], dp[r + 1]};
+      const f32x2 ds = pv * (dpp - d2) * dth;                          // dS_raw[q][key]
+      pr[r] = pv[0]; pr[r + 1] = pv[1];
+      s[r] = ds[0]; s[r + 1] = ds[1];
+    }
   }
 }
 
@@ -453,20 +658,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   const int kw_last = k0 + w * 32 + 31;                    // last key of this wave's 32-key block
 
   TileRegs qr, dr;
-  tile_gload(qr, qb, p.ld_q, qt0 * 64, n);
-  tile_gload(dr, dob, p.ld_do, qt0 * 64, n);
-  for (int jt = qt0; jt < qt1; jt++) {
-    __syncthreads();
-    tile_sstore(qr, Qs); tile_sstore(dr, Ds);
+  // per-query statistics of the tile (lse, delta, kv_end) travel with it: fetched one tile AHEAD into registers of the first wave, like the
+  // Q / dO tiles - a load issued between the two barriers would put a global round trip on every tile's critical path for all four waves
+  float st_l = 0.f, st_d = 0.f; int st_k = 0;
+  auto stats_gload = [&](int jt) {
     if (threadIdx.x < 64) {
       const int qi = jt * 64 + threadIdx.x;
       const int qcl = min(qi, n - 1);
-      s_lse[threadIdx.x] = lseb[qcl] * LOG2E;
-      s_dlt[threadIdx.x] = dltb[qcl];
-      s_kve[threadIdx.x] = qi < n ? p.kv_end[tok0 + qcl] : 0;       // rows past the end see nothing
+      st_l = lseb[qcl]; st_d = dltb[qcl];
+      st_k = qi < n ? p.kv_end[tok0 + qcl] : 0;                     // rows past the end see nothing
     }
+  };
+  tile_gload(qr, qb, p.ld_q, qt0 * 64, n);
+  tile_gload(dr, dob, p.ld_do, qt0 * 64, n);
+  stats_gload(qt0);
+  for (int jt = qt0; jt < qt1; jt++) {
     __syncthreads();
-    if (jt + 1 < qt1) { tile_gload(qr, qb, p.ld_q, (jt + 1) * 64, n); tile_gload(dr, dob, p.ld_do, (jt + 1) * 64, n); }
+    tile_sstore(qr, Qs); tile_sstore(dr, Ds);
+    if (threadIdx.x < 64) { s_lse[threadIdx.x] = st_l * LOG2E; s_dlt[threadIdx.x] = st_d; s_kve[threadIdx.x] = st_k; }
+    __syncthreads();
+    if (jt + 1 < qt1) { tile_gload(qr, qb, p.ld_q, (jt + 1) * 64, n); tile_gload(dr, dob, p.ld_do, (jt + 1) * 64, n); stats_gload(jt + 1); }
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; qb2++) {
       f32x16 s, dp;                                                // (no spare registers here for a shared zero accumulator)
@@ -480,31 +691,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
       softcap16(s, sc_);                                             // s = s2 = cap*log2e*tanh(s/cap)
       // kv_end is non-decreasing over the real queries: the 32-query block is fully visible to this wave's keys
       // iff its first query sees the wave's last key and the block holds no rows past the end (wave-uniform)
-      const bool need_mask = kw_last >= s_kve[qb2 * 32] || jt * 64 + qb2 * 32 + 31 >= n;
+      const bool need_mask = __builtin_amdgcn_readfirstlane((int)(kw_last >= s_kve[qb2 * 32] || jt * 64 + qb2 * 32 + 31 >= n)) != 0;
       f32x16 pr;
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int ql = qb2 * 32 + 8 * rg + 4 * hi;
-        const f32x4 ls4 = *(const f32x4*)(s_lse + ql), dl4 = *(const f32x4*)(s_dlt + ql);
-        const int* kv4 = s_kve + ql;
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          const int r = rg * 4 + e;
-          const f32x2 a2 = {s[r], s[r + 1]};
-          const f32x2 l2 = {ls4[e], ls4[e + 1]}, d2 = {dl4[e], dl4[e + 1]};
-          const f32x2 arg = a2 - l2;
-          f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-          if (need_mask) {
-            pv[0] = krow < kv4[e] ? pv[0] : 0.f;
-            pv[1] = krow < kv4[e + 1] ? pv[1] : 0.f;
-          }
-          const f32x2 dth = pk_fma(a2 * a2, bc2(-sc_.g2), bc2(1.f));  // 1 - tanh^2
-          const f32x2 dpp = {dp[r], dp[r + 1]};
-          const f32x2 ds = pv * (dpp - d2) * dth;                      // dS_raw[q][key]
-          pr[r] = pv[0]; pr[r + 1] = pv[1];
-          s[r] = ds[0]; s[r + 1] = ds[1];
-        }
-      }
+      if (need_mask) dkv_scores<true>(s, dp, pr, s_lse, s_dlt, s_kve, qb2 * 32 + 4 * hi, krow, sc_.g2);      // one scalar branch per 32-query block
+      else dkv_scores<false>(s, dp, pr, s_lse, s_dlt, s_kve, qb2 * 32 + 4 * hi, krow, sc_.g2);
 #pragma unroll
       for (int tt = 0; tt < 2; tt++) {
         const bf16x8 pf = pack8(pr, tt), dsf = pack8(s, tt);
@@ -533,6 +723,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   }
 }
 
+static int attn_pipe() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TFX_ATTN_PIPE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
 static int attn_order() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("TFX_ATTN_ORDER"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -547,7 +742,8 @@ int attn_fwd(const tfx_attn_args& p, hipStream_t s) {
   if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out) & 7) return -2;
   if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;     // fixed-reference softmax needs exp2(cap*log2e) finite in fp32 sums
   tfx_attn_args q = p; q.order = attn_order();
-  hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(q), dim3(256), 0, s, q);
+  if (attn_pipe()) hipLaunchKernelGGL(attn_fwd_pipe_kernel, attn_grid(q), dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(q), dim3(256), 0, s, q);
   return (int)hipGetLastError();
 }
 int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
