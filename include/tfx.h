@@ -297,6 +297,13 @@ enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_
  * the data-gradient chain); for FORK / JOIN the event slot. */
 typedef struct { int32_t op; int32_t stream; const void* args; } tfx_launch;
 int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* failed_at);
+/* hipGraph form of a launch list whose arguments live in DEVICE memory between replays (decode plans: token ids, cache positions, visible
+ * lengths, rotary positions, times and latents are device arrays the host overwrites in place; every kernel argument is a fixed pointer or
+ * size).  `tfx_graph_create` captures the list on a library-owned stream (nothing executes) and instantiates it; `tfx_graph_launch`
+ * replays it on `stream`.  Kernel arguments are frozen at capture time: re-create the graph when an args struct of the list changes. */
+int tfx_graph_create(const tfx_launch* list, int32_t n, void** graph_out);
+int tfx_graph_launch(void* graph, void* stream);
+int tfx_graph_destroy(void* graph);
 /* on != 0: replay every item on the caller's stream (FORK / JOIN become no-ops) - same results, kernels one at a time (used to time a
  * kernel family without its side-stream neighbours); returns the previous setting */
 int tfx_set_single_stream(int32_t on);

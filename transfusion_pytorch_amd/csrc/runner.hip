@@ -117,6 +117,38 @@ extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int
   return 0;
 }
 
+// ---- hipGraph form of a launch list (decode plans) ------------------------------------------------------------------------------
+namespace {
+hipStream_t g_capture_stream = nullptr;
+}
+extern "C" int tfx_graph_create(const tfx_launch* list, int32_t n, void** graph_out) {
+  if (!graph_out || n <= 0 || !list) return -1;
+  *graph_out = nullptr;
+  if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) return -120;
+  // thread-local mode: other host threads (and other streams of this thread) keep working while the list is recorded
+  if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -121;
+  int32_t failed = -1;
+  const int rc = tfx_run_list(list, n, (void*)g_capture_stream, &failed);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(g_capture_stream, &graph);
+  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess || !graph) return -122;
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess || !exec) return -123;
+  *graph_out = (void*)exec;
+  return 0;
+}
+extern "C" int tfx_graph_launch(void* graph, void* stream) {
+  if (!graph) return -1;
+  return (int)hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)stream);
+}
+extern "C" int tfx_graph_destroy(void* graph) {
+  if (!graph) return 0;
+  return (int)hipGraphExecDestroy((hipGraphExec_t)graph);
+}
+
 extern "C" int tfx_set_single_stream(int32_t on) {
   const int prev = g_single_stream ? 1 : 0;
   g_single_stream = on != 0;
