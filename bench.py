@@ -97,6 +97,58 @@ def cpu_baseline(budget_s=25.0):
                       f'{"1 warm-up + " + str(steps) + " timed" if steps else "1 timed (cold)"} step(s) of fwd+bwd+clip+Adam'}
 
 
+def sample_prompts(n_each, dev, gen, dim_latent=384):
+    """n_each x the four README prompt kinds (README.md:162-167)"""
+    prompts = []
+    for _ in range(n_each):
+        prompts += [torch.randint(0, 256, (16,), device=dev, generator=gen), (0, torch.randn(4, dim_latent, device=dev, generator=gen)), None,
+                    [torch.randint(0, 256, (8,), device=dev, generator=gen), (0, torch.randn(6, dim_latent, device=dev, generator=gen))]]
+    return prompts
+
+
+def bench_sample(args):
+    """`--sample`: wall time of `sample_many` (dim1024/depth24, 64 mixed prompts, max_length 256, 16 ODE grid
+    points, cfg 3, greedy text, fixed initial noise; free-running and with a forced modality at the start), plus the reduced configuration
+    (dim512/depth8, 8 prompts, max_length 32) the CPU reference was timed on.  Prints ONE JSON line."""
+    from transfusion_pytorch_amd import Transfusion
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    out = {'metric': 'sample_many wall time, dim1024 d24, 64 mixed prompts, max_length 256, 16 ODE steps, cfg 3', 'unit': 's', 'n_gpus': 1,
+           'higher_is_better': False, 'dtype': 'bf16', 'data': 'synthetic', 'runs': {}}
+    for name, dim, depth, n_each, max_len in (('config5', 1024, 24, 16, 256), ('reduced', 512, 8, 2, 32)):
+        torch.manual_seed(0)
+        m = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=dim, depth=depth)).to(dev).eval()
+        g = torch.Generator(device=dev).manual_seed(1234)
+        prompts = sample_prompts(n_each, dev, g)
+        noise = torch.randn(16, 384, device=dev, generator=g)
+        for force in (None, 0):
+            kw = dict(max_length=max_len, modality_steps=16, cfg_scale=3., text_temperature=0., init_modality_noise=noise, fixed_modality_shape=(4,))
+            if force is not None:
+                kw['force_modality_at_start'] = force
+            m.sample_many(prompts, **{**kw, 'max_length': min(24, max_len)})                    # warm-up (plans, shadows)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            res = m.sample_many(prompts, **kw)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            ntok = sum(sum((p.numel() if not isinstance(p, tuple) else p[1].shape[0]) for p in s) for s in res)
+            nmod = sum(sum(isinstance(p, tuple) for p in s) for s in res)
+            out['runs'][f'{name}{"_forced" if force is not None else ""}'] = {
+                'seconds': dt, 'prompts': len(prompts), 'tokens_returned': ntok, 'modality_instances': nmod,
+                'config': f'dim={dim} depth={depth} max_length={max_len} modality_steps=16 cfg_scale=3 greedy force_modality_at_start={force}'}
+        del m
+        torch.cuda.empty_cache()
+    out['value'] = out['runs']['config5_forced']['seconds']
+    # the CPU side of SURVEY 8(d): the UNMODIFIED reference on the reduced configuration, timed in the build container (the reference tree
+    # is not on the GPU box) by oracle/time_reference_sampling.py and committed as a fixture - NOT a same-box measurement
+    fx = os.path.join(ROOT, 'tests', 'golden', 'reference_sampling_time.json')
+    if os.path.exists(fx):
+        out['cpu_reference'] = json.load(open(fx))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + '\n').encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -110,7 +162,10 @@ def main():
                     '(each bracketed launch costs two ~5 us event bubbles: 84 launches = ~0.9 ms on a step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-profile', action='store_true')
+    ap.add_argument('--sample', action='store_true', help='time sample_many (SURVEY 8(d) config 5) instead of the training step')
     args = ap.parse_args()
+    if args.sample:
+        return bench_sample(args)
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -106,6 +106,11 @@ typedef struct {
 int tfx_attn_fwd(const tfx_attn_args* a, void* stream);
 int tfx_attn_bwd(const tfx_attn_args* a, void* stream);   /* prep + dK/dV kernel + dQ kernel */
 
+/* decode step (reference T:2279-2349, T:2409-2419): the forward kernel addressed against a KV cache - `n` NEW query rows per
+ * sample, keys / values in a per-sample buffer of `n_kv` > 0 rows, kv_end[t] = visible cache length of query row t (own prefix + the block
+ * being decoded).  Fails with -10 when n_kv == 0. */
+int tfx_decode_attn(const tfx_attn_args* a, void* stream);
+
 /* ---- token-wise kernels ---------------------------------------------------------------------- */
 typedef struct {
   int32_t T, d;
@@ -232,6 +237,17 @@ int tfx_mse_fwd_bwd(const tfx_mse_args* a, void* stream);
 int tfx_output_to_flow(float* pred, const float* x, const float* eps, const int32_t* row_inst, const float* inst_time,
                        int32_t R, int32_t dl, float clean_eps, void* stream);
 
+/* ---- sampling (sample_many, T:2082-2583) ------------------------------------------------------ */
+/* sample_text_token (T:597-605) with min_p_filter (T:591-595), one row of fp32 logits [B, ld] (V valid columns) per sample, on the device:
+ * temperature == 0 -> argmax (first index on ties); else p = softmax(logits / temperature), tokens with p < min_p * max p are removed and
+ * the survivor whose cumulative mass (index order) crosses uniforms[row] * (surviving mass) is drawn.  Rows with active[row] == 0 are left
+ * untouched (active NULL = all rows).  out_ids: int32 [B]. */
+int tfx_sample_tokens(const float* logits, int32_t ld, int32_t B, int32_t V, float temperature, float min_p, const float* uniforms,
+                      const int32_t* active, int32_t* out_ids, void* stream);
+/* ODE state update of the fixed-grid midpoint solver (torchdiffeq semantics; T:2468-2525) fused with classifier-free
+ * guidance (T:2516-2521): f = f_uncond ? f_uncond + cfg_scale * (f_cond - f_uncond) : f_cond;  out = y + a * f   (fp32, n elements) */
+int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, float cfg_scale, float a, float* out, int64_t n, void* stream);
+
 /* ---- parameter plumbing ---------------------------------------------------------------------- */
 /* dst[r][c] (bf16, ld_dst, Rd rows, Cd cols) = src[rowmap ? rowmap[r] : r][c] or 0 when out of range / map < 0 */
 typedef struct { const float* src; int32_t ld_src, Rs, Cs; const int32_t* rowmap; tfx_bf16* dst; int32_t ld_dst, Rd, Cd; } tfx_cast_args;
@@ -284,7 +300,7 @@ enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_
        TFX_OP_ADALN_POST_FWD = 6, TFX_OP_ADALN_POST_BWD = 7, TFX_OP_QK_NORM_ROPE_FWD = 8, TFX_OP_QK_NORM_ROPE_BWD = 9, TFX_OP_ATTNRES_FWD = 10,
        TFX_OP_ATTNRES_BWD = 11, TFX_OP_RMSNORM_FWD = 12, TFX_OP_RMSNORM_BWD = 13, TFX_OP_EMBED_FWD = 14, TFX_OP_EMBED_BWD = 15,
        TFX_OP_NOISE_MIX = 16, TFX_OP_FOURIER = 17, TFX_OP_CE_FWD_BWD = 18, TFX_OP_MSE_FWD_BWD = 19, TFX_OP_CAST_ROWS = 20, TFX_OP_CAST_ROWS_T = 21,
-       TFX_OP_ADAM_STEP = 22,
+       TFX_OP_ADAM_STEP = 22, TFX_OP_DECODE_ATTN = 23,
        /* positional entry points (args = tfx_raw_args) */
        TFX_OP_OUTPUT_TO_FLOW = 32, TFX_OP_GATHER_F32 = 33, TFX_OP_ONEHOT_BF16 = 34, TFX_OP_SCATTER_ROWS_BF16 = 35, TFX_OP_F32_TO_BF16 = 36,
        TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41,

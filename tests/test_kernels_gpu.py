@@ -583,3 +583,53 @@ def test_adaln_bwd_segment_mode(T, d):
     names = ['pre dx', 'pre dtable', 'pre dgamma_text', 'post dy', 'post dtable', 'post dlayerscale']
     for nm, a_, b_ in zip(names, outs[1], outs[0]):
         check(f'segment-mode {nm}', a_, b_, 2e-3 if 'dx' in nm or 'dy' in nm else 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- decode-side kernels
+@pytest.mark.parametrize('B,V,ld', [(1, 390, 392), (7, 392, 392), (64, 390, 448), (5, 70, 72)])
+def test_sample_tokens_greedy_and_min_p(B, V, ld):
+    """tfx_sample_tokens vs the reference's sample_text_token / min_p_filter semantics (T:591-605) in torch: greedy = argmax (first index on
+    ties); with a temperature the draw is the inverse CDF of softmax(logits / T) restricted to p >= min_p * p_max at the given uniform."""
+    import ctypes
+    torch.manual_seed(4)
+    logits = torch.randn(B, ld, device=DEV) * 3.
+    logits[:, V:] = 1e9                                            # pad columns must never be chosen
+    if B > 1:
+        logits[1, 5] = logits[1, 9] = logits[1, :V].max() + 1.      # a tie: the first index wins
+    out = torch.full((B,), -7, dtype=torch.int32, device=DEV)
+    lib = capi.lib()
+    capi.check(lib.tfx_sample_tokens(logits.data_ptr(), ld, B, V, 0., 0.1, None, None, out.data_ptr(), ctypes.c_void_p(stream())), 'greedy')
+    assert torch.equal(out.long().cpu(), logits[:, :V].argmax(-1).cpu())
+    for T, min_p in ((1.0, 0.1), (0.7, 0.3), (2.0, 0.0)):
+        u = torch.rand(B, device=DEV)
+        capi.check(lib.tfx_sample_tokens(logits.data_ptr(), ld, B, V, T, min_p, u.data_ptr(), None, out.data_ptr(), ctypes.c_void_p(stream())), 'min-p')
+        p = (logits[:, :V].double() / T).softmax(-1)
+        keep = p >= min_p * p.amax(-1, keepdim=True)
+        q = torch.where(keep, p, torch.zeros_like(p))
+        cdf = q.cumsum(-1)
+        target = u.double()[:, None] * cdf[:, -1:]
+        ref = (cdf > target).float().argmax(-1)
+        got = out.long()
+        assert bool(keep.gather(1, got[:, None]).all()), 'a filtered token was drawn'
+        # fp32 vs fp64 prefix sums may disagree exactly at a CDF boundary: accept the neighbouring survivor there
+        bad = (got != ref).nonzero().flatten().tolist()
+        for r in bad:
+            lo, hi = sorted((int(got[r]), int(ref[r])))
+            assert float(q[r, lo + 1:hi].sum()) == 0. and abs(float(cdf[r, lo] - target[r])) < 1e-5 * float(cdf[r, -1]), (r, int(got[r]), int(ref[r]))
+    # active mask: untouched rows keep their value
+    act = torch.zeros(B, dtype=torch.int32, device=DEV); act[0] = 1
+    out.fill_(-7)
+    capi.check(lib.tfx_sample_tokens(logits.data_ptr(), ld, B, V, 0., 0.1, None, act.data_ptr(), out.data_ptr(), ctypes.c_void_p(stream())), 'active')
+    assert int(out[0]) == int(logits[0, :V].argmax()) and bool((out[1:] == -7).all())
+
+
+def test_ode_axpy_with_guidance():
+    import ctypes
+    torch.manual_seed(6)
+    y, fc, fu = (torch.randn(5, 7, 33, device=DEV) for _ in range(3))
+    out = torch.empty_like(y)
+    lib = capi.lib()
+    capi.check(lib.tfx_ode_axpy(y.data_ptr(), fc.data_ptr(), fu.data_ptr(), 3., 0.25, out.data_ptr(), y.numel(), ctypes.c_void_p(stream())), 'cfg')
+    assert torch.allclose(out, y + 0.25 * (fu + 3. * (fc - fu)), rtol=1e-6, atol=1e-6)
+    capi.check(lib.tfx_ode_axpy(y.data_ptr(), fc.data_ptr(), None, 3., -0.5, out.data_ptr(), y.numel(), ctypes.c_void_p(stream())), 'plain')
+    assert torch.allclose(out, y - 0.5 * fc, rtol=1e-6, atol=1e-6)

@@ -1,0 +1,85 @@
+// Decode-side kernels of `sample_many` (reference T:2082-2583): text-token sampling on the device and the ODE state update.
+// Latency-bound (a handful of rows per step): one wave per row, no host round trip for the arithmetic.
+#include "tfx_kernels.h"
+
+namespace tfx {
+
+// sample_text_token (T:597-605) + min_p_filter (T:591-595) for one row of fp32 logits per wave.
+//   temperature == 0 : argmax over the V logits (first index on ties, like torch.argmax)
+//   else             : p = softmax(logits / temperature); tokens with p < min_p * max(p) are removed; the survivor with
+//                      cumulative mass crossing u * (total surviving mass) is drawn (inverse CDF in index order - the same
+//                      distribution torch.multinomial samples from)
+__global__ __launch_bounds__(256) void sample_tokens_k(const float* logits, int ld, int B, int V, float temperature, float min_p, const float* uniforms,
+                                                       const int* active, int* out_ids) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  if (active && !active[row]) return;
+  const float* lg = logits + (size_t)row * ld;
+  // pass 1: maximum and its first index
+  float best = -__builtin_inff(); int bi = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) { const float v = lg[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (temperature == 0.f) { if (lane == 0) out_ids[row] = bi; return; }
+  // pass 2: surviving mass.  p_c / p_max = exp((l_c - l_max) / T): the min-p test needs no normaliser
+  const float it = 1.f / temperature;
+  float mass = 0.f;
+  for (int c = lane; c < V; c += 64) { const float r = __expf((lg[c] - best) * it); mass += r >= min_p ? r : 0.f; }
+  mass = wave_sum(mass);
+  // pass 3: inverse CDF in index order, 64 columns per step with a wave prefix sum
+  const float target = uniforms[row] * mass;
+  float run = 0.f; int pick = bi;                       // falls back to the mode if rounding leaves the target unreached
+  bool done = false;
+  for (int c0 = 0; c0 < V && !done; c0 += 64) {
+    const int c = c0 + lane;
+    float r = 0.f;
+    if (c < V) { r = __expf((lg[c] - best) * it); r = r >= min_p ? r : 0.f; }
+    float pre = r;                                      // inclusive prefix sum across the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(pre, o, 64); if (lane >= o) pre += t; }
+    const bool hit = r > 0.f && run + pre > target;
+    const unsigned long long m = __ballot(hit);
+    if (m) { pick = c0 + __builtin_ctzll(m); done = true; }
+    run += __shfl(pre, 63, 64);
+  }
+  if (lane == 0) out_ids[row] = pick;
+}
+
+// out = y + a * f with f = f_cond, or f_uncond + cfg * (f_cond - f_uncond) when f_uncond is given (classifier-free guidance, T:2516-2521)
+__global__ void ode_axpy_k(const float* y, const float* fc, const float* fu, float cfg, float a, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float f = fc[i];
+  if (fu) { const float u = fu[i]; f = u + cfg * (f - u); }
+  out[i] = y[i] + a * f;
+}
+
+}  // namespace tfx
+using namespace tfx;
+
+extern "C" {
+int tfx_sample_tokens(const float* logits, int32_t ld, int32_t B, int32_t V, float temperature, float min_p, const float* uniforms,
+                      const int32_t* active, int32_t* out_ids, void* s) {
+  if (B <= 0) return 0;
+  if (!logits || !out_ids || V <= 0 || ld < V) return -1;
+  if (temperature != 0.f && !uniforms) return -2;
+  if (temperature < 0.f) return -3;
+  hipLaunchKernelGGL(sample_tokens_k, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, B, V, temperature, min_p, uniforms, active, out_ids);
+  return (int)hipGetLastError();
+}
+int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, float cfg_scale, float a, float* out, int64_t n, void* s) {
+  if (n <= 0) return 0;
+  if (!y || !f_cond || !out) return -1;
+  hipLaunchKernelGGL(ode_axpy_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, f_cond, f_uncond, cfg_scale, a, out, (long long)n);
+  return (int)hipGetLastError();
+}
+/* the K13 name of SURVEY 8(b): attention of a short block of NEW query rows per sample against keys / values that live in a KV cache
+ * (`n_kv` > 0 rows per sample, per-row visible length in `kv_end`) - the forward kernel with its cache addressing */
+int tfx_decode_attn(const tfx_attn_args* a, void* s) {
+  if (!a || a->n_kv <= 0) return -10;
+  return tfx::attn_fwd(*a, (hipStream_t)s);
+}
+}

@@ -34,6 +34,7 @@ inline int run_one(const tfx_launch& l, void* s) {
     case TFX_OP_CAST_ROWS:        return tfx_cast_rows(static_cast<const tfx_cast_args*>(a), s);
     case TFX_OP_CAST_ROWS_T:      return tfx_cast_rows_t(static_cast<const tfx_cast_args*>(a), s);
     case TFX_OP_ADAM_STEP:        return tfx_adam_step(static_cast<const tfx_adam_args*>(a), s);
+    case TFX_OP_DECODE_ATTN:      return tfx_decode_attn(static_cast<const tfx_attn_args*>(a), s);
     // positional entry points: pointers p0.., integers i0.., floats f0 in declaration order
     case TFX_OP_OUTPUT_TO_FLOW:
       return tfx_output_to_flow((float*)r->p0, (const float*)r->p1, (const float*)r->p2, (const int32_t*)r->p3, (const float*)r->p4,

@@ -80,6 +80,33 @@ class LaunchList(list):
     (grad scales, segment counts, noise pointers) are seen by the next replay.  A MUTABLE argument list (e.g. the
     model_output_clean launch) is re-packed on every replay."""
     _image = None
+    _graphs = None
+
+    def graph(self, lo: int, hi: int):
+        """hipGraph of launches[lo:hi] (created on first use).  Only for lists whose kernel arguments are fixed pointers / sizes between
+        replays (decode plans): the arguments are frozen at capture time - `invalidate_graphs` after changing an args struct."""
+        if self._graphs is None:
+            self._graphs = {}
+        g = self._graphs.get((lo, hi))
+        if g is None:
+            arr = self.native()
+            out = ctypes.c_void_p()
+            rc = capi.lib().tfx_graph_create(ctypes.byref(arr, lo * ctypes.sizeof(_LAUNCH)), hi - lo, ctypes.byref(out))
+            if rc != 0 or not out.value:
+                raise capi.TfxError(f'tfx_graph_create failed with code {rc}')
+            g = self._graphs[(lo, hi)] = out.value
+        return g
+
+    def invalidate_graphs(self):
+        for g in (self._graphs or {}).values():
+            capi.lib().tfx_graph_destroy(ctypes.c_void_p(g))
+        self._graphs = None
+
+    def __del__(self):
+        try:
+            self.invalidate_graphs()
+        except Exception:
+            pass
 
     def native(self):
         if self._image is None or self._image[0] != len(self):
@@ -127,8 +154,10 @@ class Plan:
         e = lambda *s, dtype=BF16: torch.empty(*s, device=dev, dtype=dtype)
         I1 = max(I, 1)
         # ---- index arrays (filled per step)
-        self.tok_inst = z(T, dtype=torch.int32); self.kv_end = z(T, dtype=torch.int32); self.q_start = z(T, dtype=torch.int32)
-        self.rot_pos = z(T, dtype=torch.int32); self.text_ids = z(T, dtype=torch.int32); self.labels = z(T, dtype=torch.int32)
+        # per-token index arrays: rows of ONE int32 buffer, so that a decode step uploads its five host-built arrays
+        # (ids, cache positions, visible lengths, rotary positions, instance ids) with a single pinned, asynchronous copy
+        self.idx = z(7, max(T, 1), dtype=torch.int32)
+        self.text_ids, self.cache_pos, self.kv_end, self.rot_pos, self.tok_inst, self.q_start, self.labels = (self.idx[r, :T] if r != 1 else self.idx[r] for r in range(7))
         self.inst_time = z(I1, dtype=torch.float32)
         self.row_tok = {t: z(r, dtype=torch.int32) for t, r in R.items()}
         self.row_inst = {t: z(r, dtype=torch.int32) for t, r in R.items()}
@@ -159,7 +188,6 @@ class Plan:
         self.loaded_structure = None
         self._seg_args = []
         self.seg_start = z(max(T, 1), dtype=torch.int32); self.seg_len = z(max(T, 1), dtype=torch.int32)
-        self.cache_pos = z(max(T, 1), dtype=torch.int32)
         self._build_forward()
         if training:
             self.dH = e(D + 1, T, d)
@@ -268,7 +296,7 @@ class Plan:
                 ck = self.cache[i]                                   # [b, maxlen, 2*hd]
                 self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkr, i) + 2 * hd, 2 * hd, hd, ck.data_ptr(), 2 * hd, self.cache_pos.data_ptr(), T)
                 self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkvg, i) + 2 * 2 * hd, ldq, hd, ck.data_ptr() + 2 * hd, 2 * hd, self.cache_pos.data_ptr(), T)
-            self._k(L, 'tfx_attn_fwd', 'tfx_attn_args', **self._attn_kw(i))
+            self._k(L, 'tfx_attn_fwd' if self.cache is None else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
             self._nt(L, algo_k=md.hd, A=self.og[i], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[i], ldc=d)
             self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[i], out=self.xb[i], tok_inst=self.tok_inst,
                     table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
@@ -341,6 +369,8 @@ class Plan:
         return kw
 
     def set_rope_tables(self, cos_tab, sin_tab):
+        if self.cos_tab is not None and (self.cos_tab.data_ptr() != cos_tab.data_ptr() or self.sin_tab.data_ptr() != sin_tab.data_ptr()):
+            self.fwd.invalidate_graphs()                 # captured kernel arguments hold the old table pointers
         self.cos_tab, self.sin_tab = cos_tab, sin_tab
         for a in getattr(self, '_rope_args', []):
             a.cos_tab, a.sin_tab = cos_tab.data_ptr(), sin_tab.data_ptr()
@@ -486,9 +516,9 @@ class Plan:
 
     # ------------------------------------------------------------------------------------ run
     @staticmethod
-    def run(launches, stream, lo=0, hi=None):
+    def run(launches, stream, lo=0, hi=None, graph=False):
         """replay launches[lo:hi] on `stream`: one `tfx_run_list` call for a LaunchList (the product path), a per-launch loop for a
-        plain list (tools that bracket individual launches)."""
+        plain list (tools that bracket individual launches).  graph=True: replay the captured hipGraph of the range (decode plans)."""
         lib = capi.lib()
         sp = ctypes.c_void_p(stream)
         if isinstance(launches, LaunchList):
@@ -496,6 +526,11 @@ class Plan:
             lo = max(0, lo if lo >= 0 else n + lo)
             hi = n if hi is None else min(n, hi if hi >= 0 else n + hi)
             if hi <= lo:
+                return
+            if graph:
+                rc = lib.tfx_graph_launch(ctypes.c_void_p(launches.graph(lo, hi)), sp)
+                if rc != 0:
+                    raise capi.TfxError(f'tfx_graph_launch failed with code {rc}')
                 return
             arr = launches.native()
             failed = ctypes.c_int32(-1)

@@ -15,12 +15,14 @@ modality are those of the LAST conditional ODE evaluation (T:2531-2533); past mo
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
+from . import capi
 from .engine import Plan
 
 
@@ -41,17 +43,24 @@ class _State:                                   # _SamplingState, T:1270-1287 (t
     forced: tuple = (None, None)
 
 
-def _min_p_filter(logits, min_p):                # T:591-595
-    probs = logits.softmax(dim=-1)
-    limit = min_p * probs.amax(dim=-1, keepdim=True)
-    return torch.where(probs < limit, torch.full_like(logits, float('-inf')), logits)
+def _sample_text_token(logits, V, temperature, min_p, stream):
+    """sample_text_token (T:597-605) incl. min_p_filter (T:591-595) on the device: `tfx_sample_tokens` over the rows of a 2-d fp32
+    logits tensor (V valid columns).  Returns int32 ids on the device."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    B = logits.shape[0]
+    out = torch.empty(B, dtype=torch.int32, device=logits.device)
+    u = torch.rand(B, device=logits.device) if temperature != 0. else None
+    capi.check(capi.lib().tfx_sample_tokens(logits.data_ptr(), logits.stride(0), B, V, float(temperature), float(min_p), capi.ptr(u), None,
+                                            out.data_ptr(), ctypes.c_void_p(stream)), 'tfx_sample_tokens')
+    return out
 
 
-def _sample_text_token(logits, temperature, min_p):   # T:597-605
-    if temperature == 0.:
-        return logits.argmax(dim=-1)
-    logits = _min_p_filter(logits / temperature, min_p)
-    return torch.multinomial(logits.softmax(dim=-1), 1).squeeze(-1)
+def _ode_axpy(y, f_cond, f_uncond, cfg_scale, a, stream):
+    """out = y + a * (f_uncond + cfg_scale * (f_cond - f_uncond)) (or y + a * f_cond): one fused launch (tfx_ode_axpy)"""
+    out = torch.empty_like(y)
+    capi.check(capi.lib().tfx_ode_axpy(y.data_ptr(), f_cond.data_ptr(), capi.ptr(f_uncond), float(cfg_scale), float(a), out.data_ptr(), y.numel(),
+                                       ctypes.c_void_p(stream)), 'tfx_ode_axpy')
+    return out
 
 
 class Sampler:
@@ -205,7 +214,9 @@ class Sampler:
         logits0 = plan.logits.view(B, n0, md.vp)[..., :md.vocab]
         for st in states:
             self._maybe_transition(st, fixed_modality_shape)
-        first = _sample_text_token(torch.stack([logits0[i, s.cache_len - 1] for i, s in enumerate(states)]), text_temperature, text_min_p).tolist()
+        stream = m._stream()
+        last_rows = torch.tensor([i * n0 + s.cache_len - 1 for i, s in enumerate(states)], device=dev)
+        first = _sample_text_token(plan.logits.index_select(0, last_rows), md.vocab, text_temperature, text_min_p, stream).tolist()
         for st, tok in zip(states, first):
             if st.phase == 'text':
                 st.curr_seq.append(tok); st.last_token = tok; st.num_tokens += 1
@@ -217,7 +228,6 @@ class Sampler:
             if st.num_tokens > max_length:
                 st.phase = 'done'
 
-        stream = m._stream()
         while not all(s.phase == 'done' for s in states):
             # ------------------------------------------------ text phase
             while any(s.phase == 'text' for s in states):
@@ -229,8 +239,8 @@ class Sampler:
                     if st.phase == 'text':
                         ids[i], pos[i], kve[i], rot[i] = st.last_token, i * cache.shape[2] + st.cache_len, st.cache_len + 1, st.tokens_seen
                 self._load(p, ids=ids, pos=pos, kve=kve, rot=rot, tok_inst=np.full(B, -1, np.int32))
-                Plan.run(p.fwd, stream, 0, p.fwd_logits_end)
-                toks = _sample_text_token(p.logits[:, :md.vocab], text_temperature, text_min_p).tolist()
+                self._run(p, stream, 0, p.fwd_logits_end)
+                toks = _sample_text_token(p.logits, md.vocab, text_temperature, text_min_p, stream).tolist()
                 for st, tok in zip(states, toks):
                     if st.phase != 'text':
                         continue
@@ -266,19 +276,19 @@ class Sampler:
             if use_cfg:
                 self._load_modality(up, states, group, Lmax, ucache.shape[2], uncond=True)
 
-            def velocity(t, yy):
-                f = self._eval(cp, states, group, Lmax, t, yy, stream)
-                if not use_cfg:
-                    return f
-                fu = self._eval(up, states, group, Lmax, t, yy, stream)
-                return fu + cfg_scale * (f - fu)
+            type_mask = self._type_masks(states, group, Lmax)
+
+            def step(t, y_eval, y_base, a):
+                """y_base + a * velocity(t, y_eval): both model evaluations + guidance + the state update (tfx_ode_axpy)"""
+                f = self._eval(cp, type_mask, Lmax, t, y_eval, stream)
+                fu = self._eval(up, type_mask, Lmax, t, y_eval, stream) if use_cfg else None
+                return _ode_axpy(y_base, f, fu, cfg_scale, a, stream)
 
             ts = torch.linspace(0, 1, modality_steps)                  # fixed grid = the linspace itself (odeint midpoint)
             for k in range(modality_steps - 1):
-                t0, dt = ts[k], ts[k + 1] - ts[k]
-                f0 = velocity(float(t0), y)
-                y_mid = y + f0 * float(dt * 0.5)
-                y = y + float(dt) * velocity(float(t0 + dt * 0.5), y_mid)
+                t0, dt = float(ts[k]), float(ts[k + 1] - ts[k])
+                y_mid = step(t0, y, y, dt * 0.5)
+                y = step(t0 + dt * 0.5, y_mid, y, dt)
             for i in group:                                            # commit, T:2531-2556
                 st = states[i]; L, dl, ty = st.modality_length, md.dim_latents[st.curr_modality_id], st.curr_modality_id
                 st.cache_len += L
@@ -305,11 +315,16 @@ class Sampler:
             return out
         N = m.num_text_tokens
 
+        stream = m._stream()
+
         def pick(logits):
+            """T:2690-2698: temperature 0 -> argmax over ALL logits; else min-p filter over all logits, then the text-only mask, then the
+            draw.  The filter's threshold is relative to the global maximum, the draw runs over the first N columns."""
             if temperature == 0.:
-                return logits.argmax(dim=-1)
-            lg = _min_p_filter(logits / temperature, min_p)
-            lg = lg[:, :N]                                            # text_only_logits_mask
+                return _sample_text_token(logits, md.vocab, 0., min_p, stream).long()
+            lg = logits[:, :md.vocab] / temperature
+            probs = lg.softmax(dim=-1)
+            lg = torch.where(probs < min_p * probs.amax(dim=-1, keepdim=True), torch.full_like(lg, float('-inf')), lg)[:, :N]
             return torch.multinomial(lg.softmax(dim=-1), 1).squeeze(-1)
 
         plan, S = m._forward_plain([[row] for row in prompt], torch.ones(B, 1, device=dev), add_meta=False)
@@ -318,17 +333,16 @@ class Sampler:
         m._decode_plans = {}
         cache = self._alloc_cache(B, maxlen)
         self._fill_cache(cache, plan, B, n_pad)
-        tok = pick(plan.logits.view(B, n_pad, md.vp)[:, n0 - 1, :md.vocab].float())
+        tok = pick(plan.logits.view(B, n_pad, md.vp)[:, n0 - 1].contiguous())
         out[:, 0] = tok
-        stream = m._stream()
         p = self._decode_plan(('text', cache.data_ptr()), B, 1, cache, False)
         rows = np.arange(B, dtype=np.int32) * maxlen
         for step in range(1, num):
             L = n0 + step - 1                                          # keys already in the cache
             self._load(p, ids=tok.to(torch.int32).cpu().numpy(), pos=rows + L, kve=np.full(B, L + 1, np.int32), rot=np.full(B, L, np.int32),
                        tok_inst=np.full(B, -1, np.int32))
-            Plan.run(p.fwd, stream, 0, p.fwd_logits_end)
-            tok = pick(p.logits[:, :md.vocab].float())
+            self._run(p, stream, 0, p.fwd_logits_end)
+            tok = pick(p.logits)
             out[:, step] = tok
         return out
 
@@ -342,9 +356,20 @@ class Sampler:
         return new
 
     def _load(self, p, ids, pos, kve, rot, tok_inst):
-        dev = self.dev
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        p.text_ids.copy_(up(ids)); p.cache_pos.copy_(up(pos)); p.kv_end.copy_(up(kve)); p.rot_pos.copy_(up(rot)); p.tok_inst.copy_(up(tok_inst))
+        """the step's five index arrays go up in ONE pinned, asynchronous copy (rows 0..4 of Plan.idx): no host sync, no pageable staging"""
+        T = p.T
+        # pinned staging buffers are kept in a small ring (a pinned allocation per step costs more than the step's copy); a text step ends in
+        # a host sync, a modality phase issues at most four uploads before one
+        ring = self.__dict__.setdefault('_stage', {})
+        key = p.idx.shape[1]
+        if key not in ring:
+            ring[key] = [[torch.empty(5, key, dtype=torch.int32, pin_memory=True) for _ in range(8)], 0]
+        bufs, k = ring[key]
+        ring[key][1] = (k + 1) % len(bufs)
+        host = bufs[k]
+        hv = host.numpy()
+        hv[0, :T], hv[1, :T], hv[2, :T], hv[3, :T], hv[4, :T] = ids, pos, kve, rot, tok_inst
+        p.idx[:5].copy_(host, non_blocking=True)
         p.set_rope_tables(*self.m._rope_tables(int(rot.max()) + 1))
 
     def _load_modality(self, p, states, group, Lmax, maxlen, uncond):
@@ -373,16 +398,40 @@ class Sampler:
             p.row_inst[t].copy_(up(np.repeat(np.arange(B, dtype=np.int32), Lmax)))
             p.set_noise(t, None)
 
-    def _eval(self, p, states, group, Lmax, t, y, stream):
+    def _run(self, p, stream, lo, hi):
+        """replay a range of a decode plan: eagerly the first time (one-off kernel attribute setup happens outside any capture), as a
+        hipGraph afterwards - every kernel argument of a decode plan is a fixed pointer, the per-step values live in device arrays"""
+        seen = p.__dict__.setdefault('_ran', set())
+        if (lo, hi) not in seen:
+            seen.add((lo, hi))
+            Plan.run(p.fwd, stream, lo, hi)
+        else:
+            Plan.run(p.fwd, stream, lo, hi, graph=True)
+
+    def _type_masks(self, states, group, Lmax):
+        """per modality type: (B, Lmax, 1) 0/1 mask of the state rows that belong to a sample decoding that type"""
+        B = len(states)
+        masks = {}
+        for ty in range(self.m.num_modalities):
+            mk = np.zeros((B, Lmax, 1), np.float32)
+            for i in group:
+                if states[i].curr_modality_id == ty:
+                    mk[i, :states[i].modality_length] = 1.
+            masks[ty] = torch.from_numpy(mk).to(self.dev)
+        return masks
+
+    def _eval(self, p, type_mask, Lmax, t, y, stream):
         """one model evaluation of the joint ODE state y (B, Lmax, dmax) at time t -> predicted flow, same layout (T:2468-2521)."""
-        md, B = self.md, len(states)
+        md, B = self.md, y.shape[0]
         p.inst_time.fill_(t)
         for ty in range(self.m.num_modalities):
             p.lat[ty]['x'].copy_(y[:, :, :md.dim_latents[ty]].reshape(B * Lmax, md.dim_latents[ty]))
-        Plan.run(p.fwd, stream, 0, p.fwd_embed_end)
-        Plan.run(p.fwd, stream, p.fwd_logits_end, p.fwd_pred_end)
+        self._run(p, stream, 0, p.fwd_embed_end)
+        self._run(p, stream, p.fwd_logits_end, p.fwd_pred_end)
+        if self.m.num_modalities == 1 and md.dim_latents[0] == y.shape[2]:
+            return p.lat[0]['pred'].view(B, Lmax, -1) * type_mask[0]
         out = torch.zeros_like(y)
-        for i in group:
-            st = states[i]; L, ty = st.modality_length, st.curr_modality_id; dl = md.dim_latents[ty]
-            out[i, :L, :dl] = p.lat[ty]['pred'].view(B, Lmax, dl)[i, :L]
+        for ty in range(self.m.num_modalities):
+            dl = md.dim_latents[ty]
+            out[:, :, :dl] += p.lat[ty]['pred'].view(B, Lmax, dl) * type_mask[ty]
         return out

@@ -184,11 +184,13 @@ class Transfusion(nn.Module):
 
     def _plan(self, b, n, I, R, training):
         key = (b, n, I, tuple(sorted(R.items())), training)
-        if key not in self._plans:
-            if len(self._plans) > 8:
-                self._plans.clear()
-            self._plans[key] = Plan(self.store, b, n, I, R, training=training)
-        return self._plans[key]
+        plan = self._plans.pop(key, None)
+        if plan is None:
+            while len(self._plans) >= 8:                             # least recently used plan goes first (dict order = use order)
+                self._plans.pop(next(iter(self._plans)))
+            plan = Plan(self.store, b, n, I, R, training=training)
+        self._plans[key] = plan                                      # (re-)insert at the most recent position
+        return plan
 
     def _build_structure(self, modalities, return_loss, add_meta=True, pad_n=1):
         """full structure scan (host) + upload of every derived index array; cached per structure signature.
@@ -246,7 +248,16 @@ class Transfusion(nn.Module):
             S = self._struct_cache[key] = self._build_structure(samples, False, add_meta=add_meta, pad_n=pad_n)
         tm, b, n, I, R = S['tm'], S['b'], S['n'], S['I'], S['R']
         self.store.refresh_shadows(stream)
-        plan = self._plan(b, n, I, R, training=False)
+        # The prefill plans of a decode loop differ only in their instance / latent-row counts from one modality phase to the next: round
+        # both up (instances to 64, rows to 256) so that ONE plan per (batch, padded length) serves them all - a plan holds every activation
+        # of the forward, building one costs more than running it.  Padding rows scatter nowhere (row_tok = -1), padding instances are
+        # referenced by no token.
+        Ip = -(-I // 64) * 64 if I > 0 else 0
+        Rp = {t: -(-r // 256) * 256 for t, r in R.items()}
+        if Ip > 0:
+            for t in range(self.num_modalities):
+                Rp.setdefault(t, 256)
+        plan = self._plan(b, n, Ip, Rp, training=False)
         plan.set_rope_tables(*self._rope_tables(int(tm.rot_pos.max()) if tm.rot_pos.size else 0))
         plan.tok_inst.copy_(S['tok_inst'].view(-1)); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['q_start']); plan.rot_pos.copy_(S['rot_pos'])
         plan.loaded_structure = S
@@ -255,10 +266,14 @@ class Transfusion(nn.Module):
             text_full.view(-1).index_copy_(0, S['text_dest'], torch.cat(user_text).to(dev, torch.int32))
         plan.text_ids.copy_(text_full[:, :n].reshape(-1))
         if I > 0:
-            plan.inst_time.copy_(times.to(dev, torch.float32)[S['inst_b'], S['inst_m']])
-        for t in R:
-            plan.row_tok[t].copy_(S['row_tok'][t]); plan.row_inst[t].copy_(S['row_inst'][t])
-            plan.lat[t]['x'].copy_(torch.cat(latents[t]).to(dev, torch.float32))
+            plan.inst_time.zero_()
+            plan.inst_time[:I].copy_(times.to(dev, torch.float32)[S['inst_b'], S['inst_m']])
+        for t in Rp:
+            plan.row_tok[t].fill_(-1); plan.row_inst[t].zero_()
+            if t in R:
+                r = R[t]
+                plan.row_tok[t][:r].copy_(S['row_tok'][t]); plan.row_inst[t][:r].copy_(S['row_inst'][t])
+                plan.lat[t]['x'][:r].copy_(torch.cat(latents[t]).to(dev, torch.float32))
             plan.set_noise(t, None)
         Plan.run(plan.fwd, stream, 0, plan.fwd_logits_end)
         return plan, S
