@@ -39,6 +39,11 @@ def cast_tuple(t, length=1):
     return t if isinstance(t, tuple) else ((t,) * length)
 
 
+class KVCacheView(torch.Tensor):
+    """the kv-cache tensor `forward(..., return_kv_cache=True)` hands out: reference layout (layers, key/value, batch, heads, seq, dim_head),
+    bf16, a view of the native cache buffer it remembers (so that passing it back as `cache=` appends in place instead of copying)."""
+
+
 class Transformer:
     """config holder with the reference's constructor signature (T:1043-1059); the layers live in `Transfusion`."""
 
@@ -305,7 +310,13 @@ class Transfusion(nn.Module):
             return self.forward_modality(modalities, times=times, modality_type=modality_type, return_loss=return_loss,             # T:2989-2990
                                          velocity_consistency_ema_model=velocity_consistency_ema_model, return_loss_breakdown=return_breakdown)
         if cache is not None or decoding_text_or_modality is not None or return_kv_cache or return_hiddens:
-            raise NotImplementedError('kv-cache decoding / hiddens through forward() are not wired in the native path (use sample_many)')
+            if return_loss and not return_embed:
+                raise NotImplementedError('kv cache / hiddens are returned by the inference forward only (return_loss = False or return_embed = True), '
+                                          'as in the reference\'s own decode calls (T:1917-1924, T:1998-2006)')
+            if self.model_output_clean:
+                raise NotImplementedError('model_output_clean is not wired in the decode forward')
+            return self._forward_decode(modalities, times, cache, decode_length, decoding_text_or_modality, return_embed=return_embed,
+                                        return_kv_cache=return_kv_cache, return_hiddens=return_hiddens, return_times=return_times)
         if self.model_output_clean:
             raise NotImplementedError('model_output_clean in the interleaved forward converts in MODEL space against the projected noised tokens '
                                       '(MP:786-792): the difference of two O(1) bf16 activations scaled by 1/(1-t) - not representable at the '
@@ -322,11 +333,12 @@ class Transfusion(nn.Module):
 
         # ---- structure: one cheap signature pass; everything derived from it is cached ON THE DEVICE per signature
         sig, user_text, latents = fast_signature(modalities)
-        S = self._struct_cache.get((sig, return_loss))
+        add_meta = return_loss or not return_embed           # MP:330: `return_embed` (the decode-time call) packs WITHOUT [meta][shape][som] ... [eom]
+        S = self._struct_cache.get((sig, return_loss, add_meta))
         if S is None:
             if len(self._struct_cache) > 16:
                 self._struct_cache.clear()
-            S = self._struct_cache[(sig, return_loss)] = self._build_structure(modalities, return_loss)
+            S = self._struct_cache[(sig, return_loss, add_meta)] = self._build_structure(modalities, return_loss, add_meta=add_meta)
         P, tm, b, n, I, R = S['P'], S['tm'], S['b'], S['n'], S['I'], S['R']
 
         # ---- times (T:3075-3082)
@@ -378,9 +390,9 @@ class Transfusion(nn.Module):
         if not return_loss:
             end = plan.fwd_embed_end if return_embed else plan.fwd_logits_end
             Plan.run(plan.fwd, stream, 0, end)
-            if return_embed:
-                out = plan.embed.view(b, n, md.dim).float()
-                return (out, P) if not return_times else ((out, P), times)
+            if return_embed:                                                               # T:3275-3276: (embed, get_pred_flows)
+                out = (plan.embed.view(b, n, md.dim).float(), self._pred_flow_closures(P))
+                return out if not return_times else (out, times)
             logits = plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
             return (logits, times) if return_times else logits
 
@@ -454,6 +466,156 @@ class Transfusion(nn.Module):
         if return_times:
             ret = (*ret, times)
         return ret
+
+    # ------------------------------------------------------------------ decode contract of forward() (T:2926-2948, T:3186-3271)
+    def _pred_flow_closures(self, P):
+        """`get_pred_flows` of the reference (build_record_closures MP:764-805, model_to_pred_flow MP:160-175): per modality type, in scan
+        order, closures that cut an instance's rows out of an `embed` (b, n, d) tensor and reshape them to (*axial shape, d)."""
+        out = [[] for _ in range(self.num_modalities)]
+        d = self.md.dim
+        for gi in range(len(P.inst_b)):
+            bi, off, L, shape = int(P.inst_b[gi]), int(P.inst_off[gi]), int(P.inst_len[gi]), tuple(P.inst_shape[gi])
+
+            def inner(embed, need_splice=True, bi=bi, off=off, L=L, shape=shape):
+                e = embed[bi]
+                if need_splice:
+                    e = e[-L:] if e.shape[0] < off + L else e[off:off + L]      # MP:167-171: a decode-step embed holds the new block only
+                return e.reshape(*shape, d)
+            out[int(P.inst_type[gi])].append(inner)
+        return out
+
+    def model_to_latent(self, modality_type: int, embed_rows):
+        """`model_to_latent_projs[type]` (Linear(dim, dim_latent, bias=False), T:1479) applied to rows of the final embedding - the last
+        step of the reference's external decode loop (T:2013-2015) - through the native NT GEMM.  embed_rows: (..., dim) -> (..., dim_latent) fp32."""
+        self._require_gpu()
+        md, dev, stream = self.md, self.device, self._stream()
+        self.store.refresh_shadows(stream)
+        x = embed_rows.reshape(-1, md.dim).to(dev, torch.bfloat16).contiguous()
+        dl = md.dim_latents[modality_type]
+        out = torch.empty(x.shape[0], dl, device=dev, dtype=torch.float32)
+        a = capi.make_args('tfx_gemm_nt_args', A=x, lda=md.dim, B=self.store.shadows[f'outp{modality_type}'], ldb=md.dim, M=x.shape[0], N=dl, K=md.dim,
+                           epi=capi.ENUMS['TFX_EPI_F32'], C=out, ldc=dl)
+        capi.call('tfx_gemm_nt', a, stream)
+        return out.reshape(*embed_rows.shape[:-1], dl)
+
+    def _kv_public(self, buf, length):
+        """the public kv-cache object of forward() (T:3252: `(tensor, tokens_seen)`): a VIEW of the native cache buffer
+        [depth, b, capacity, k~ | v (heads x 64 each)] in the reference's layout (layers, key/value, batch, heads, seq, dim_head) (T:977, T:1264)."""
+        md = self.md
+        D, b, cap, _ = buf.shape
+        v = buf.view(D, b, cap, 2, md.heads, 64)[:, :, :length, :, :, :md.dim_head].permute(0, 3, 1, 4, 2, 5)
+        v = v.as_subclass(KVCacheView)
+        v._tfx_buf, v._tfx_len = buf, length
+        return v
+
+    def _kv_native(self, kv, extra):
+        """native buffer [depth, b, capacity >= length + extra, 2 * heads * 64] behind a public kv-cache tensor.  Our own views are
+        appended IN PLACE while they are the newest view of their buffer (linear decoding); anything else is copied."""
+        md, dev = self.md, self.device
+        buf, length = getattr(kv, '_tfx_buf', None), getattr(kv, '_tfx_len', None)
+        if buf is not None and getattr(buf, '_tfx_filled', None) == length and buf.shape[2] >= length + extra:
+            return buf, length
+        D, two, b, h, n, dh = kv.shape
+        assert (D, two, h, dh) == (md.depth, 2, md.heads, md.dim_head), 'kv cache tensor must be (layers, 2, batch, heads, seq, dim_head) (T:977)'
+        cap = -(-(n + extra + 64) // 64) * 64
+        new = torch.zeros(D, b, cap, 2 * md.hdk, device=dev, dtype=torch.bfloat16)
+        new.view(D, b, cap, 2, h, 64)[:, :, :n, :, :, :dh].copy_(kv.permute(0, 2, 4, 1, 3, 5))
+        return new, n
+
+    def _forward_decode(self, modalities, times, cache, decode_length, decoding, return_embed, return_kv_cache, return_hiddens, return_times):
+        """`forward(..., return_loss=False)` with the decode-time arguments of the reference (T:2926-2948):
+
+          cache=None          full forward over the samples (meta tokens only when logits are asked for, MP:330); `return_kv_cache` hands back
+                              `(kv, tokens_seen)` with tokens_seen = last rotary position + 1 (T:3215)
+          cache=(kv, seen)    only the LAST `decode_length` tokens of every sample run (T:1167-1176), against the cache: 'text' = one token at
+                              rotary position `seen` (T:3196, T:3210-3211); 'modality' = the trailing modality block, conditioned on its time,
+                              every token at rotary position `seen`, attending to the cache and to the whole block (T:3206-3208, T:2409-2419)
+        Returns logits (b, n | decode_length, V) - or `(embed, get_pred_flows)` with `return_embed` - followed by the requested extras in the
+        reference's order: kv cache, hiddens, times (maybe_pack_aux, T:3256-3271)."""
+        from .sampling import Sampler
+        md, dev, stream = self.md, self.device, self._stream()
+        assert isinstance(modalities, list), 'the decode forward takes the list-of-samples input'
+        b = len(modalities)
+        if cache is None:
+            if times is None:
+                nm = max((sum(1 for p in s if isinstance(p, tuple) or (torch.is_tensor(p) and p.is_floating_point())) for s in modalities), default=0)
+                times = self._default_times(np.array([sum(1 for p in s if isinstance(p, tuple) or (torch.is_tensor(p) and p.is_floating_point()))
+                                                     for s in modalities])) if nm else torch.empty((b, 0), device=dev)
+            plan, S = self._forward_plain(modalities, times, add_meta=not return_embed, pad_n=1)
+            n, P, tm = S['n'], S['P'], S['tm']
+            out = (plan.embed.view(b, n, md.dim).float(), self._pred_flow_closures(P)) if return_embed \
+                else plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
+            kv = None
+            if return_kv_cache:
+                buf = torch.zeros(md.depth, b, -(-(n + 64) // 64) * 64, 2 * md.hdk, device=dev, dtype=torch.bfloat16)
+                Sampler(self)._fill_cache(buf, plan, b, n)
+                buf._tfx_filled = n
+                kv = (self._kv_public(buf, n), int(tm.rot_pos.max()) + 1 if tm.rot_pos.size else 0)
+        else:
+            assert decode_length is not None, '`decode_length` must be passed in on forward for modality sampling. think of a cleaner way on some future date'   # T:3191
+            assert decoding in ('text', 'modality')                                                                                                          # T:3192
+            kv_in, seen = cache
+            L = 1 if decoding == 'text' else int(decode_length)
+            buf, n_cached = self._kv_native(kv_in, L)
+            assert buf.shape[1] == b, 'kv cache batch does not match the number of samples'
+            T = b * L
+            if not hasattr(self, '_decode_plans') or len(self._decode_plans) > 8:
+                self._decode_plans = {}
+            smp = Sampler(self)
+            is_mod = decoding == 'modality'
+            plan = smp._decode_plan(('fwd', decoding, L, buf.data_ptr()), b, L, buf, is_mod)
+            ids = np.zeros(T, np.int32); tok_inst = np.full(T, -1, np.int32)
+            pos = (np.arange(b, dtype=np.int32)[:, None] * buf.shape[2] + n_cached + np.arange(L, dtype=np.int32)[None, :]).reshape(-1)
+            if not is_mod:
+                for i, sample in enumerate(modalities):
+                    last = sample[-1]
+                    assert is_int_tensor(last) and last.numel() > 0, 'decoding text: every sample must end in a text token'
+                    ids[i] = int(last.reshape(-1)[-1])
+                kve = np.full(T, n_cached + 1, np.int32)
+                rot = np.full(T, seen, np.int32)
+            else:
+                tys = []
+                for i, sample in enumerate(modalities):
+                    last = sample[-1]
+                    last = (0, last) if torch.is_tensor(last) and last.is_floating_point() else last
+                    assert isinstance(last, tuple), 'decoding a modality: every sample must end in the modality being decoded'
+                    ty, x = int(last[0]), last[1]
+                    assert int(np.prod(x.shape[:-1])) == L, '`decode_length` must be the number of tokens of the trailing modality'
+                    tys.append((ty, x))
+                    tok_inst[i * L:(i + 1) * L] = i
+                kve = np.full(T, n_cached + L, np.int32)                   # own prefix + the whole (bidirectional) block
+                rot = np.full(T, seen, np.int32)                           # all tokens of the instance share one rotary position (T:3206)
+                row_tok = {t: np.full(T, -1, np.int32) for t in range(self.num_modalities)}
+                for i, (ty, x) in enumerate(tys):
+                    row_tok[ty][i * L:(i + 1) * L] = np.arange(i * L, (i + 1) * L)
+                    plan.lat[ty]['x'][i * L:(i + 1) * L].copy_(x.reshape(L, -1).to(dev, torch.float32))
+                up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                for t in row_tok:
+                    plan.row_tok[t].copy_(up(row_tok[t])); plan.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
+                    plan.row_inst[t].copy_(up(np.repeat(np.arange(b, dtype=np.int32), L)))
+                    plan.set_noise(t, None)
+                assert times is not None, 'decoding a modality needs `times` (the ODE step time in the last column, T:1990-1996)'
+                plan.inst_time.copy_(times.to(dev, torch.float32).reshape(b, -1)[:, -1])
+            smp._load(plan, ids=ids, pos=pos, kve=kve, rot=rot, tok_inst=tok_inst)
+            Plan.run(plan.fwd, stream, 0, plan.fwd_embed_end if return_embed else plan.fwd_logits_end)
+            n = L
+            if return_embed:
+                P = self._scan(modalities, add_sos_eos=False, add_meta=False)
+                out = (plan.embed.view(b, L, md.dim).float(), self._pred_flow_closures(P))
+            else:
+                out = plan.logits.view(b, L, md.vp)[..., :md.vocab].clone()
+            kv = None
+            buf._tfx_filled = n_cached + L
+            if return_kv_cache:
+                kv = (self._kv_public(buf, n_cached + L), seen + 1 if is_mod else seen + L)
+        ret = (out,)
+        if return_kv_cache:
+            ret = (*ret, kv)
+        if return_hiddens:                                                     # hiddens = [x_0 .. x_depth, final norm output] (T:1199, T:1244, T:1253)
+            ret = (*ret, [plan.hid[i].view(b, n, md.dim).float() for i in range(md.depth + 1)] + [plan.embed.view(b, n, md.dim).float()])
+        if return_times:
+            ret = (*ret, times)
+        return ret[0] if len(ret) == 1 else ret
 
     # ------------------------------------------------------------------ pure-text LM path (T:2586-2664)
     def forward_text(self, text, return_loss=True, return_embed=False, cache=None, return_hiddens=False, return_kv_cache=False):
@@ -652,6 +814,85 @@ class Transfusion(nn.Module):
                                 return_unprocessed_modalities=return_unprocessed_modalities, cfg_scale=cfg_scale)[0]
 
     sample = sample_one
+
+    @torch.no_grad()
+    def _sample_one_through_forward(self, prompt=None, max_length=2048, text_temperature=1., text_min_p=0.1, cache_kv=False, fixed_modality_shape=None,
+                                    force_modality_at_start=None, init_modality_noise=None, modality_steps=16, cfg_scale=3.):
+        """The reference's `sample_one` loop (T:1858-2075) written against the PUBLIC decode contract of `forward()` - one `forward(...)` per
+        text token (T:1917-1924) and per ODE evaluation (T:1998-2006, T:2021-2029), with (`cache_kv=True`) or without the kv cache it returns.
+        `sample_one` itself runs the batched KV-cached decoder; this loop exists so that the contract has a caller (the reference's
+        cache-equivalence tests go through it, tests/test_transfusion.py:578-662) - tests/test_decode_contract_gpu.py compares the three."""
+        from .sampling import Sampler, _sample_text_token, _ode_axpy
+        was_training = self.training
+        self.eval()
+        try:
+            smp = Sampler(self)
+            dev, stream = self.device, self._stream()
+            parts, forced_id, forced_shape = smp._prepare(prompt, force_modality_at_start)
+            sample = [(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in parts]
+            curr_length = 0                                                            # counts DECODED tokens only (T:1878)
+            num_past = sum(isinstance(p, tuple) for p in sample)
+            cache = None
+            st = type('S', (), {})()
+            st.curr_seq, st.forced = parts[-1] if isinstance(parts[-1], list) else [self.sos_id], (forced_id, forced_shape)
+            decoding_text = not smp._maybe_transition(st, fixed_modality_shape)
+            while curr_length <= max_length:
+                if decoding_text:
+                    # (the reference leaves `times` to the random default here, T:1917-1924; prompted / decoded modalities are conditioned at 1
+                    # everywhere else in its samplers - T:1996, T:2192 - and so here)
+                    logits, new_cache = self.forward([sample], return_loss=False, cache=cache, decode_length=1, decoding_text_or_modality='text',
+                                                     return_kv_cache=True, times=torch.ones(1, max(num_past, 1), device=dev))
+                    tok = int(_sample_text_token(logits[0, -1:].float().contiguous(), self.md.vocab, text_temperature, text_min_p, stream)[0])
+                    sample[-1] = torch.cat((sample[-1], torch.tensor([tok], device=dev)))
+                    st.curr_seq = sample[-1].tolist()
+                    curr_length += 1
+                    if cache_kv:
+                        cache = new_cache
+                    if tok == self.eos_id:
+                        break
+                    decoding_text = not smp._maybe_transition(st, fixed_modality_shape)
+                    continue
+                ty, shape = st.curr_modality_id, st.modality_shape
+                L, dl = st.modality_length, self.md.dim_latents[ty]
+                y = (init_modality_noise[:L, :dl].to(dev, torch.float32) if init_modality_noise is not None else torch.randn(L, dl, device=dev)).reshape(*shape, dl)
+                use_cfg = cfg_scale != 1.
+                uncond_hist = [torch.full_like(p, self.null_text_id) if not isinstance(p, tuple) else p for p in sample]
+                uncond_cache = None
+                if use_cfg and cache_kv:                                            # T:1976-1988
+                    _, uncond_cache = self.forward([uncond_hist], return_loss=False, return_kv_cache=True, return_embed=True,
+                                                   times=torch.ones(1, max(num_past, 1), device=dev), decoding_text_or_modality='modality')
+                new_cache = None
+
+                def flow(t, yy, hist, kv):
+                    tt = torch.ones(1, num_past + 1, device=dev); tt[0, -1] = t          # past modalities are conditioned at time 1 (T:1996)
+                    (emb, fns), kv_out = self.forward([[*hist, (ty, yy)]], times=tt, return_embed=True, cache=kv, decode_length=L, return_kv_cache=True,
+                                                      decoding_text_or_modality='modality')
+                    return self.model_to_latent(ty, fns[ty][-1](emb, need_splice=kv is None)), kv_out
+
+                def velocity(t, yy):
+                    nonlocal new_cache
+                    fc, new_cache = flow(t, yy, sample, cache if cache_kv else None)
+                    fu = flow(t, yy, uncond_hist, uncond_cache)[0] if use_cfg else None
+                    return fc, fu
+
+                ts = torch.linspace(0, 1, modality_steps)
+                for k in range(modality_steps - 1):                                  # torchdiffeq fixed-grid midpoint (SURVEY Appendix D)
+                    t0, dt = float(ts[k]), float(ts[k + 1] - ts[k])
+                    fc, fu = velocity(t0, y)
+                    y_mid = _ode_axpy(y.contiguous(), fc.contiguous(), fu, cfg_scale, dt * 0.5, stream)
+                    fc, fu = velocity(t0 + dt * 0.5, y_mid)
+                    y = _ode_axpy(y.contiguous(), fc.contiguous(), fu, cfg_scale, dt, stream)
+                sample.append((ty, y))
+                sample.append(torch.tensor([self.eom_ids[ty]], device=dev))
+                st.curr_seq = [self.eom_ids[ty]]
+                if cache_kv:
+                    cache = new_cache
+                curr_length += L
+                num_past += 1
+                decoding_text = True
+            return sample
+        finally:
+            self.train(was_training)
 
     def _clone_architecture(self):
         """a fresh model with this one's constructor arguments on the same device (weights NOT copied)"""
