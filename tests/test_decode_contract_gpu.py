@@ -109,3 +109,56 @@ def test_sample_one_through_forward_cached_equals_uncached_and_batched_decoder()
                 assert float(lg.topk(2).values.diff().abs()) < 0.05, (k, la, lo)
                 break
             assert len(la) == len(lo)
+
+
+def test_processing_strategy_registry_returns_the_reference_batch_type():
+    """seam (2) of SURVEY 8(b): `PROCESSING_STRATEGIES[name](modalities, times, model, *, need_axial_pos_emb, return_loss, return_embed)` ->
+    `ProcessedModalityBatch` (MP:138-147, MP:1050-1058).  Layout against the oracle's packer (pinned to the reference's known answers),
+    projected tokens / flows against fp32 torch on the same noise, every strategy name, both meta-token modes."""
+    from oracle.cases import build_case
+    from oracle.transfusion_oracle import pack_batch
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.modality_processing import PROCESSING_STRATEGIES, ProcessedModalityBatch
+    cfg, sd, batch, times, noise = build_case('small2')
+    m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents, transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert set(PROCESSING_STRATEGIES) == {'naive', 'grouped', 'flat', 'hybrid', 'auto'}
+    sos, eos = torch.tensor([cfg.sos_id]), torch.tensor([cfg.eos_id])
+    with_sos = [[sos, *s, eos] for s in batch]                                        # what forward() hands to the packer (T:3016-3023)
+    ref = pack_batch(cfg, batch, add_sos_eos=True)
+    for name in PROCESSING_STRATEGIES:
+        out = PROCESSING_STRATEGIES[name](with_sos, times, m, need_axial_pos_emb=False, return_loss=True, return_embed=False,
+                                          **({'noise': noise} if name == 'flat' else {}))
+        assert isinstance(out, ProcessedModalityBatch)
+        assert torch.equal(out.text.cpu(), ref.text) and out.modality_positions == ref.positions and out.total_tokens == ref.total_tokens
+        assert out.modality_tokens.shape == (*ref.text.shape, cfg.dim)
+        if name != 'flat':
+            continue
+        # fp32 reference of noising + projection on the injected noise (MP:654-656, T:1478)
+        inst_time = torch.stack([times[bi, mi] for bi, mi in zip(ref.inst_b, ref.inst_m)])
+        expect = torch.zeros(*ref.text.shape, cfg.dim)
+        for t, x in ref.latents.items():
+            tt = inst_time[ref.inst_of_row[t]][:, None]
+            xt = x * tt + noise[t] * (1. - tt)
+            proj = torch.nn.functional.linear(xt, sd[f'latent_to_model_projs.{t}.weight'], sd[f'latent_to_model_projs.{t}.bias'])
+            r = 0
+            for gi in ref.inst_of_row[t].unique_consecutive().tolist():
+                L = ref.inst_len[gi]
+                expect[ref.inst_b[gi], ref.inst_off[gi]:ref.inst_off[gi] + L] = proj[r:r + L]
+                r += L
+            got_flow = torch.cat([f.reshape(-1, f.shape[-1]) for f in out.flows[t]]).cpu()
+            assert torch.allclose(got_flow, x - noise[t], atol=1e-6)
+        assert rel(out.modality_tokens.cpu(), expect) < 8e-3
+        emb = torch.randn(*ref.text.shape, cfg.dim)
+        rows = out.get_pred_flows[0][0](emb)
+        gi = ref.inst_type.index(0)
+        assert torch.equal(rows.reshape(-1, cfg.dim), emb[ref.inst_b[gi], ref.inst_off[gi]:ref.inst_off[gi] + ref.inst_len[gi]])
+        # get_recon_loss as the reference writes it (MP:177-200): mse(noised, noise + pred_flow * (1 - t))
+        L0, t0 = ref.inst_len[gi], inst_time[gi]
+        x0, n0 = ref.latents[0][:L0], noise[0][:L0]
+        pf = torch.randn(L0, cfg.dim_latents[0])
+        want = torch.nn.functional.mse_loss(x0 * t0 + n0 * (1. - t0), n0 + pf * (1. - t0))
+        assert abs(float(out.get_recon_losses[0][0](pf.cuda())) - float(want)) < 1e-5
+    no_meta = PROCESSING_STRATEGIES['auto'](batch, times, m, return_loss=False, return_embed=True)       # decode-time layout: no meta tokens (MP:330)
+    assert no_meta.text.shape[1] < ref.text.shape[1] and not no_meta.flows

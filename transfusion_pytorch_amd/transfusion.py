@@ -28,7 +28,7 @@ class LossBreakdown(NamedTuple):            # T:105-110
     recon: list | None = None
 
 
-PROCESSING_STRATEGIES = ('naive', 'grouped', 'flat', 'hybrid', 'auto')    # MP:1050-1058: every name maps to the native packer
+from .modality_processing import PROCESSING_STRATEGIES, ProcessedModalityBatch, process_modalities      # noqa: E402  the registry seam (MP:1050-1058)
 
 
 def default_to_modality_shape_fn(maybe_shape_str):       # T:176-177
