@@ -195,6 +195,8 @@ def main():
                         transformer=dict(dim=args.dim, depth=args.depth)).to(dev).train()
     opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
     opt.always_sync = use_pg
+    if use_pg and os.environ.get('TFX_DP_OVERLAP', '1') != '0':
+        opt.overlap_grad_sync(groups=4)                       # the gradient all-reduce goes out in 4 layer groups DURING the backward
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     torch.manual_seed(7 + rank)                               # per-rank noise / times / CFG streams
     batch = canonical_batch(args.batch, dev, gen)
@@ -280,7 +282,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'Transfusion dim={args.dim} depth={args.depth} heads=8 dim_head=64 num_text_tokens=256 dim_latent=384; '
                                    f'per-GPU batch {args.batch} x seq 1024 (32 x [24 text tokens + (4,384) latent] per sample); '
-                                   'step = pack + fwd + bwd + grad all-reduce + clip(0.5) + Adam(3e-4)',
+                                   'step = pack + fwd + bwd + grad all-reduce (4 layer groups, overlapped with the backward) + clip(0.5) + Adam(3e-4)',
                        'global_batch': world * args.batch, 'seq_len': 1024, 'parallelism': f'dp{world}'},
             'loss': float(loss.detach()),
             'model_flops_utilization': value / world * fcore / (PEAK_BF16_TFLOPS * 1e12),

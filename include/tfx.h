@@ -266,6 +266,9 @@ int tfx_onehot_bf16(const int32_t* ids, const int32_t* tok_inst, tfx_bf16* out, 
 /* dst[rowmap[r]][0:cols] = src[r][0:cols] for rowmap[r] >= 0   (KV-cache append; bf16, cols % 8 == 0) */
 int tfx_scatter_rows_bf16(const tfx_bf16* src, int32_t ld_src, int32_t cols, tfx_bf16* dst, int32_t ld_dst, const int32_t* rowmap, int32_t R, void* stream);
 int tfx_f32_to_bf16(const float* src, tfx_bf16* dst, int64_t n, void* stream);
+/* dst[r][c] (bf16, row stride ld_dst) = src[r][c] (fp32, row stride ld_src) for an R x C block inside larger matrices (C, both strides and both base
+ * offsets multiples of 8): the per-layer slice of the AdaLN table gradients, cast as soon as that layer's backward has finished */
+int tfx_cast_block_bf16(const float* src, int32_t ld_src, tfx_bf16* dst, int32_t ld_dst, int32_t R, int32_t C, void* stream);
 /* dst(bf16) = a(bf16) * silu'(pre(bf16))  (time-MLP backward) */
 int tfx_silu_bwd(const tfx_bf16* dy, const tfx_bf16* pre, tfx_bf16* dx, int64_t n, void* stream);
 /* column sums: out[c] += sum_r src[r][c]  (bias gradients); src bf16 or fp32 */
@@ -303,7 +306,7 @@ enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_
        TFX_OP_ADAM_STEP = 22, TFX_OP_DECODE_ATTN = 23,
        /* positional entry points (args = tfx_raw_args) */
        TFX_OP_OUTPUT_TO_FLOW = 32, TFX_OP_GATHER_F32 = 33, TFX_OP_ONEHOT_BF16 = 34, TFX_OP_SCATTER_ROWS_BF16 = 35, TFX_OP_F32_TO_BF16 = 36,
-       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41,
+       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41, TFX_OP_CAST_BLOCK_BF16 = 42,
        /* stream control (args = any non-NULL pointer; `stream` = event slot 0..63):
           FORK: the library's side stream waits for everything enqueued so far on the caller's stream;
           JOIN_RECORD: mark "everything enqueued so far on the side stream";  JOIN_WAIT: the caller's stream waits for that mark;

@@ -50,3 +50,56 @@ def test_flat_gradient_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_overlap(rank, world, port, q):
+    """the overlapped exchange (optim.GradReducer): layer groups all-reduced in backward order, tail at the end - every element exactly once,
+    the result equal to ONE all-reduce of the whole buffer, and a (torch-emulated) clip + Adam step on the mean gradient leaves identical
+    parameters on every rank, equal to the single-process step on the mean gradient."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.optim import GradReducer
+    torch.manual_seed(0)
+    m = Transfusion(num_text_tokens=16, dim_latent=(32, 8), transformer=dict(dim=64, depth=5, heads=1))      # odd depth: uneven groups
+    ps = m.store
+    gen = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(ps.numel, generator=gen)
+    ps.grad = local.clone()
+    red = GradReducer(m, None, groups=3)
+    red.begin()
+    per = red.per
+    ok = True
+    for first in range(((5 - 1) // per) * per, -1, -per):                     # the cut order of engine.Plan: last group first
+        red.group_ready(first, min(first + per, 5) - 1)
+    red.finish()
+    expect = local.clone()
+    dist.all_reduce(expect, op=dist.ReduceOp.SUM)
+    ok &= bool(torch.equal(ps.grad, expect))
+    # step on the mean gradient (train_toy.py:55-57 semantics, emulated with torch on CPU): identical on every rank
+    g = ps.grad / world
+    g = g * min(1., 0.5 / (float(g.norm()) + 1e-6))
+    new = ps.flat.detach() - 3e-4 * g / (g.abs() + 1e-8)                      # first Adam step: m / sqrt(v) = sign(g)
+    ref = new.clone()
+    dist.all_reduce(ref, op=dist.ReduceOp.MAX)
+    ok &= bool(torch.equal(ref, new))
+    all_local = [torch.randn(ps.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    gm = sum(all_local) / world
+    gm = gm * min(1., 0.5 / (float(gm.norm()) + 1e-6))
+    ok &= bool(torch.allclose(new, ps.flat.detach() - 3e-4 * gm / (gm.abs() + 1e-8), rtol=0, atol=1e-6))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_exchange_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

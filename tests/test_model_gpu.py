@@ -443,6 +443,44 @@ def test_upstream_gradient_scales_seeds_once_and_second_backward_raises():
             assert rel(grads[1][k] * 3., grads[0][k]) <= 2e-2, k          # the seeds are re-rounded to bf16 after the scale: noise, not a factor
 
 
+def test_overlapped_gradient_exchange_equals_plain_step_rccl_world1():
+    """data-parallel step with the gradient all-reduce cut into layer groups and issued DURING the backward (optim.GradReducer, engine
+    `bwd_cuts`) on a real RCCL communicator (world size 1 on this box; world 2 runs on gloo in tests/test_dp_gloo.py): loss, every gradient and
+    the post-step parameters equal the plain path's (per-layer AdaLN weight-gradient GEMMs instead of one: fp32 atomic ordering noise only)."""
+    import torch.distributed as dist
+    from transfusion_pytorch_amd.optim import FusedAdam
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29541')
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        cfg, sd, batch, times, noise = build_case('small2')
+        res = []
+        for overlap in (False, True):
+            model = build_native(cfg, sd).train()
+            model._noise_override = {t: v.cuda() for t, v in noise.items()}
+            opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
+            opt.always_sync = True
+            if overlap:
+                opt.overlap_grad_sync(groups=3)
+            loss = model(batch, times=times)
+            loss.backward()
+            plan = model._live[0]
+            assert bool(plan.bwd_cuts) == overlap and (not overlap or len(plan.bwd_cuts) == 2)        # depth 4, groups of 2 layers
+            grads = {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+            torch.cuda.synchronize()
+            res.append((float(loss), grads, model.store.flat.clone()))
+        (l0, g0, p0), (l1, g1, p1) = res
+        assert abs(l0 - l1) <= 1e-6 * max(1., abs(l0))
+        for k in g0:
+            assert rel(g1[k], g0[k]) <= 2e-3, k
+        assert rel(p1, p0) <= 1e-5
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

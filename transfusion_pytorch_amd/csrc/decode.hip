@@ -57,6 +57,18 @@ __global__ void ode_axpy_k(const float* y, const float* fc, const float* fu, flo
   out[i] = y[i] + a * f;
 }
 
+// R x C block of a fp32 matrix -> bf16 block of another matrix (8 elements per thread)
+__global__ void cast_block_k(const float* src, int ld_src, bf16* dst, int ld_dst, int R, int C8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)R * C8) return;
+  const int r = (int)(i / C8), c = (int)(i % C8) * 8;
+  const f32x4 a = *(const f32x4*)(src + (size_t)r * ld_src + c), b = *(const f32x4*)(src + (size_t)r * ld_src + c + 4);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; e++) { o[e] = f2bf(a[e]); o[4 + e] = f2bf(b[e]); }
+  *(bf16x8*)(dst + (size_t)r * ld_dst + c) = o;
+}
+
 }  // namespace tfx
 using namespace tfx;
 
@@ -74,6 +86,13 @@ int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, flo
   if (n <= 0) return 0;
   if (!y || !f_cond || !out) return -1;
   hipLaunchKernelGGL(ode_axpy_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, f_cond, f_uncond, cfg_scale, a, out, (long long)n);
+  return (int)hipGetLastError();
+}
+int tfx_cast_block_bf16(const float* src, int32_t ld_src, tfx_bf16* dst, int32_t ld_dst, int32_t R, int32_t C, void* s) {
+  if (R <= 0 || C <= 0) return 0;
+  if (!src || !dst || (C | ld_src | ld_dst) % 8 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return -1;
+  const long long n = (long long)R * (C / 8);
+  hipLaunchKernelGGL(cast_block_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, src, ld_src, dst, ld_dst, R, C / 8);
   return (int)hipGetLastError();
 }
 /* the K13 name of SURVEY 8(b): attention of a short block of NEW query rows per sample against keys / values that live in a KV cache

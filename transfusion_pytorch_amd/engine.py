@@ -139,13 +139,15 @@ class LaunchList(list):
 
 
 class Plan:
-    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None):
+    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None, dp_groups: int = 0):
         """cache: None, or a KV cache tensor [depth, b, maxlen, 2*heads*64] (k~ | v per token).  With a cache the plan is a
         DECODE step: each layer appends this step's k~ / v rows at `cache_pos` (flat row b*maxlen + position, -1 = skip) and
         attention reads keys / values from the cache (per-token visible length in `kv_end`)."""
         md = ps.md
         self.cache = cache
         assert cache is None or not training
+        self.dp_groups = dp_groups          # > 0: the backward list is cut into that many layer groups for the overlapped gradient all-reduce (optim.GradReducer)
+        self.bwd_cuts = []                  # [(list index, first layer of the group, last layer of the group)], in backward order
         self.ps, self.md, self.b, self.n, self.I, self.R = ps, md, b, n, I, dict(R)
         self.T = T = b * n
         dev = ps.device
@@ -481,7 +483,22 @@ class Plan:
                 sk = self.xres[src[i]]
                 self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
                 self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
+            if I > 0:
+                # AdaLN conditioning weights of THIS layer (both wrappers: 6d table columns, 63 % of all parameters): their table gradients
+                # are final once the layer's backward is, so the weight / bias gradients are formed here, layer by layer, instead of in one
+                # GEMM at the very end - the gradient buffer then completes back to front and its all-reduce can start during the backward
+                off = i * 2 * 3 * d
+                w_item = lambda it: L.append(Side(it) if side else it)
+                w_item((lib.tfx_cast_block_bf16, (self.dtables.data_ptr() + 4 * off, nt3, self.dtab_bf.data_ptr() + 2 * off, nt3, I, 6 * d)))
+                self._tn(L, I, 6 * d, 4 * d, side=side, A=self.dtab_bf.data_ptr() + 2 * off, lda=nt3, a_cols=6 * d, B=self.cond, ldb=4 * d, b_cols=4 * d,
+                         C=gp(f'{p}.1.to_film.weight'), ldc=4 * d)
+                w_item((lib.tfx_colsum_f32, (self.dtables.data_ptr() + 4 * off, nt3, I, 6 * d, gp(f'{p}.1.to_film.bias'))))
             sync('tfx_join_record', i)
+            if self.dp_groups > 0:
+                per = -(-D // self.dp_groups)
+                if i % per == 0:                                     # lowest layer of a group: every gradient of layers >= i is final
+                    sync('tfx_join_wait', i)
+                    self.bwd_cuts.append((len(L), i, min(i + per, D) - 1))
             if md.has_skip(i):
                 st = S[f'skip_t{i}']
                 self._nt(L, A=G, lda=d, B=st, ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.gx, ldc=d, R=G, ldr=d)
@@ -504,10 +521,7 @@ class Plan:
                      C=gp(f'latent_to_model_projs.{t}.weight'), ldc=dl)
             self._raw(L, lib.tfx_colsum_bf16, self.dx0.data_ptr(), d, r, d, None, self.row_tok[t].data_ptr(), gp(f'latent_to_model_projs.{t}.bias'))
         if I > 0:
-            self._raw(L, lib.tfx_f32_to_bf16, self.dtables.data_ptr(), self.dtab_bf.data_ptr(), I * nt3)
-            self._tn(L, I, nt3, 4 * d, A=self.dtab_bf, lda=nt3, a_cols=nt3, B=self.cond, ldb=4 * d, b_cols=4 * d,
-                     C=gp('transformer.layers.0.1.to_film.weight'), ldc=4 * d)
-            self._raw(L, lib.tfx_colsum_f32, self.dtables.data_ptr(), nt3, I, nt3, gp('transformer.layers.0.1.to_film.bias'))
+            # (dtab_bf = bf16 table gradients, cast layer by layer above - the join before this point covers the side stream)
             self._nt(L, A=self.dtab_bf, lda=nt3, B=S['ada_t'], ldb=nt3, M=I, N=4 * d, K=nt3, epi=E['TFX_EPI_BF16'], C=self.dcond, ldc=4 * d)
             self._raw(L, lib.tfx_silu_bwd, self.dcond.data_ptr(), self.pre.data_ptr(), self.dpre.data_ptr(), I * 4 * d)
             self._tn(L, I, 4 * d, d + 1, A=self.dpre, lda=4 * d, a_cols=4 * d, B=self.fe, ldb=md.kf, b_cols=md.kf,

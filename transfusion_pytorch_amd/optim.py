@@ -12,6 +12,71 @@ import torch.distributed as dist
 from . import capi
 
 
+class GradReducer:
+    """Overlap of the data-parallel gradient exchange with the backward (reference practice: DDP's bucketed all-reduce under `accelerate`,
+    train_mnist.py:114-126).  The flat gradient buffer completes BACK TO FRONT during the hand-written backward - the heads first, then the
+    layers from the last to the first (their AdaLN conditioning weights included: engine.Plan forms those per layer), the embeddings last -
+    so the buffer is exchanged in `groups` layer groups: as soon as a group's gradients are final (`Plan.bwd_cuts`), its three contiguous
+    ranges (AdaLN weights, AdaLN biases, the layers' own parameters) are all-reduced asynchronously on the collective's stream while the
+    backward of the earlier layers runs; what is left (time conditioning, embeddings, input projections) follows the backward.
+    Every element is reduced exactly once (tests/test_dp_gloo.py).  One process per GPU, RCCL over xGMI via torch.distributed."""
+
+    def __init__(self, model, process_group=None, groups: int = 4):
+        self.model, self.group = model, process_group
+        ps, md = model.store, model.md
+        self.groups = max(1, min(groups, md.depth))
+        self.per = -(-md.depth // self.groups)
+        self.handles, self.done = [], []
+        self._step = -1
+        d, D = md.dim, md.depth
+        off = lambda name: ps.offsets[name][0]
+        end = lambda name: ps.offsets[name][0] + int(torch.Size(ps.offsets[name][1]).numel())
+        self._w0, self._b0 = off('transformer.layers.0.1.to_film.weight'), off('transformer.layers.0.1.to_film.bias')
+        self._wl, self._bl = 2 * 3 * d * 4 * d, 2 * 3 * d                     # AdaLN weight / bias elements per layer (contiguous, layer-major)
+        first = lambda i: off(f'transformer.layers.{i}.0.weight') if md.has_skip(i) else off(f'transformer.layers.{i}.1.fn.to_qk.0.weight')
+        self._core = [first(i) for i in range(D)] + [off('transformer.norm.gamma')]
+        self._head = (off('transformer.norm.gamma'), ps.numel)               # final norm, in / out projections, embeddings, logits
+        self._mid = (end(f'transformer.layers.{D - 1}.2.to_ada_ln_zero.bias'), self._core[0])     # time conditioning MLP
+
+    def ranges(self, lo: int, hi: int):
+        """flat [start, end) ranges that hold exactly the gradients of layers lo..hi (inclusive)"""
+        return [(self._w0 + lo * self._wl, self._w0 + (hi + 1) * self._wl), (self._b0 + lo * self._bl, self._b0 + (hi + 1) * self._bl),
+                (self._core[lo], self._core[hi + 1])]
+
+    def _reduce(self, ranges, async_op):
+        g = self.model.store.grad
+        for a, b in ranges:
+            if b > a:
+                h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                if async_op:
+                    self.handles.append(h)
+                self.done.append((a, b))
+
+    def begin(self):
+        self.handles, self.done = [], []
+
+    def group_ready(self, lo: int, hi: int):
+        """called between two segments of the backward list: layers lo..hi are final (and, at the first cut, nothing else is)"""
+        self._reduce(self.ranges(lo, hi), async_op=True)
+
+    def finish(self):
+        """after the backward: exchange whatever no cut covered, then make the current stream wait for every collective"""
+        n = self.model.store.numel
+        covered = sorted(self.done)
+        rest, pos = [], 0
+        for a, b in covered:
+            if a > pos:
+                rest.append((pos, a))
+            pos = max(pos, b)
+        if pos < n:
+            rest.append((pos, n))
+        self._reduce(rest, async_op=False)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        assert sum(b - a for a, b in self.done) == n, 'every gradient element must be reduced exactly once'
+
+
 class FusedAdam:
     def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0., max_grad_norm=None, process_group=None,
                  average_grads=True):
@@ -22,6 +87,14 @@ class FusedAdam:
         self.step_count = 0
         self.always_sync = False        # run the collective even at world size 1 (exercises the RCCL path on a 1-GPU box)
         self.m = self.v = self.sumsq = None
+        self.reducer = None             # set by `overlap_grad_sync`: the exchange then runs in layer groups during the backward
+
+    def overlap_grad_sync(self, groups: int = 4):
+        """exchange the gradients in `groups` layer groups DURING the backward (GradReducer) instead of one all-reduce after it"""
+        self.reducer = GradReducer(self.model, self.group, groups)
+        self.model._grad_reducer = self.reducer
+        self.model._dp_groups = self.reducer.groups
+        return self
 
     def _world(self):
         if dist.is_available() and dist.is_initialized():
@@ -32,7 +105,11 @@ class FusedAdam:
         """the ONE collective of a data-parallel step: all-reduce(sum) of the flat gradient buffer (RCCL over xGMI)."""
         world = self._world()
         if world > 1 or (self.always_sync and dist.is_initialized()):
-            dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self.reducer is not None and self.reducer.done:
+                self.reducer.finish()                  # the groups went out during the backward: tail + wait
+                self.reducer.begin()
+            else:
+                dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM, group=self.group)
         return world
 
     def step(self):

@@ -188,12 +188,13 @@ class Transfusion(nn.Module):
         return self._rope
 
     def _plan(self, b, n, I, R, training):
-        key = (b, n, I, tuple(sorted(R.items())), training)
+        dp_groups = getattr(self, '_dp_groups', 0) if training else 0
+        key = (b, n, I, tuple(sorted(R.items())), training, dp_groups)
         plan = self._plans.pop(key, None)
         if plan is None:
             while len(self._plans) >= 8:                             # least recently used plan goes first (dict order = use order)
                 self._plans.pop(next(iter(self._plans)))
-            plan = Plan(self.store, b, n, I, R, training=training)
+            plan = Plan(self.store, b, n, I, R, training=training, dp_groups=dp_groups)
         self._plans[key] = plan                                      # (re-)insert at the most recent position
         return plan
 
@@ -784,7 +785,18 @@ class Transfusion(nn.Module):
         for seed in [plan.dlogits] + [lt['dpred'] for lt in plan.lat.values()]:
             capi.check(lib.tfx_scale_bf16_dev(seed.data_ptr(), seed.numel(), go.data_ptr(), sp), 'tfx_scale_bf16_dev')
         plan.dtables.zero_()
-        Plan.run(plan.bwd, stream)
+        red = getattr(self, '_grad_reducer', None)
+        if red is None or not plan.bwd_cuts or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            Plan.run(plan.bwd, stream)
+            return
+        # data parallel with overlap: replay the list group by group; a finished group's gradient ranges go out while the rest runs
+        red.begin()
+        lo = 0
+        for idx, first, last in plan.bwd_cuts:
+            Plan.run(plan.bwd, stream, lo, idx)
+            red.group_ready(first, last)
+            lo = idx
+        Plan.run(plan.bwd, stream, lo, None)
 
     # ------------------------------------------------------------------ sampling surface (T:1842-2583)
     @torch.no_grad()
