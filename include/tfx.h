@@ -279,6 +279,8 @@ int tfx_add_bf16(const tfx_bf16* a, const tfx_bf16* b, tfx_bf16* out, int64_t n,
  * exactly 1.0 makes every block return before touching memory: `loss.backward()` with the default upstream gradient costs a launch,
  * not a pass over the loss seeds (autograd hands d total / d loss over as a device tensor, T: train_toy.py:53) */
 int tfx_scale_bf16_dev(tfx_bf16* x, int64_t n, const float* scale, void* stream);
+/* dst[i] = scale * src[i] (bf16, host scalar): the negated loss seed of the model-space model_output_clean backward */
+int tfx_scale_bf16_copy(const tfx_bf16* src, tfx_bf16* dst, int64_t n, float scale, void* stream);
 
 /* fused global-norm clip + Adam over flat fp32 buffers   train_toy.py:55-57
  * sumsq[0] must hold the sum of squared gradients (tfx_sumsq accumulates into it; zero it first). */
@@ -306,7 +308,7 @@ enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_
        TFX_OP_ADAM_STEP = 22, TFX_OP_DECODE_ATTN = 23,
        /* positional entry points (args = tfx_raw_args) */
        TFX_OP_OUTPUT_TO_FLOW = 32, TFX_OP_GATHER_F32 = 33, TFX_OP_ONEHOT_BF16 = 34, TFX_OP_SCATTER_ROWS_BF16 = 35, TFX_OP_F32_TO_BF16 = 36,
-       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41, TFX_OP_CAST_BLOCK_BF16 = 42,
+       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41, TFX_OP_CAST_BLOCK_BF16 = 42, TFX_OP_SCALE_BF16_COPY = 43,
        /* stream control (args = any non-NULL pointer; `stream` = event slot 0..63):
           FORK: the library's side stream waits for everything enqueued so far on the caller's stream;
           JOIN_RECORD: mark "everything enqueued so far on the side stream";  JOIN_WAIT: the caller's stream waits for that mark;

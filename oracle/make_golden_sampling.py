@@ -30,8 +30,10 @@ CFG_DEEP = dict(num_text_tokens=256, dim=256, depth=8, dim_latents=(32,), heads=
 DEEP_KW = dict(max_length=64, text_temperature=0., modality_steps=16, fixed_modality_shape=(4,), cfg_scale=3.)
 
 
-def sampling_case(deep: bool = False):
-    cfg = OracleConfig(**(CFG_DEEP if deep else CFG))
+def sampling_case(deep: bool = False, clean: bool = False):
+    """`clean`: the same small case with `model_output_clean=True` (T:1297): the sampler converts the model's output to a flow in model
+    space against the projected state (T:2446-2456)"""
+    cfg = OracleConfig(**(CFG_DEEP if deep else CFG), **(dict(model_output_clean=True, eps=1e-2) if clean else {}))
     tag = 'sampling_deep' if deep else 'sampling'
     sd = D.det_state_dict(cfg.state_dict_shapes(), tag=tag)
     pk = 'spd' if deep else 'sp'
@@ -107,11 +109,11 @@ class MarginRecorder:
         return out
 
 
-def run_case(deep: bool):
-    cfg, sd, prompts, noise = sampling_case(deep)
+def run_case(deep: bool, clean: bool = False):
+    cfg, sd, prompts, noise = sampling_case(deep, clean)
     model = build_reference_model(cfg, sd, modality_default_shape=(4,))
     model.eval()
-    g = dict(cfg=CFG_DEEP if deep else CFG, runs={}, margins={})
+    g = dict(cfg=CFG_DEEP if deep else CFG, runs={}, margins={}, model_output_clean=clean)
     rec = MarginRecorder().install()
     try:
         for name, kw in [('free', dict()), ('forced', dict(force_modality_at_start=0)), ('forced_nocfg', dict(force_modality_at_start=0, cfg_scale=1.))]:
@@ -128,14 +130,18 @@ def run_case(deep: bool):
                       f'{sum(m < 0.05 for _, _, m in mg)} below 0.05')
     finally:
         rec.remove()
-    path = os.path.join(OUT, 'sampling_deep.pt' if deep else 'sampling.pt')
+    path = os.path.join(OUT, 'sampling_clean.pt' if clean else ('sampling_deep.pt' if deep else 'sampling.pt'))
     torch.save(g, path)
     print('saved', path, os.path.getsize(path), 'bytes')
 
 
 def main():
+    import sys
+    if 'clean' in sys.argv[1:]:
+        return run_case(False, clean=True)
     run_case(False)
     run_case(True)
+    run_case(False, clean=True)
 
 
 if __name__ == '__main__':

@@ -351,8 +351,8 @@ def test_velocity_consistency_matches_reference_golden():
 
 def test_model_output_clean_forward_modality_matches_reference_golden():
     """`model_output_clean=True` on the pure flow path (T:2772-2810): pred flow = (output - x_t) / max(1 - t, eps) in fp32, with the
-    eps floor active for one sample (t = 0.995); golden from the reference (tests/golden/clean1.pt).  The interleaved forward and
-    the sampler refuse the option loudly (model-space conversion)."""
+    eps floor active for one sample (t = 0.995); golden from the reference (tests/golden/clean1.pt).  Then the INTERLEAVED step of the same
+    model (model-space conversion, MP:786-792) against the reference's interleaved golden of the same fixture."""
     from oracle.make_golden_clean import clean_case
     from transfusion_pytorch_amd import Transfusion
     cfg, sd, batch, times, noise, xm, tm, nm = clean_case()
@@ -378,8 +378,29 @@ def test_model_output_clean_forward_modality_matches_reference_golden():
     with torch.no_grad():
         pred = model.forward_modality(xm, times=tm, modality_type=1, return_loss=False)
     assert rel(pred.cpu(), g['mod_pred_noloss']) <= 2e-2
-    with pytest.raises(NotImplementedError):
-        model(batch, times=times)
+    # the interleaved step converts in MODEL space against the projected noised tokens (MP:786-792): (W embed - W proj) / max(1 - t, eps), the
+    # subtraction between two fp32 GEMM results; golden from the reference's own interleaved call (same fixture)
+    model._noise_override = {t: v.cuda() for t, v in noise.items()}
+    model.zero_grad(set_to_none=True)
+    loss, bd = model(batch, times=times, return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f'  interleaved: loss native {float(loss.detach()):.4f} reference {float(g["loss"]):.4f}; flows {[round(float(f), 3) for f in bd.flow]} vs '
+          f'{[round(float(f), 3) for f in g["flow_losses"]]}')
+    assert abs(float(loss.detach()) - float(g['loss'])) <= 5e-3 * abs(float(g['loss']))                # 1 / (1 - t) up to 100 amplifies the bf16 floor
+    for a, r in zip(bd.flow, g['flow_losses']):
+        assert abs(float(a) - float(r)) <= 8e-3 * abs(float(r))
+    assert abs(float(bd.text) - float(g['text_loss'])) <= 2e-3 * abs(float(g['text_loss']))
+    wsum = nsum = worst = 0.
+    for k, p in model.named_parameters():
+        if k not in g['grad_norms'] or g['grad_norms'][k] < 1e-6:
+            continue
+        r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][k])
+        gn = float(p.grad.double().norm())
+        assert abs(gn - g['grad_norms'][k]) <= 6e-2 * g['grad_norms'][k], (k, gn, g['grad_norms'][k])
+        worst = max(worst, r); wsum += r * g['grad_norms'][k]; nsum += g['grad_norms'][k]
+    print(f'  interleaved gradients: worst head rel {worst:.3e}, norm-weighted mean rel {wsum / nsum:.3e}')
+    assert wsum / nsum <= 3e-2
 
 
 def test_native_list_replay_equals_per_launch_calls():

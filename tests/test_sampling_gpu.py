@@ -21,10 +21,10 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden', 'sampling.pt')
 GOLDEN_DEEP = os.path.join(os.path.dirname(__file__), 'golden', 'sampling_deep.pt')
 
 
-def native_model(deep=False):
+def native_model(deep=False, clean=False):
     from transfusion_pytorch_amd import Transfusion
-    cfg, sd, prompts, noise = sampling_case(deep)
-    m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents[0], modality_default_shape=(4,),
+    cfg, sd, prompts, noise = sampling_case(deep, clean)
+    m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents[0], modality_default_shape=(4,), model_output_clean=clean, eps=cfg.eps,
                     transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
     m.load_state_dict(sd)
     return m.cuda().eval(), prompts, noise
@@ -68,14 +68,16 @@ RUNS = [('free', {}), ('forced', dict(force_modality_at_start=0)), ('forced_nocf
 
 
 @pytest.mark.parametrize('run,kw', RUNS)
-@pytest.mark.parametrize('deep', [False, True])
+@pytest.mark.parametrize('deep', [False, True, 'clean'])
 def test_sample_many_matches_reference_golden(run, kw, deep):
     """every greedy decision whose reference top-2 margin is >= 0.05 must be identical; the native path may leave the reference's
     only AT a recorded near-tie (after which the two histories differ and nothing more can be compared for that sample).  `deep`:
     dim256 / depth 8, max_length 64, 16 ODE grid points (the reference default)."""
     from oracle.make_golden_sampling import DEEP_KW
-    g = torch.load(GOLDEN_DEEP if deep else GOLDEN, weights_only=False)
-    m, prompts, noise = native_model(deep)
+    clean = deep == 'clean'                    # the small case with model_output_clean=True: model-space flow conversion in the ODE (T:2446-2456)
+    deep = deep is True
+    g = torch.load(GOLDEN.replace('sampling.pt', 'sampling_clean.pt') if clean else (GOLDEN_DEEP if deep else GOLDEN), weights_only=False)
+    m, prompts, noise = native_model(deep, clean)
     kwargs = dict(DEEP_KW, init_modality_noise=noise) if deep else \
         dict(max_length=12, text_temperature=0., init_modality_noise=noise, modality_steps=4, fixed_modality_shape=(4,), cfg_scale=3.)
     kwargs.update(kw)

@@ -69,6 +69,16 @@ __global__ void cast_block_k(const float* src, int ld_src, bf16* dst, int ld_dst
   *(bf16x8*)(dst + (size_t)r * ld_dst + c) = o;
 }
 
+__global__ void scale_copy_k(const bf16* src, bf16* dst, long long n, float sc) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 7 < n) {
+    bf16x8 v = *(const bf16x8*)(src + i);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = f2bf(bf2f(v[e]) * sc);
+    *(bf16x8*)(dst + i) = v;
+  } else for (long long j = i; j < n; j++) dst[j] = f2bf(bf2f(src[j]) * sc);
+}
+
 }  // namespace tfx
 using namespace tfx;
 
@@ -86,6 +96,12 @@ int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, flo
   if (n <= 0) return 0;
   if (!y || !f_cond || !out) return -1;
   hipLaunchKernelGGL(ode_axpy_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, f_cond, f_uncond, cfg_scale, a, out, (long long)n);
+  return (int)hipGetLastError();
+}
+int tfx_scale_bf16_copy(const tfx_bf16* src, tfx_bf16* dst, int64_t n, float scale, void* s) {
+  if (n <= 0) return 0;
+  if (!src || !dst) return -1;
+  hipLaunchKernelGGL(scale_copy_k, dim3((unsigned)((n / 8 + 256) / 256)), dim3(256), 0, (hipStream_t)s, src, dst, (long long)n, scale);
   return (int)hipGetLastError();
 }
 int tfx_cast_block_bf16(const float* src, int32_t ld_src, tfx_bf16* dst, int32_t ld_dst, int32_t R, int32_t C, void* s) {

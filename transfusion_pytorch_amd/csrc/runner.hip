@@ -59,6 +59,8 @@ inline int run_one(const tfx_launch& l, void* s) {
       return tfx_add_bf16((const tfx_bf16*)r->p0, (const tfx_bf16*)r->p1, (tfx_bf16*)r->p2, r->i0, s);
     case TFX_OP_CAST_BLOCK_BF16:
       return tfx_cast_block_bf16((const float*)r->p0, (int32_t)r->i0, (tfx_bf16*)r->p1, (int32_t)r->i1, (int32_t)r->i2, (int32_t)r->i3, s);
+    case TFX_OP_SCALE_BF16_COPY:
+      return tfx_scale_bf16_copy((const tfx_bf16*)r->p0, (tfx_bf16*)r->p1, r->i0, r->f0, s);
     case TFX_OP_SCALE_BF16_DEV:
       return tfx_scale_bf16_dev((tfx_bf16*)r->p0, r->i0, (const float*)r->p1, s);
     default: return -100;          // unknown op

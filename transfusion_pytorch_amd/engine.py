@@ -323,18 +323,19 @@ class Plan:
             for t, r in self.R.items():
                 dl = md.dim_latents[t]; lt = self.lat[t]
                 self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_src[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
+            self._clean_launch, self.clean_mode = {}, 'model'
+            if md.model_output_clean:        # decode: always the model-space form (T:2446-2456), see below
+                for t, r in self.R.items():
+                    self._clean_model_space(L, t, r, self.row_src[t])
             self.fwd_pred_end = len(L)
             return
         for t, r in self.R.items():          # flow predictions first, so that a loss-free forward can stop at fwd_pred_end
             dl = md.dim_latents[t]; lt = self.lat[t]
             self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_tok[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
-        self._clean_launch = {}
+        self._clean_launch, self.clean_mode = {}, 'latent'
         if md.model_output_clean:            # pred <- (pred - noised) / max(1 - t, eps): the model predicts the clean latent (MP:100-126)
             for t, r in self.R.items():
-                dl = md.dim_latents[t]; lt = self.lat[t]
-                self._clean_launch[t] = [lt['pred'].data_ptr(), lt['x'].data_ptr(), None, self.row_inst[t].data_ptr(), self.inst_time.data_ptr(),
-                                         r, dl, float(md.clean_eps)]
-                L.append((capi.lib().tfx_output_to_flow, self._clean_launch[t]))
+                self._clean_model_space(L, t, r, self.row_tok[t])
         self.fwd_pred_end = len(L)
         self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
                                        dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
@@ -354,6 +355,32 @@ class Plan:
                                                dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + len(md.dim_latents) + t), accumulate=1,
                                                **(dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}))
             self.vel.append(('tfx_mse_fwd_bwd', self._vel_args[t]))
+
+    def _clean_model_space(self, L, t, r, rowmap):
+        """`model_output_clean` (T:1297).  Two conversions exist in the reference:
+          latent space (forward_modality, T:2772-2810):   flow = (model_to_latent(embed) - x_t) / max(1 - t, eps)
+          model space  (interleaved forward MP:786-792, sample_many T:2446-2456):   flow = model_to_latent((embed - proj) / max(1 - t, eps)),
+                        proj = the projected noised tokens the transformer consumed
+        model_to_latent is linear without bias, so the model-space form is (W embed - W proj) / max(1 - t, eps): the cancellation of the two
+        O(1) model-space vectors is carried out AFTER the projection, between two fp32 GEMM results `pred` and `q = W proj` - never in bf16.
+        Both forms run through ONE launch (`tfx_output_to_flow`): `set_clean_mode` points its subtrahend at x / eps (latent) or at q (model)."""
+        md, d = self.md, self.md.dim
+        dl = md.dim_latents[t]; lt = self.lat[t]
+        lt['q'] = torch.empty(r, dl, device=self.ps.device, dtype=torch.float32)
+        self._nt(L, A=self.hid[0], lda=d, a_rowmap=rowmap, B=self.ps.shadows[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['q'], ldc=dl)
+        self._clean_launch[t] = [lt['pred'].data_ptr(), lt['q'].data_ptr() if self.clean_mode == 'model' else lt['x'].data_ptr(), None,
+                                 self.row_inst[t].data_ptr(), self.inst_time.data_ptr(), r, dl, float(md.clean_eps)]
+        L.append((capi.lib().tfx_output_to_flow, self._clean_launch[t]))
+
+    def set_clean_mode(self, mode: str):
+        """'latent' (forward_modality) or 'model' (interleaved forward / sampler): which subtrahend `tfx_output_to_flow` uses, and whether the
+        backward adds the gradient paths through `q = W proj` (clean_bwd)"""
+        assert mode in ('latent', 'model')
+        self.clean_mode = mode
+        for t, a in self._clean_launch.items():
+            lt = self.lat[t]
+            a[1] = lt['q'].data_ptr() if mode == 'model' else lt['x'].data_ptr()
+            a[2] = None if mode == 'model' else self.noise_args[t].eps
 
     def _attn_kw(self, i, bwd=False):
         md, hd, ldq = self.md, self.md.hdk, self.md.ldq
@@ -386,7 +413,7 @@ class Plan:
     def set_noise(self, t: int, eps_ptr):
         """noise source of modality type t for this run: a device pointer (training: x_t = t x + (1 - t) eps) or None (no noising)"""
         self.noise_args[t].eps = eps_ptr
-        if t in getattr(self, '_clean_launch', {}):
+        if t in getattr(self, '_clean_launch', {}) and self.clean_mode == 'latent':
             self._clean_launch[t][2] = eps_ptr
 
     def set_ce_vocab(self, V: int):
@@ -407,6 +434,22 @@ class Plan:
         pp, gp = ps.ptr, ps.grad_ptr
         lib = capi.lib()
         gmap = ps._maps['geglu']
+        # model-space `model_output_clean`: pred = (W embed - W proj) s, so the (already s-scaled) seed also flows, negated, through q = W proj:
+        #   d proj = -(dpred W)  ->  latent_to_model weight / bias gradients;   dW += (-dpred)^T proj.   Run before the main list when the mode is 'model'.
+        self.clean_bwd = LaunchList()
+        if md.model_output_clean:
+            C = self.clean_bwd
+            for t, r in self.R.items():
+                dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+                lt['ndpred'] = torch.zeros(r, dlp, device=self.ps.device, dtype=BF16)
+                self._raw(C, lib.tfx_scale_bf16_copy, lt['dpred'].data_ptr(), lt['ndpred'].data_ptr(), r * dlp, -1.0)
+                self._tn(C, r, dl, d, A=lt['ndpred'], lda=dlp, a_cols=dlp, B=self.hid[0], ldb=d, b_cols=d, b_rowmap=self.row_tok[t],
+                         C=gp(f'model_to_latent_projs.{t}.weight'), ldc=d)
+                if dl != d:
+                    lt['dpx'] = torch.empty(r, d, device=self.ps.device, dtype=BF16)
+                    self._nt(C, algo_k=dl, A=lt['ndpred'], lda=dlp, B=S[f'outp_t{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=lt['dpx'], ldc=d)
+                    self._tn(C, r, d, dl, A=lt['dpx'], lda=d, a_cols=d, B=lt['xt'], ldb=dlp, b_cols=dlp, C=gp(f'latent_to_model_projs.{t}.weight'), ldc=dl)
+                    self._raw(C, lib.tfx_colsum_bf16, lt['dpx'].data_ptr(), d, r, d, None, None, gp(f'latent_to_model_projs.{t}.bias'))
         self._nt(L, algo_k=md.vocab, A=self.dlogits, lda=md.vp, B=S['logits_t'], ldb=md.vp, M=T, N=d, K=md.vp, epi=E['TFX_EPI_BF16'], C=self.dembed, ldc=d)
         self._tn(L, T, md.vocab, d, A=self.dlogits, lda=md.vp, a_cols=md.vp, B=self.embed, ldb=d, b_cols=d, C=gp('to_text_logits.weight'), ldc=d)
         for t, r in self.R.items():

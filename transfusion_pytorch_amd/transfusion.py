@@ -318,10 +318,6 @@ class Transfusion(nn.Module):
                 raise NotImplementedError('model_output_clean is not wired in the decode forward')
             return self._forward_decode(modalities, times, cache, decode_length, decoding_text_or_modality, return_embed=return_embed,
                                         return_kv_cache=return_kv_cache, return_hiddens=return_hiddens, return_times=return_times)
-        if self.model_output_clean:
-            raise NotImplementedError('model_output_clean in the interleaved forward converts in MODEL space against the projected noised tokens '
-                                      '(MP:786-792): the difference of two O(1) bf16 activations scaled by 1/(1-t) - not representable at the '
-                                      'bf16 activation precision of the native path; forward_modality / generate_modality_only (latent-space, fp32) support it')
         ema = velocity_consistency_ema_model
         if ema is not None and hasattr(ema, 'ema_model'):                                  # EMA wrapper, T:2967-2969
             ema = ema.ema_model
@@ -353,6 +349,8 @@ class Transfusion(nn.Module):
 
         ps.refresh_shadows(stream)
         plan = self._plan(b, n, I, R, training=return_loss)
+        if md.model_output_clean:
+            plan.set_clean_mode('model')                    # interleaved path: the model-space conversion (MP:786-792)
         if plan.loaded_structure is not S:
             plan.set_rope_tables(*self._rope_tables(int(tm.rot_pos.max()) if tm.rot_pos.size else 0))
             plan.tok_inst.copy_(S['tok_inst'].view(-1)); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['q_start']); plan.rot_pos.copy_(S['rot_pos'])
@@ -697,6 +695,8 @@ class Transfusion(nn.Module):
                                                empty=torch.zeros(0, dtype=torch.int32, device=dev))
         self.store.refresh_shadows(stream)
         plan = self._plan(b, L, b, {t: rows}, training=return_loss)
+        if md.model_output_clean:
+            plan.set_clean_mode('latent')                   # pure flow path: the latent-space conversion (T:2772-2810)
         if plan.loaded_structure is not S:
             plan.set_rope_tables(*self._rope_tables(0))
             plan.tok_inst.copy_(S['tok_inst']); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['zeros']); plan.rot_pos.copy_(S['zeros'])
@@ -785,6 +785,8 @@ class Transfusion(nn.Module):
         for seed in [plan.dlogits] + [lt['dpred'] for lt in plan.lat.values()]:
             capi.check(lib.tfx_scale_bf16_dev(seed.data_ptr(), seed.numel(), go.data_ptr(), sp), 'tfx_scale_bf16_dev')
         plan.dtables.zero_()
+        if self.md.model_output_clean and plan.clean_mode == 'model' and len(plan.clean_bwd):
+            Plan.run(plan.clean_bwd, stream)                # gradient paths through q = W proj (engine._clean_model_space)
         red = getattr(self, '_grad_reducer', None)
         if red is None or not plan.bwd_cuts or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             Plan.run(plan.bwd, stream)
@@ -804,8 +806,6 @@ class Transfusion(nn.Module):
                     force_modality_at_start=None, init_modality_noise=None, modality_steps=16, return_unprocessed_modalities=False,
                     cfg_scale=3.):
         from .sampling import Sampler
-        if self.model_output_clean:
-            raise NotImplementedError('sample_many with model_output_clean (the model-space flow conversion of T:2446-2456) is not wired in the native decoder')
         was_training = self.training
         self.eval()                                              # @temp_eval in the reference
         try:
