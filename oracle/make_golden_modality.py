@@ -20,6 +20,7 @@ from .ref_runner import build_reference_model
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
 GEN_STEPS = 5
+VC_DELTA = 1e-3
 
 
 def gen_noise(name, b, shape, dl):
@@ -48,7 +49,20 @@ def make(name: str):
         sampled = model.generate_modality_only(batch_size=2, modality_type=ty, fixed_modality_shape=tuple(shape), modality_steps=GEN_STEPS)
     finally:
         torch.randn = orig_randn
-    g = dict(case=name, reference='lucidrains/transfusion-pytorch v0.19.4 forward_modality / generate_modality_only, fp32, CPU',
+    # forward_modality with an EMA teacher (T:2716-2859): the student is noised at t (1 - delta), the teacher predicts at t + delta on the
+    # CLEAN input, and the term is mse(flow target, teacher flow) - constant in the student's parameters (same gradients, larger loss)
+    sd_t = D.det_state_dict(cfg.state_dict_shapes(), tag=f'{name}/teacher')
+    teacher = build_reference_model(cfg, sd_t, tuple(shape if i == ty else (2,) * len(shape) for i in range(cfg.num_modalities)))
+    teacher.eval()
+    model.zero_grad(set_to_none=True)
+    torch.randn_like = lambda t, **kw: noise.clone()
+    try:
+        vloss, (vflow, vvel, _) = model.forward_modality(x, times=times, modality_type=ty, velocity_consistency_ema_model=teacher,
+                                                         velocity_consistency_delta_time=VC_DELTA, return_loss_breakdown=True)
+    finally:
+        torch.randn_like = orig
+    g = dict(vc_delta=VC_DELTA, vc_loss=vloss.detach().double(), vc_flow=vflow.detach().double(), vc_velocity=vvel.detach().double(),
+             case=name, reference='lucidrains/transfusion-pytorch v0.19.4 forward_modality / generate_modality_only, fp32, CPU',
              input_checksum=float(x.double().abs().sum() + noise.double().abs().sum() + times.double().sum()),
              loss=loss.detach().double(), pred_noloss=pred.detach().clone(),
              grad_norms={k: float(v.double().norm()) for k, v in grads.items()},

@@ -297,6 +297,19 @@ def test_forward_modality_matches_reference_golden():
     with torch.no_grad():
         pred = model(x.cuda(), times=times, modality_type=ty, return_loss=False)          # float tensor routes to forward_modality (T:2989)
     assert pred.shape == x.shape and rel(pred.cpu(), g['pred_noloss']) <= LOGIT_TOL
+    # with an EMA teacher (T:2716-2859): student noised at t (1 - delta), term = mse(flow target, teacher flow at t + delta)
+    from oracle import detdata as D
+    teacher = build_native(cfg, D.det_state_dict(cfg.state_dict_shapes(), tag='flow1/teacher')).eval()
+    model.zero_grad(set_to_none=True)
+    vloss, (vflow, vvel, _) = model.forward_modality(x, times=times, modality_type=ty, velocity_consistency_ema_model=teacher,
+                                                     velocity_consistency_delta_time=g['vc_delta'], return_loss_breakdown=True)
+    vloss.backward()
+    print(f'  with teacher: loss {float(vloss.detach()):.6f} / {float(g["vc_loss"]):.6f}, flow {float(vflow):.6f} / {float(g["vc_flow"]):.6f}, '
+          f'velocity {float(vvel):.6f} / {float(g["vc_velocity"]):.6f}')
+    for a, r in ((vloss.detach(), g['vc_loss']), (vflow, g['vc_flow']), (vvel, g['vc_velocity'])):
+        assert abs(float(a) - float(r)) <= 3e-3 * max(1., abs(float(r)))
+    with pytest.raises(ValueError):
+        model.forward_modality(x, times=times, modality_type=ty, velocity_consistency_ema_model=model)
     model._gen_noise_override = gen_noise('flow1', 2, shape, cfg.dim_latents[ty])
     gen = model.generate_modality_only(batch_size=2, modality_type=ty, fixed_modality_shape=tuple(shape), modality_steps=g['gen_steps'])
     r = rel(gen.cpu(), g['gen'])

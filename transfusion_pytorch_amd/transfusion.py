@@ -323,6 +323,8 @@ class Transfusion(nn.Module):
             ema = ema.ema_model
         if ema is not None and not isinstance(ema, Transfusion):
             raise NotImplementedError('velocity_consistency_ema_model must be a native Transfusion (or the EMA wrapper of one)')
+        if ema is self:
+            raise ValueError('velocity_consistency_ema_model is the model itself: the teacher pass would overwrite the activations the backward needs - pass an EMA copy (create_ema)')
         return_loss = (return_loss and not return_embed) or return_only_pred_flows or ema is not None
         dev = self.device
         stream = self._stream()
@@ -444,7 +446,9 @@ class Transfusion(nn.Module):
             for t, r in sorted(R.items()):
                 w_t = float(tm.is_type[t]) / total
                 plan.lat[t]['vel'].copy_(teacher[t])
-                plan._vel_args[t].grad_scale = 2.0 * self.velocity_consistency_loss_weight * w_t / (r * md.dim_latents[t])
+                va = plan._vel_args[t]
+                va.pred, va.flow = plan.lat[t]['pred'].data_ptr(), plan.lat[t]['vel'].data_ptr()
+                va.grad_scale = 2.0 * self.velocity_consistency_loss_weight * w_t / (r * md.dim_latents[t])
             Plan.run(plan.vel, stream)
             for t, r in sorted(R.items()):
                 vl = plan.acc[2 + M + t] / (r * md.dim_latents[t])
@@ -673,8 +677,13 @@ class Transfusion(nn.Module):
         the sample's time, no attention mask, no rotary embedding; loss = MSE(pred flow, x - noise).  Encoders / EMA velocity
         consistency / reconstruction loss are outside the native path."""
         self._require_gpu()
-        if velocity_consistency_ema_model is not None:
-            raise NotImplementedError('velocity consistency (EMA teacher) is outside the native path (SURVEY.md 8(f) rank 3)')
+        ema = velocity_consistency_ema_model
+        if ema is not None and hasattr(ema, 'ema_model'):
+            ema = ema.ema_model
+        if ema is not None and not isinstance(ema, Transfusion):
+            raise NotImplementedError('velocity_consistency_ema_model must be a native Transfusion (or the EMA wrapper of one)')
+        if ema is self:
+            raise ValueError('velocity_consistency_ema_model is the model itself: the teacher pass would overwrite the activations the backward needs - pass an EMA copy (create_ema)')
         if self.num_modalities > 1 and modality_type is None:
             raise AssertionError('`modality_type` must be explicitly passed in on forward when training on greater than 1 modality')
         t = 0 if modality_type is None else int(modality_type)
@@ -706,7 +715,11 @@ class Transfusion(nn.Module):
             plan.loaded_structure = S
         if times is None:
             times = torch.rand(b, device=dev)                                              # T:2746-2747
-        plan.inst_time.copy_(times.to(dev, torch.float32).reshape(b))
+        times = times.to(dev, torch.float32).reshape(b)
+        if ema is not None and return_loss:                                                # T:2752-2755
+            orig_times = times.clone()
+            times = times * (1. - velocity_consistency_delta_time)
+        plan.inst_time.copy_(times)
         lt = plan.lat[t]
         lt['x'].copy_(x.reshape(rows, dl))
         if not return_loss:
@@ -726,6 +739,23 @@ class Transfusion(nn.Module):
         Plan.run(plan.fwd, stream)
         flow_loss = plan.acc[2 + t] / (rows * dl)                                          # T:2817
         loss = flow_loss
+        velocity_loss = None
+        if ema is not None:
+            # T:2823-2836: mse(FLOW TARGET, teacher flow at t + delta on the clean input) - no gradient reaches the student through it
+            was_training = ema.training
+            ema.eval()
+            try:
+                with torch.no_grad():
+                    teacher = ema.forward_modality(x.view(modalities.shape), times=orig_times + velocity_consistency_delta_time, modality_type=t,
+                                                   encode_modality=False, return_loss=False)
+            finally:
+                ema.train(was_training)
+            lt['vel'].copy_(teacher.reshape(rows, dl))
+            va = plan._vel_args[t]
+            va.pred, va.flow, va.grad_scale = lt['vel'].data_ptr(), lt['flow'].data_ptr(), 0.0
+            Plan.run(plan.vel, stream)
+            velocity_loss = plan.acc[2 + self.num_modalities + t] / (rows * dl)
+            loss = loss + self.velocity_consistency_loss_weight * velocity_loss              # T:2858-2862
         self._step_id += 1
         self._live = (plan, self._step_id)
         if torch.is_grad_enabled():
@@ -735,7 +765,7 @@ class Transfusion(nn.Module):
         if not return_loss_breakdown:
             return loss
         zero = torch.zeros((), device=dev)
-        return loss, (flow_loss.detach(), zero, zero)
+        return loss, (flow_loss.detach(), velocity_loss.detach() if velocity_loss is not None else zero, zero)
 
     @torch.no_grad()
     def generate_modality_only(self, batch_size=1, modality_type=None, fixed_modality_shape=None, modality_steps=16,
