@@ -521,3 +521,58 @@ def test_no_fallback_on_cpu():
     m = Transfusion(num_text_tokens=16, dim_latent=32, transformer=dict(dim=64, depth=1, heads=1))
     with pytest.raises(TfxError):
         m([[torch.randint(0, 16, (4,)), torch.randn(2, 32)]])
+
+
+def test_channel_first_latents_with_frozen_encoder_decoder_match_reference_golden():
+    """SURVEY 8(f) rank 4, first half: `channel_first_latent=True` + frozen `modality_encoder` / `modality_decoder` (T:1352, T:1405-1418,
+    T:1481-1489, T:3094-3101) - host-side layout and pre / post-processing around the native path.  Golden tests/golden/f4_chfirst.pt
+    (oracle/make_golden_f4.py): interleaved step, `return_only_pred_flows` shapes, forward_modality, generate_modality_only through the decoder;
+    the reference checkpoint's `Sequential` key names (`latent_to_model_projs.0.1.*`, `model_to_latent_projs.0.0.*`) load unchanged."""
+    from oracle.make_golden_f4 import enc_dec, f4_case
+    from transfusion_pytorch_amd import Transfusion
+    g = torch.load(os.path.join(GOLDEN, 'f4_chfirst.pt'), weights_only=False)
+    cfg, sd, batch, times, noise, xm, nm, tm, g0 = f4_case()
+    enc, dec = enc_dec()
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=16, channel_first_latent=True, modality_default_shape=(4,),
+                        modality_encoder=enc, modality_decoder=dec, prob_uncond=0.,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    ref_keys = {k.replace('latent_to_model_projs.0.', 'latent_to_model_projs.0.1.').replace('model_to_latent_projs.0.', 'model_to_latent_projs.0.0.'): v
+                for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(ref_keys, strict=False)
+    assert not unexpected and all(k.startswith(('modality_encoder', 'modality_decoder')) for k in missing), (missing, unexpected)
+    assert 'latent_to_model_projs.0.1.weight' in model.state_dict() and 'model_to_latent_projs.0.0.weight' in model.state_dict()
+    model = model.cuda().train()
+    model._noise_override = {0: noise[0].cuda()}
+    loss, bd = model([[p.cuda() for p in s] for s in batch], times=times, return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    out = dict(loss=float(loss), text=float(bd.text), flow=[float(f) for f in bd.flow])
+    compare_losses(out, g)
+    wsum = nsum = 0.
+    for k, p in model.named_parameters():
+        kr = k.replace('latent_to_model_projs.0.', 'latent_to_model_projs.0.1.').replace('model_to_latent_projs.0.', 'model_to_latent_projs.0.0.')
+        if kr not in g['grad_norms'] or g['grad_norms'][kr] < 1e-7:
+            continue
+        r = rel(p.grad.float().reshape(-1)[:1024], g['grad_head'][kr])
+        assert abs(float(p.grad.double().norm()) - g['grad_norms'][kr]) <= GRAD_TOL * g['grad_norms'][kr], k
+        wsum += r * g['grad_norms'][kr]; nsum += g['grad_norms'][kr]
+    assert wsum / nsum <= GRAD_MEAN_TOL
+    with torch.no_grad():
+        flows = model([[p.cuda() for p in s] for s in batch], times=times, return_only_pred_flows=True)
+    assert [tuple(f.shape) for f in flows[0]] == g['pred_flow_shapes']                  # channel-first (16, L)
+    assert rel(flows[0][0].cpu(), g['pred_flow0']) <= 1.5e-2
+    model._noise_override = {0: nm.movedim(1, -1).reshape(-1, 16).cuda()}               # the reference's (b, d, L) noise as channel-last rows
+    lm = model.forward_modality(xm.cuda(), times=tm)
+    assert abs(float(lm.detach()) - float(g['mod_loss'])) <= 2e-3 * max(1., abs(float(g['mod_loss'])))
+    with torch.no_grad():
+        pm = model.forward_modality(xm.cuda(), times=tm, return_loss=False)
+    assert pm.shape == g['mod_pred_noloss'].shape and rel(pm.cpu(), g['mod_pred_noloss']) <= 1.5e-2
+    model._gen_noise_override = g0
+    gen = model.generate_modality_only(batch_size=2, fixed_modality_shape=(4,), modality_steps=g['gen_steps'])
+    assert gen.shape == g['gen'].shape and rel(gen.cpu(), g['gen']) <= 2e-2               # decoded: (2, 3, 4)
+    # sample_many: prompted raw modality is encoded, the decoded one comes back through the decoder, raw channel-first
+    model.eval()
+    res = model.sample_many([[torch.randint(0, 256, (5,)).cuda(), (0, torch.randn(3, 4).cuda())]], max_length=8, text_temperature=0., modality_steps=3,
+                            fixed_modality_shape=(4,), force_modality_at_start=0, cfg_scale=1.)
+    mods = [p for p in res[0] if isinstance(p, tuple)]
+    assert len(mods) >= 2 and all(m[1].shape == (3, 4) for m in mods)

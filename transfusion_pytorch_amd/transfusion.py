@@ -90,6 +90,8 @@ class Transfusion(nn.Module):
         super().__init__()
         self._init_kwargs = dict(num_text_tokens=num_text_tokens, transformer=transformer, model_output_clean=model_output_clean, dim_latent=dim_latent,
                                  channel_first_latent=channel_first_latent, add_pos_emb=add_pos_emb, modality_default_shape=modality_default_shape,
+                                 modality_encoder=modality_encoder, modality_decoder=modality_decoder,
+                                 modality_encoder_decoder_requires_batch_dim=modality_encoder_decoder_requires_batch_dim,
                                  fallback_to_default_shape_if_invalid=fallback_to_default_shape_if_invalid, modality_num_dim=modality_num_dim,
                                  to_modality_shape_fn=to_modality_shape_fn, ignore_index=ignore_index, flow_loss_weight=flow_loss_weight,
                                  text_loss_weight=text_loss_weight, velocity_consistency_loss_weight=velocity_consistency_loss_weight,
@@ -97,9 +99,7 @@ class Transfusion(nn.Module):
         assert modality_processing in PROCESSING_STRATEGIES, \
             f'unknown modality processing strategy `{modality_processing}`, available: {list(PROCESSING_STRATEGIES)}'      # MP:1254-1256
         self.modality_processing = modality_processing
-        unsupported = dict(channel_first_latent=any(cast_tuple(channel_first_latent)),
-                           add_pos_emb=any(cast_tuple(add_pos_emb)), modality_encoder=modality_encoder is not None,
-                           modality_decoder=modality_decoder is not None, pre_post_transformer_enc_dec=pre_post_transformer_enc_dec is not None,
+        unsupported = dict(add_pos_emb=any(cast_tuple(add_pos_emb)), pre_post_transformer_enc_dec=pre_post_transformer_enc_dec is not None,
                            reconstruction_loss_weight=reconstruction_loss_weight > 0.)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -117,6 +117,15 @@ class Transfusion(nn.Module):
             modality_default_shape = (modality_default_shape,) * self.num_modalities           # T:1362-1363
         self.modality_default_shape = modality_default_shape
         assert len(self.modality_default_shape) == self.num_modalities
+        # channel-first latents (T:1352, T:1481-1489) and frozen modality encoders / decoders (T:1405-1418): host-side layout / pre- and
+        # post-processing around the native path - the kernels always see (*axial, dim_latent) rows
+        self.channel_first_latent = cast_tuple(channel_first_latent, self.num_modalities)
+        assert len(self.channel_first_latent) == self.num_modalities
+        enc = cast_tuple(modality_encoder, 1 if modality_encoder is not None else self.num_modalities)
+        dec = cast_tuple(modality_decoder, 1 if modality_decoder is not None else self.num_modalities)
+        assert len(enc) == self.num_modalities and len(dec) == self.num_modalities
+        self.modality_encoder, self.modality_decoder = nn.ModuleList(enc), nn.ModuleList(dec)
+        self._enc_dec_batch_dim = bool(modality_encoder_decoder_requires_batch_dim)
         self.fallback_to_default_shape_if_invalid = fallback_to_default_shape_if_invalid
         if modality_num_dim is None:
             modality_num_dim = tuple(len(s) if s is not None else None for s in self.modality_default_shape)
@@ -139,6 +148,26 @@ class Transfusion(nn.Module):
         self.md = ModelDims(num_text_tokens=num_text_tokens, dim=dim, depth=transformer.depth, heads=transformer.heads,
                             dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor, model_output_clean=bool(model_output_clean), clean_eps=float(eps))
         self.store = ParamStore(self.md, self)
+        # state_dict names of a channel-first type's projections: the reference wraps them in nn.Sequential(Rearrange, Linear) / (Linear,
+        # Rearrange) (T:1481-1483), i.e. `latent_to_model_projs.t.1.*` and `model_to_latent_projs.t.0.*`: translate on load and on save
+        self._key_renames = {}
+        for t, cf in enumerate(self.channel_first_latent):
+            if cf:
+                self._key_renames[f'latent_to_model_projs.{t}.weight'] = f'latent_to_model_projs.{t}.1.weight'
+                self._key_renames[f'latent_to_model_projs.{t}.bias'] = f'latent_to_model_projs.{t}.1.bias'
+                self._key_renames[f'model_to_latent_projs.{t}.weight'] = f'model_to_latent_projs.{t}.0.weight'
+        if self._key_renames:
+            def _pre(state_dict, prefix, *a):
+                for ours, ref in self._key_renames.items():
+                    if prefix + ref in state_dict:
+                        state_dict[prefix + ours] = state_dict.pop(prefix + ref)
+            def _post(module, state_dict, prefix, local_metadata):
+                for ours, ref in self._key_renames.items():
+                    if prefix + ours in state_dict:
+                        state_dict[prefix + ref] = state_dict.pop(prefix + ours)
+                return state_dict
+            self._register_load_state_dict_pre_hook(_pre)
+            self._register_state_dict_hook(_post)
         self._plans = {}
         self._struct_cache = {}
         self._step_id = 0
@@ -167,6 +196,64 @@ class Transfusion(nn.Module):
 
     def vocab_size(self):
         return self.md.vocab
+
+    # ------------------------------------------------------------------ encoders / decoders / channel-first layout
+    def parameters_without_encoder_decoder(self):                     # T:1650-1655
+        return set(self.parameters()) - set(self.modality_encoder.parameters()) - set(self.modality_decoder.parameters())
+
+    def _apply_fn_modality_type(self, fn, samples, modality_type):
+        """apply_fn_modality_type (T:542-582): run `fn` on every modality of one type in a list of samples, same-shaped tensors stacked"""
+        single = bool(samples) and not isinstance(samples[0], list)
+        batch = [samples] if single else samples
+        groups = {}
+        for si, sample in enumerate(batch):
+            for pi, part in enumerate(sample):
+                if torch.is_tensor(part) and part.is_floating_point():
+                    part = (0, part)
+                if isinstance(part, tuple) and part[0] == modality_type:
+                    groups.setdefault(tuple(part[1].shape), []).append((si, pi, part[1]))
+        out = [list(sample) for sample in batch]
+        for shape, items in groups.items():
+            res = fn(torch.stack([x for _, _, x in items]))
+            for (si, pi, _), r in zip(items, res):
+                out[si][pi] = (modality_type, r)
+        return out[0] if single else out
+
+    def _encode_modalities(self, samples):
+        """frozen modality encoders (T:3094-3101), no gradients"""
+        for t, enc in enumerate(self.modality_encoder):
+            if enc is not None:
+                with torch.no_grad():
+                    enc.eval()
+                    samples = self._apply_fn_modality_type(enc, samples, t)
+        return samples
+
+    @torch.no_grad()
+    def decode_modalities(self, samples):                              # T:1826-1840
+        for t, dec in enumerate(self.modality_decoder):
+            if dec is not None:
+                dec.eval()
+                samples = self._apply_fn_modality_type(dec, samples, t)
+        return samples
+
+    def _to_channel_last(self, samples):
+        """(dim_latent, *axial) -> (*axial, dim_latent) for the channel-first modality types (T:1481-1489); no copy for the others"""
+        if not any(self.channel_first_latent):
+            return samples
+        out = []
+        for sample in samples:
+            s = []
+            for part in sample:
+                if torch.is_tensor(part) and part.is_floating_point():
+                    part = (0, part)
+                if isinstance(part, tuple) and self.channel_first_latent[part[0]]:
+                    part = (part[0], part[1].movedim(0, -1))
+                s.append(part)
+            out.append(s)
+        return out
+
+    def _from_channel_last(self, ty, x):
+        return x.movedim(-1, 0) if self.channel_first_latent[ty] else x
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -310,6 +397,12 @@ class Transfusion(nn.Module):
                                          return_hiddens=return_hiddens, return_kv_cache=return_kv_cache)
             return self.forward_modality(modalities, times=times, modality_type=modality_type, return_loss=return_loss,             # T:2989-2990
                                          velocity_consistency_ema_model=velocity_consistency_ema_model, return_loss_breakdown=return_breakdown)
+        is_decoding = decoding_text_or_modality is not None
+        if isinstance(modalities, list) and (any(self.channel_first_latent) or any(e is not None for e in self.modality_encoder)):
+            modalities = [list(sample) for sample in modalities]                           # T:3010-3012: never mutate the caller's lists
+            if not is_decoding:
+                modalities = self._encode_modalities(modalities)                           # T:3094-3101
+            modalities = self._to_channel_last(modalities)
         if cache is not None or decoding_text_or_modality is not None or return_kv_cache or return_hiddens:
             if return_loss and not return_embed:
                 raise NotImplementedError('kv cache / hiddens are returned by the inference forward only (return_loss = False or return_embed = True), '
@@ -406,7 +499,7 @@ class Transfusion(nn.Module):
             for gi in range(len(P.inst_b)):
                 t, L = int(P.inst_type[gi]), int(P.inst_len[gi])
                 rows = plan.lat[t]['pred'][cursor[t]:cursor[t] + L]; cursor[t] += L
-                out[t].append(rows.view(*P.inst_shape[gi], md.dim_latents[t]).clone())
+                out[t].append(self._from_channel_last(t, rows.view(*P.inst_shape[gi], md.dim_latents[t]).clone()))
             return out
 
         # ---- loss seeds (the token-count normalisers cancel: d loss / d logit = w / total_tokens, T:3331)
@@ -688,6 +781,13 @@ class Transfusion(nn.Module):
             raise AssertionError('`modality_type` must be explicitly passed in on forward when training on greater than 1 modality')
         t = 0 if modality_type is None else int(modality_type)
         dev, stream, md = self.device, self._stream(), self.md
+        modalities = modalities.to(dev)
+        if encode_modality and self.modality_encoder[t] is not None:                       # T:2735-2738
+            with torch.no_grad():
+                self.modality_encoder[t].eval()
+                modalities = self.modality_encoder[t](modalities).detach()
+        if self.channel_first_latent[t]:
+            modalities = modalities.movedim(1, -1)                                         # (b, d, *axial) -> (b, *axial, d)
         x = modalities.to(dev, torch.float32)
         dl = md.dim_latents[t]
         assert x.shape[-1] == dl, f'last dimension must be dim_latent = {dl}'
@@ -725,7 +825,8 @@ class Transfusion(nn.Module):
         if not return_loss:
             plan.set_noise(t, None)                                                  # T:2759-2760: no noising
             Plan.run(plan.fwd, stream, 0, plan.fwd_pred_end)
-            return lt['pred'].view(x.shape).clone()
+            out = lt['pred'].view(x.shape).clone()
+            return out.movedim(-1, 1) if self.channel_first_latent[t] else out
         if self._noise_override is not None:
             lt['eps'].copy_(self._noise_override[t].reshape(rows, dl))
         else:
@@ -746,8 +847,11 @@ class Transfusion(nn.Module):
             ema.eval()
             try:
                 with torch.no_grad():
-                    teacher = ema.forward_modality(x.view(modalities.shape), times=orig_times + velocity_consistency_delta_time, modality_type=t,
-                                                   encode_modality=False, return_loss=False)
+                    xin = x.view(modalities.shape)
+                    teacher = ema.forward_modality(xin.movedim(-1, 1) if self.channel_first_latent[t] else xin, times=orig_times + velocity_consistency_delta_time,
+                                                   modality_type=t, encode_modality=False, return_loss=False)
+                    if self.channel_first_latent[t]:
+                        teacher = teacher.movedim(1, -1)
             finally:
                 ema.train(was_training)
             lt['vel'].copy_(teacher.reshape(rows, dl))
@@ -780,6 +884,8 @@ class Transfusion(nn.Module):
         dev = self.device
         y = self._gen_noise_override.to(dev, torch.float32).clone() if getattr(self, '_gen_noise_override', None) is not None \
             else torch.randn((batch_size, *shape, self.md.dim_latents[t]), device=dev)
+        if self.channel_first_latent[t]:
+            y = y.movedim(-1, 1).contiguous()                                               # T:2892-2893
         was_training = self.training
         self.eval()
         try:
@@ -791,6 +897,9 @@ class Transfusion(nn.Module):
                 y = y + dt * f(t0 + dt * 0.5, y_mid)
         finally:
             self.train(was_training)
+        if self.modality_decoder[t] is not None:                                           # T:2917-2921
+            self.modality_decoder[t].eval()
+            y = self.modality_decoder[t](y)
         return y
 
     def _native_backward(self, grad_out, step_id):
@@ -839,9 +948,25 @@ class Transfusion(nn.Module):
         was_training = self.training
         self.eval()                                              # @temp_eval in the reference
         try:
-            return Sampler(self).sample_many(prompts, max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
-                                             fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
-                                             init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale)
+            special = any(self.channel_first_latent) or any(e is not None for e in self.modality_encoder) or any(d is not None for d in self.modality_decoder)
+            if special and prompts is not None:
+                # prompted modalities: frozen encoder first (prepare_prompt_sample, T:1755-1758), then the kernels' channel-last layout
+                norm = []
+                for pr in (prompts if isinstance(prompts, list) else [prompts]):
+                    parts = [pr] if (isinstance(pr, tuple) or torch.is_tensor(pr)) else (list(pr) if pr is not None else None)
+                    if parts is not None:
+                        parts = self._to_channel_last(self._encode_modalities([parts]))[0]
+                        parts = parts[0] if (isinstance(pr, tuple) or torch.is_tensor(pr)) else parts
+                    norm.append(parts)
+                prompts = norm
+            out = Sampler(self).sample_many(prompts, max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
+                                            fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
+                                            init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale)
+            if special:
+                out = [[(p[0], self._from_channel_last(p[0], p[1])) if isinstance(p, tuple) else p for p in sample] for sample in out]
+                if not return_unprocessed_modalities:
+                    out = self.decode_modalities(out)                                       # T:2581-2583
+            return out
         finally:
             self.train(was_training)
 
