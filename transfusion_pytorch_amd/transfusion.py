@@ -334,11 +334,12 @@ class Transfusion(nn.Module):
         dev, stream = self.device, self._stream()
         sig, user_text, latents = fast_signature(samples)
         key = (sig, 'plain', add_meta, pad_n)
-        S = self._struct_cache.get(key)
+        S = self._struct_cache.pop(key, None)
         if S is None:
-            if len(self._struct_cache) > 16:
-                self._struct_cache.clear()
-            S = self._struct_cache[key] = self._build_structure(samples, False, add_meta=add_meta, pad_n=pad_n)
+            while len(self._struct_cache) >= 32:
+                self._struct_cache.pop(next(iter(self._struct_cache)))
+            S = self._build_structure(samples, False, add_meta=add_meta, pad_n=pad_n)
+        self._struct_cache[key] = S
         tm, b, n, I, R = S['tm'], S['b'], S['n'], S['I'], S['R']
         self.store.refresh_shadows(stream)
         # The prefill plans of a decode loop differ only in their instance / latent-row counts from one modality phase to the next: round
@@ -426,11 +427,13 @@ class Transfusion(nn.Module):
         # ---- structure: one cheap signature pass; everything derived from it is cached ON THE DEVICE per signature
         sig, user_text, latents = fast_signature(modalities)
         add_meta = return_loss or not return_embed           # MP:330: `return_embed` (the decode-time call) packs WITHOUT [meta][shape][som] ... [eom]
-        S = self._struct_cache.get((sig, return_loss, add_meta))
+        skey = (sig, return_loss, add_meta)
+        S = self._struct_cache.pop(skey, None)
         if S is None:
-            if len(self._struct_cache) > 16:
-                self._struct_cache.clear()
-            S = self._struct_cache[(sig, return_loss, add_meta)] = self._build_structure(modalities, return_loss, add_meta=add_meta)
+            while len(self._struct_cache) >= 32:                      # least recently used structure goes first (dict order = use order)
+                self._struct_cache.pop(next(iter(self._struct_cache)))
+            S = self._build_structure(modalities, return_loss, add_meta=add_meta)
+        self._struct_cache[skey] = S
         P, tm, b, n, I, R = S['P'], S['tm'], S['b'], S['n'], S['I'], S['R']
 
         # ---- times (T:3075-3082)
