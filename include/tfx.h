@@ -295,6 +295,16 @@ int tfx_adam_step(const tfx_adam_args* a, void* stream);
  * Transfusion.create_ema T:1681-1699) */
 int tfx_ema_update(float* ema, const float* online, int64_t n, float decay, void* stream);
 
+/* ---- data-parallel gradient exchange -----------------------------------
+ * ONE all-reduce(sum) per range of the flat fp32 gradient buffer over RCCL / xGMI, one process per GPU (reference practice: DDP under
+ * `accelerate`, train_mnist.py:114-126).  RCCL is bound at run time (dlopen), so a host that already carries a copy keeps using it.
+ *   rank 0: tfx_allreduce_unique_id(id);  broadcast the 128 bytes by any host channel;  every rank: tfx_allreduce_init(rank, world, id)
+ *   per step: tfx_allreduce_run(grad + offset, count, stream)  (in place, enqueued on `stream`; scale by 1 / world in tfx_adam_step.grad_scale) */
+int tfx_allreduce_unique_id(void* out128);
+int tfx_allreduce_init(int32_t rank, int32_t world, const void* unique_id128);
+int tfx_allreduce_run(float* buf, int64_t count, void* stream);
+int tfx_allreduce_destroy(void);
+
 /* ---- launch lists ------------------------------------------------------------------------------
  * The step is a STATIC list of launches over persistent buffers (engine.Plan), so the host replays it with ONE call instead of one
  * FFI round trip per kernel: `tfx_run_list` walks `n` items in order on `stream` (or the side stream, per item) and stops at the first non-zero return code

@@ -633,3 +633,23 @@ def test_ode_axpy_with_guidance():
     assert torch.allclose(out, y + 0.25 * (fu + 3. * (fc - fu)), rtol=1e-6, atol=1e-6)
     capi.check(lib.tfx_ode_axpy(y.data_ptr(), fc.data_ptr(), None, 3., -0.5, out.data_ptr(), y.numel(), ctypes.c_void_p(stream())), 'plain')
     assert torch.allclose(out, y - 0.5 * fc, rtol=1e-6, atol=1e-6)
+
+
+def test_allreduce_entry_points_world1():
+    """K12: tfx_allreduce_unique_id / _init / _run / _destroy on a real RCCL communicator of ONE rank (the box has one GPU; the
+    N > 1 exchange is covered on gloo, tests/test_dp_gloo.py, and by the driver's scaling run): the sum over one rank is the identity."""
+    import ctypes
+    lib = capi.lib()
+    uid = (ctypes.c_char * 128)()
+    capi.check(lib.tfx_allreduce_unique_id(ctypes.byref(uid)), 'unique_id')
+    capi.check(lib.tfx_allreduce_init(0, 1, ctypes.byref(uid)), 'init')
+    try:
+        g = torch.randn(1 << 20, device=DEV)
+        want = g.clone()
+        capi.check(lib.tfx_allreduce_run(g.data_ptr(), g.numel(), ctypes.c_void_p(stream())), 'run')
+        capi.check(lib.tfx_allreduce_run(g[1000:].data_ptr(), 4096, ctypes.c_void_p(stream())), 'run (range)')
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+    finally:
+        capi.check(lib.tfx_allreduce_destroy(), 'destroy')
+    assert lib.tfx_allreduce_run(g.data_ptr(), 16, ctypes.c_void_p(stream())) != 0        # no communicator: refused

@@ -9,17 +9,17 @@ mkdir -p $W/pkg/csrc $W/include          # the sources include "../../include/tf
 if [ "$REV" = WORK ]; then
   cp $R/transfusion_pytorch_amd/csrc/* $W/pkg/csrc/; cp $R/include/tfx.h $W/include/
 else
-  for f in gemm.hip attention.hip tokenwise.hip decode.hip runner.hip tfx_common.h tfx_kernels.h; do git -C $R show $REV:transfusion_pytorch_amd/csrc/$f > $W/pkg/csrc/$f 2>/dev/null || rm -f $W/pkg/csrc/$f; done
+  for f in gemm.hip attention.hip tokenwise.hip decode.hip collective.hip runner.hip tfx_common.h tfx_kernels.h; do git -C $R show $REV:transfusion_pytorch_amd/csrc/$f > $W/pkg/csrc/$f 2>/dev/null || rm -f $W/pkg/csrc/$f; done
   git -C $R show $REV:include/tfx.h > $W/include/tfx.h
 fi
 OBJS=""
-for s in gemm attention tokenwise decode runner; do
+for s in gemm attention tokenwise decode collective runner; do
   [ -f $W/pkg/csrc/$s.hip ] || continue
   FF=""; [ $s = attention ] && [ "$REV" = WORK ] && FF="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $FF "$@" -c $W/pkg/csrc/$s.hip -o $W/$s.o &
   OBJS="$OBJS $W/$s.o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $R/transfusion_pytorch_amd/lib/libtfx_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $R/transfusion_pytorch_amd/lib/libtfx_$NAME.so
 rm -rf $W
 echo built $R/transfusion_pytorch_amd/lib/libtfx_$NAME.so

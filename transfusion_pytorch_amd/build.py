@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libtfx_hip.so')
-SOURCES = ['gemm.hip', 'attention.hip', 'tokenwise.hip', 'decode.hip', 'runner.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'tokenwise.hip', 'decode.hip', 'collective.hip', 'runner.hip']
 HEADERS = [os.path.join(CSRC, 'tfx_common.h'), os.path.join(CSRC, 'tfx_kernels.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'tfx.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result'] + os.environ.get('TFX_HIPCC_EXTRA', '').split()   # e.g. -DTFX_PP_TIMING (tools/pp_timing.py)
@@ -55,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for pr, s in procs:
         if pr.wait() != 0:
             raise RuntimeError(f'hipcc failed on {s}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB]
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-ldl', '-o', LIB]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
