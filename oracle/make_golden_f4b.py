@@ -1,0 +1,180 @@
+"""Goldens for SURVEY 8(f) rank 4, second half: `add_pos_emb` (T:1384-1403, T:2781-2796, T:3173-3180) and learnable
+`pre_post_transformer_enc_dec` pairs (the paper's U-Net down / up, T:1451-1494, MP:715-745) from the UNMODIFIED reference - build container
+only.   python -m oracle.make_golden_f4b
+
+Two models:
+  pos   one channel-last modality type (dim_latent 16, 2 axial dims) with the axial positional embedding: interleaved training step,
+        forward_modality, greedy `sample_one` (the reference's sampler that adds the embedding during the ODE steps, through forward())
+  unet  one channel-first type (4, H, W) with Conv2d(4 -> dim, 3, stride 2) / ConvTranspose2d(dim -> 4) around the transformer AND the positional
+        embedding on the down-sampled grid: interleaved training step with text, forward_modality, generate_modality_only
+The positional-embedding module on both sides is the repo's restatement (oracle/shims/axial_positional_embedding): its arithmetic is unpinned,
+everything around it is the reference's.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch import nn
+
+from . import detdata as D
+from .ref_runner import import_reference
+from .transfusion_oracle import OracleConfig
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+POS_CFG = dict(num_text_tokens=256, dim=128, depth=2, dim_latents=(16,), heads=2, dim_head=64)
+UNET_CFG = dict(num_text_tokens=256, dim=128, depth=2, dim_latents=(4,), heads=2, dim_head=64)
+GEN_STEPS = 3
+
+
+def fill_module_(mod, tag, scale=0.3):
+    """deterministic values for every parameter of a torch module (the positional-embedding MLPs, the conv pair)"""
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            p.copy_(D.det_uniform(f'{tag}/{name}', tuple(p.shape), -scale, scale))
+
+
+def base_sd(cfg, tag, drop_proj=False):
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag=tag)
+    if drop_proj:
+        sd = {k: v for k, v in sd.items() if not k.startswith(('latent_to_model_projs', 'model_to_latent_projs'))}
+    return sd
+
+
+def pos_case():
+    cfg = OracleConfig(**POS_CFG)
+    sd = base_sd(cfg, 'f4b/pos')
+    lat = lambda key, shape: D.det_normalish(key, (*shape, 16))
+    batch = [[D.det_randint('f4b/t0', (5,), 0, 256), (0, lat('f4b/m0', (2, 3))), D.det_randint('f4b/t1', (3,), 0, 256), (0, lat('f4b/m1', (3, 2)))],
+             [(0, lat('f4b/m2', (2, 3))), D.det_randint('f4b/t2', (7,), 0, 256)],
+             [D.det_randint('f4b/t3', (9,), 0, 256)]]
+    times = D.det_uniform('f4b/times', (3, 2), 0.05, 0.95)
+    noise = D.det_normalish('f4b/noise', (18, 16))                     # flat (R, dim_latent) rows in scan order (MP:654)
+    xm = D.det_normalish('f4b/xm', (2, 2, 3, 16)); nm = D.det_normalish('f4b/nm', (2, 2, 3, 16)); tm = torch.tensor([0.3, 0.8])
+    prompt = D.det_randint('f4b/prompt', (6,), 0, 256)
+    init_noise = D.det_normalish('f4b/init', (6, 16))
+    return cfg, sd, batch, times, noise, xm, nm, tm, prompt, init_noise
+
+
+def unet_modules(dim):
+    enc, dec = nn.Conv2d(4, dim, 3, 2, 1), nn.ConvTranspose2d(dim, 4, 3, 2, 1, output_padding=1)
+    fill_module_(enc, 'f4b/unet/enc', 0.15); fill_module_(dec, 'f4b/unet/dec', 0.05)
+    return enc, dec
+
+
+def unet_case():
+    cfg = OracleConfig(**UNET_CFG)
+    sd = base_sd(cfg, 'f4b/unet', drop_proj=True)
+    img = lambda key, hw: D.det_normalish(key, (4, *hw))
+    batch = [[D.det_randint('f4b/u/t0', (5,), 0, 256), (0, img('f4b/u/m0', (8, 8))), D.det_randint('f4b/u/t1', (3,), 0, 256)],
+             [(0, img('f4b/u/m1', (4, 8))), D.det_randint('f4b/u/t2', (4,), 0, 256), (0, img('f4b/u/m2', (8, 8)))]]
+    times = D.det_uniform('f4b/u/times', (2, 2), 0.05, 0.95)
+    noises = [D.det_normalish(f'f4b/u/n{i}', s) for i, s in enumerate([(4, 8, 8), (4, 4, 8), (4, 8, 8)])]      # per instance, scan order (MP:716)
+    xm = D.det_normalish('f4b/u/xm', (2, 4, 8, 8)); nm = D.det_normalish('f4b/u/nm', (2, 4, 8, 8)); tm = torch.tensor([0.3, 0.8])
+    g0 = D.det_normalish('f4b/u/gen', (2, 8, 8, 4))                      # generate_modality_only noise before the channel-first rearrange (T:2890)
+    return cfg, sd, batch, times, noises, xm, nm, tm, g0
+
+
+class patched:
+    """torch.randn_like / torch.randn replaced by a queue of prepared tensors (checked by shape)"""
+
+    def __init__(self, name, queue):
+        self.name, self.queue = name, list(queue)
+
+    def __enter__(self):
+        self.orig = getattr(torch, self.name)
+        def fake(*a, **k):
+            v = self.queue.pop(0)
+            shape = tuple(a[0].shape) if torch.is_tensor(a[0]) else tuple(a[0] if isinstance(a[0], (tuple, list)) else a)
+            assert tuple(v.shape) == shape, (tuple(v.shape), shape)
+            return v.clone()
+        setattr(torch, self.name, fake)
+        return self
+
+    def __exit__(self, *a):
+        setattr(torch, self.name, self.orig)
+
+
+def grads_of(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def summarize(grads):
+    """norm of every gradient + the head of a few: enough to pin the backward without storing it all"""
+    out = {k: g.norm() for k, g in grads.items()}
+    heads = {k: g.reshape(-1)[:64].clone() for k, g in grads.items()
+             if k.startswith(('pos_emb_mlp', 'latent_to_model_projs', 'model_to_latent_projs')) or k in ('text_embed.weight', 'transformer.layers.0.1.fn.to_qk.0.weight')}
+    return out, heads
+
+
+def make_pos():
+    tp = import_reference()
+    cfg, sd, batch, times, noise, xm, nm, tm, prompt, init_noise = pos_case()
+    model = tp.Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=16, modality_default_shape=(2, 3), add_pos_emb=True, modality_num_dim=2,
+                           modality_processing='flat', prob_uncond=0.,
+                           transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith('pos_emb_mlp') for k in missing), (missing, unexpected)
+    fill_module_(model.pos_emb_mlp, 'f4b/pos/mlp')
+    pos_sd = {k: v.clone() for k, v in model.state_dict().items() if k.startswith('pos_emb_mlp')}
+    model.train()
+    with patched('randn_like', [noise]):
+        loss, bd = model(batch, times=times, return_breakdown=True)
+    loss.backward()
+    gn, gh = summarize(grads_of(model))
+    model.zero_grad(set_to_none=True)
+    with patched('randn_like', [nm]):
+        lm = model.forward_modality(xm, times=tm)
+    lm.backward()
+    gn_m, gh_m = summarize(grads_of(model))
+    model.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        pm = model.forward_modality(xm, times=tm, return_loss=False)
+        logits = model(batch, times=times, return_loss=False)
+    # greedy sample_one: text is deterministic at temperature 0; the modality noise is injected
+    torch.manual_seed(0)
+    out = model.sample_one(prompt, max_length=14, text_temperature=0., init_modality_noise=init_noise, modality_steps=GEN_STEPS, fixed_modality_shape=(2, 3),
+                           cfg_scale=1., force_modality_at_start=0, cache_kv=True)
+    parts = [(p if not isinstance(p, tuple) else ('mod', p[0], p[1])) for p in out]
+    torch.save(dict(pos_sd=pos_sd, loss=loss.detach(), text_loss=bd.text.detach(), flow_losses=[f.detach() for f in bd.flow], grad_norms=gn, grad_heads=gh,
+                    fm_loss=lm.detach(), fm_grad_norms=gn_m, fm_grad_heads=gh_m, fm_pred=pm, logits=logits, sample=parts),
+               os.path.join(OUT, 'f4b_pos.pt'))
+    print('pos: loss', float(loss), 'fm', float(lm), 'sample', [p.shape if torch.is_tensor(p) else p[2].shape for p in parts])
+
+
+def make_unet():
+    tp = import_reference()
+    cfg, sd, batch, times, noises, xm, nm, tm, g0 = unet_case()
+    enc, dec = unet_modules(cfg.dim)
+    model = tp.Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=4, modality_default_shape=(8, 8), channel_first_latent=True,
+                           pre_post_transformer_enc_dec=(enc, dec), add_pos_emb=True, modality_num_dim=2, modality_processing='flat', prob_uncond=0.,
+                           transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(('pos_emb_mlp', 'latent_to_model_projs', 'model_to_latent_projs')) for k in missing), (missing, unexpected)
+    fill_module_(model.pos_emb_mlp, 'f4b/unet/mlp')
+    ext_sd = {k: v.clone() for k, v in model.state_dict().items() if k.startswith(('pos_emb_mlp', 'latent_to_model_projs', 'model_to_latent_projs'))}
+    model.train()
+    with patched('randn_like', noises):
+        loss, bd = model(batch, times=times, return_breakdown=True)
+    loss.backward()
+    gn, gh = summarize(grads_of(model))
+    model.zero_grad(set_to_none=True)
+    with patched('randn_like', [nm]):
+        lm = model.forward_modality(xm, times=tm)
+    lm.backward()
+    gn_m, gh_m = summarize(grads_of(model))
+    model.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        pm = model.forward_modality(xm, times=tm, return_loss=False)
+        logits = model(batch, times=times, return_loss=False)
+    with patched('randn', [g0]):
+        gen = model.generate_modality_only(batch_size=2, modality_steps=GEN_STEPS)
+    torch.save(dict(ext_sd=ext_sd, loss=loss.detach(), text_loss=bd.text.detach(), flow_losses=[f.detach() for f in bd.flow], grad_norms=gn, grad_heads=gh,
+                    fm_loss=lm.detach(), fm_grad_norms=gn_m, fm_grad_heads=gh_m, fm_pred=pm, logits=logits, gen=gen),
+               os.path.join(OUT, 'f4b_unet.pt'))
+    print('unet: loss', float(loss), 'fm', float(lm), 'gen', tuple(gen.shape), 'logits', tuple(logits.shape))
+
+
+if __name__ == '__main__':
+    make_pos()
+    make_unet()

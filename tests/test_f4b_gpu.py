@@ -1,0 +1,174 @@
+"""SURVEY 8(f) rank 4, second half: `add_pos_emb` (axial positional embedding, T:1384-1403 / T:2781-2796 / T:3173-3180) and learnable
+`pre_post_transformer_enc_dec` pairs (T:1451-1494, MP:715-745) around the native engine - goldens from the UNMODIFIED reference
+(oracle/make_golden_f4b.py -> tests/golden/f4b_pos.pt, f4b_unet.pt).
+
+What is native here: everything between the token rows and the final embedding rows, forward and backward, including the ADD of the
+positional rows into the packed stream and the gradients back out to the rows (identity-GEMM mapped RESID epilogue).  What is PyTorch: the
+positional MLP (a few hundred rows) and the user's conv encoder / decoder.  Tolerances as in tests/test_model_gpu.py (bf16 vs fp32)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.make_golden_f4b import GEN_STEPS, pos_case, unet_case, unet_modules      # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+GRAD_TOL, GRAD_MEAN_TOL, GRAD_HEAD_TOL = 4e-2, 1.2e-2, 6e-2
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def close(a, r, what):
+    a, r = float(a.detach()) if torch.is_tensor(a) else float(a), float(r)
+    print(f'  {what}: native {a:.6f} reference {r:.6f} delta {a - r:+.2e}')
+    assert abs(a - r) <= 2e-3 * max(1., abs(r)), what
+
+
+def check_grads(model, norms, heads, what):
+    wsum = nsum = 0.
+    worst = ('', 0.)
+    for k, p in model.named_parameters():
+        if k not in norms or float(norms[k]) < 1e-6:
+            continue
+        assert p.grad is not None, f'{what}: no gradient for {k}'
+        gn = float(p.grad.double().norm())
+        assert abs(gn - float(norms[k])) <= GRAD_TOL * float(norms[k]), (what, k, gn, float(norms[k]))
+        if k in heads:
+            r = rel(p.grad.float().reshape(-1)[:64], heads[k])
+            if r > worst[1]:
+                worst = (k, r)
+            assert r <= GRAD_HEAD_TOL, (what, k, r)
+            wsum += r * float(norms[k]); nsum += float(norms[k])
+    print(f'  {what}: gradient heads worst {worst[0]} {worst[1]:.2e}, norm-weighted mean {wsum / max(nsum, 1e-30):.2e}')
+    assert wsum / nsum <= GRAD_MEAN_TOL
+    missing = [k for k in norms if float(norms[k]) >= 1e-6 and k not in dict(model.named_parameters())]
+    assert not missing, missing
+
+
+def to_cuda(batch):
+    return [[(p[0], p[1].cuda()) if isinstance(p, tuple) else p.cuda() for p in s] for s in batch]
+
+
+def test_axial_positional_embedding_matches_reference_golden():
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.optim import FusedAdam
+    g = torch.load(os.path.join(GOLDEN, 'f4b_pos.pt'), weights_only=False)
+    cfg, sd, batch, times, noise, xm, nm, tm, prompt, init_noise = pos_case()
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=16, modality_default_shape=(2, 3), add_pos_emb=True, modality_num_dim=2, prob_uncond=0.,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    model.load_state_dict({**sd, **g['pos_sd']}, strict=True)
+    model = model.cuda().train()
+    model._noise_override = {0: noise.cuda()}
+    loss, bd = model(to_cuda(batch), times=times, return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    print('[pos] interleaved step')
+    close(loss, g['loss'], 'loss'); close(bd.text, g['text_loss'], 'text'); close(bd.flow[0], g['flow_losses'][0], 'flow')
+    check_grads(model, g['grad_norms'], g['grad_heads'], 'interleaved')
+    assert any(k.startswith('pos_emb_mlp') and float(v) > 1e-6 for k, v in g['grad_norms'].items())
+    with torch.no_grad():
+        logits = model(to_cuda(batch), times=times, return_loss=False)
+    assert logits.shape == g['logits'].shape and rel(logits, g['logits']) <= 1e-2
+    for p in model.parameters():
+        p.grad = None
+    model._noise_override = {0: nm.reshape(-1, 16).cuda()}
+    lm = model.forward_modality(xm.cuda(), times=tm)
+    lm.backward()
+    print('[pos] forward_modality')
+    close(lm, g['fm_loss'], 'loss')
+    check_grads(model, g['fm_grad_norms'], g['fm_grad_heads'], 'forward_modality')
+    with torch.no_grad():
+        pm = model.forward_modality(xm.cuda(), times=tm, return_loss=False)
+    assert pm.shape == g['fm_pred'].shape and rel(pm, g['fm_pred']) <= 1.5e-2
+    # the fused optimizer steps the MLP too (stock Adam under the same global clip coefficient)
+    before = {k: v.detach().clone() for k, v in model.pos_emb_mlp.state_dict().items()}
+    flat_before = model.store.flat.clone()
+    opt = FusedAdam(model, lr=1e-3, max_grad_norm=0.5)
+    assert len(opt.ext_params) == len(list(model.pos_emb_mlp.parameters())) > 0
+    opt.step(); opt.zero_grad()
+    assert any(not torch.equal(before[k], v) for k, v in model.pos_emb_mlp.state_dict().items()) and not torch.equal(flat_before, model.store.flat)
+    assert all(p.grad is None for p in model.parameters())
+
+
+def test_sample_one_adds_positional_embedding_like_the_reference():
+    """the reference's `sample_one` (= `sample`) goes through forward() and adds the embedding to the block being decoded (T:3179-3180); its
+    `sample_many` does not (T:2436-2444).  Greedy text + injected modality noise: the decoded modality must match the reference's `sample_one`."""
+    from transfusion_pytorch_amd import Transfusion
+    g = torch.load(os.path.join(GOLDEN, 'f4b_pos.pt'), weights_only=False)
+    cfg, sd, batch, times, noise, xm, nm, tm, prompt, init_noise = pos_case()
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=16, modality_default_shape=(2, 3), add_pos_emb=True, modality_num_dim=2, prob_uncond=0.,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    model.load_state_dict({**sd, **g['pos_sd']}, strict=True)
+    model = model.cuda().eval()
+    kw = dict(max_length=14, text_temperature=0., init_modality_noise=init_noise, modality_steps=GEN_STEPS, fixed_modality_shape=(2, 3), cfg_scale=1.,
+              force_modality_at_start=0)
+    ref = g['sample']
+    ref_mod = next(p for p in ref if isinstance(p, tuple))
+    out_one = model.sample_one(prompt.cuda(), **kw)
+    out_many = model.sample_many([prompt.cuda()], **kw)[0]
+    through = model._sample_one_through_forward(prompt.cuda(), cache_kv=True, **kw)
+    mod = lambda parts: next(p for p in parts if isinstance(p, tuple))
+    e_one, e_many, e_thr = rel(mod(out_one)[1], ref_mod[2]), rel(mod(out_many)[1], ref_mod[2]), rel(mod(through)[1], ref_mod[2])
+    print(f'decoded modality vs reference sample_one: sample_one {e_one:.2e}, forward()-loop {e_thr:.2e}, sample_many (no embedding in the ODE) {e_many:.2e}')
+    assert mod(out_one)[1].shape == ref_mod[2].shape == (2, 3, 16)
+    assert e_one <= 3e-2 and e_thr <= 3e-2
+    assert e_many > 2 * e_one            # the two reference samplers really differ; each entry point follows its own
+    assert out_one[0].tolist() == ref[0].tolist()          # prompt + [meta] shape [som]: forced, identical
+
+
+def test_unet_encoder_decoder_around_the_transformer_matches_reference_golden():
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.optim import FusedAdam
+    g = torch.load(os.path.join(GOLDEN, 'f4b_unet.pt'), weights_only=False)
+    cfg, sd, batch, times, noises, xm, nm, tm, g0 = unet_case()
+    enc, dec = unet_modules(cfg.dim)
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=4, modality_default_shape=(8, 8), channel_first_latent=True,
+                        pre_post_transformer_enc_dec=(enc, dec), add_pos_emb=True, modality_num_dim=2, prob_uncond=0.,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    # the reference's key names for the wrapped conv pair load unchanged: Sequential(enc, Rearrange) -> `.0.0.*`, Sequential(Rearrange, dec) -> `.0.1.*`
+    assert {'latent_to_model_projs.0.0.weight', 'model_to_latent_projs.0.1.weight'} <= set(g['ext_sd'])
+    model.load_state_dict({**sd, **g['ext_sd']}, strict=True)
+    model = model.cuda().train()
+    model._noise_override = {0: [n.cuda() for n in noises]}
+    loss, bd = model(to_cuda(batch), times=times, return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    print('[unet] interleaved step')
+    close(loss, g['loss'], 'loss'); close(bd.text, g['text_loss'], 'text'); close(bd.flow[0], g['flow_losses'][0], 'flow')
+    check_grads(model, g['grad_norms'], g['grad_heads'], 'interleaved')
+    with torch.no_grad():
+        logits = model(to_cuda(batch), times=times, return_loss=False)
+    assert logits.shape == g['logits'].shape and rel(logits, g['logits']) <= 1e-2      # packed with the PROJECTED (down-sampled) lengths, MP:738-741
+    for p in model.parameters():
+        p.grad = None
+    model._noise_override = {0: nm.cuda()}
+    lm = model.forward_modality(xm.cuda(), times=tm)
+    lm.backward()
+    print('[unet] forward_modality')
+    close(lm, g['fm_loss'], 'loss')
+    check_grads(model, g['fm_grad_norms'], g['fm_grad_heads'], 'forward_modality')
+    with torch.no_grad():
+        pm = model.forward_modality(xm.cuda(), times=tm, return_loss=False)
+    assert pm.shape == g['fm_pred'].shape and rel(pm, g['fm_pred']) <= 1.5e-2
+    model._gen_noise_override = g0
+    gen = model.generate_modality_only(batch_size=2, modality_steps=GEN_STEPS)
+    assert gen.shape == g['gen'].shape == (2, 4, 8, 8) and rel(gen, g['gen']) <= 2e-2
+    # one optimizer step moves the conv pair, the MLP and the flat buffer; the EMA copy owns its own modules
+    opt = FusedAdam(model, lr=1e-3, max_grad_norm=0.5)
+    w0 = model.latent_to_model_projs[0][0].weight.detach().clone()
+    opt.step(); opt.zero_grad()
+    assert not torch.equal(w0, model.latent_to_model_projs[0][0].weight)
+    ema = model.create_ema()
+    assert ema.ema_model.latent_to_model_projs[0][0].weight.data_ptr() != model.latent_to_model_projs[0][0].weight.data_ptr()
+    assert torch.equal(ema.ema_model.latent_to_model_projs[0][0].weight, model.latent_to_model_projs[0][0].weight)
+    with pytest.raises(NotImplementedError):
+        model.sample_many([prompt_ids()], max_length=4)
+
+
+def prompt_ids():
+    return torch.randint(0, 256, (4,)).cuda()

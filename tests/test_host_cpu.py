@@ -127,6 +127,8 @@ def test_unsupported_options_raise_and_no_cpu_fallback():
         Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1, dim_head=128))   # kernels hold 64 columns per head
     Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=2, dim_head=8, use_flex_attn=True))   # small heads run zero-padded; flex = backend name only
     with pytest.raises(NotImplementedError):
+        Transfusion(num_text_tokens=8, dim_latent=16, reconstruction_loss_weight=0.1, transformer=dict(dim=64, depth=1, heads=1))
+    with pytest.raises(AssertionError):                   # T:1396: the positional embedding needs the number of axial dimensions
         Transfusion(num_text_tokens=8, dim_latent=16, add_pos_emb=True, transformer=dict(dim=64, depth=1, heads=1))
     m = Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1))
     with pytest.raises(capi.TfxError):
@@ -167,3 +169,42 @@ def test_default_times_match_reference_golden():
         assert not pu.queue
     assert torch.equal(times.cpu(), g['times'])
     assert model._default_times(np.zeros(3, dtype=np.int64)).shape == (3, 0)          # T:189-190
+
+
+def test_axial_positional_embedding_and_external_encoder_wiring():
+    """host side of `add_pos_emb` / `pre_post_transformer_enc_dec` (T:1384-1403, T:1451-1494): the embedding of a position is the sum of its
+    per-axis vectors, row-major over the axes; factorised evaluation at the maximum extents + slicing gives the same rows (MP:1003-1045); the user's
+    encoder / decoder take the reference's attribute names (so its checkpoints load), own no entry in the flat buffer, and the packer sees the
+    PROJECTED axial shape (MP:738-741)."""
+    from torch import nn
+    from transfusion_pytorch_amd.axial import ContinuousAxialPositionalEmbedding
+    pe = ContinuousAxialPositionalEmbedding(dim=32, num_axial_dims=2)
+    rows = pe((3, 4), flatten=True)
+    fac = pe((5, 6), return_factorized=True)
+    assert rows.shape == (12, 32) and [tuple(f.shape) for f in fac] == [(5, 32), (6, 32)]
+    assert torch.allclose(rows, pe.combine_factorized(fac, (3, 4), flatten=True), atol=1e-6)
+    assert torch.allclose(rows.view(3, 4, 32)[2, 1], fac[0][2] + fac[1][1], atol=1e-6)
+    with pytest.raises(AssertionError):
+        pe((3, 4, 5))
+    enc, dec = nn.Conv2d(4, 64, 3, 2, 1), nn.ConvTranspose2d(64, 4, 3, 2, 1, output_padding=1)
+    m = Transfusion(num_text_tokens=8, dim_latent=4, channel_first_latent=True, pre_post_transformer_enc_dec=(enc, dec), add_pos_emb=True, modality_num_dim=2,
+                    modality_default_shape=(8, 8), transformer=dict(dim=64, depth=1, heads=1))
+    keys = set(m.state_dict())
+    assert {'latent_to_model_projs.0.0.weight', 'model_to_latent_projs.0.1.weight', 'pos_emb_mlp.0.mlps.1.0.weight'} <= keys       # Sequential(enc, Rearrange) / (Rearrange, dec)
+    assert not any(k in m.store.offsets for k in keys if k.startswith(('latent_to_model_projs', 'model_to_latent_projs', 'pos_emb_mlp')))
+    ext = m.external_parameters()
+    assert len(ext) == 4 + 12 and all(p.requires_grad for p in ext)
+    assert m.md.ext_types == (0,) and m.md.pos_types == (0,)
+    batch = [[torch.randint(0, 8, (3,)), (0, torch.randn(4, 8, 8))], [(0, torch.randn(4, 4, 8))]]
+    out, ctx = m._ext_preprocess(batch, torch.full((2, 1), 0.5), return_loss=True)
+    assert [tuple(p[1].shape) for s in out for p in s if isinstance(p, tuple)] == [(4, 4, 4), (2, 4, 4)] and out[0][1][1].device.type == 'meta'
+    assert ctx[0]['shape'] == [(4, 4), (2, 4)] and [tuple(t.shape) for t in ctx[0]['tok']] == [(16, 64), (8, 64)] and ctx[0]['tok'][0].requires_grad
+    assert [tuple(f.shape) for f in ctx[0]['flow']] == [(4, 8, 8), (4, 4, 8)]
+    P = m._scan(out, add_sos_eos=True)
+    assert P.inst_len.tolist() == [16, 8] and P.inst_shape == [(4, 4), (2, 4)]
+    # the [meta] shape string of the first instance spells the projected shape "4,4"
+    row = P.text_host[0].tolist()
+    i = row.index(m.meta_id)
+    assert [c - m.meta_id - 1 for c in row[i + 1:i + 4]] == [ord('4'), ord(','), ord('4')]
+    clone = m._clone_architecture()
+    assert clone.latent_to_model_projs[0][0] is not m.latent_to_model_projs[0][0]

@@ -39,6 +39,14 @@ class EMA(nn.Module):
             self.ema_model.store.fourier_w.copy_(self.model.store.fourier_w)
             self.ema_model.store.rot_param.copy_(self.model.store.rot_param)
             self.ema_model.store.mark_dirty()
+            for dst, src in self._external_pairs():
+                dst.copy_(src)
+
+    def _external_pairs(self):
+        """(ema, online) pairs of the parameters that live outside the flat buffer (positional-embedding MLPs, user encoder / decoder modules)"""
+        ext = lambda m: [p for mod in ([x for x in m.pos_emb_mlp if x is not None] +
+                                       [x for t in sorted(m._ext) for x in (m.latent_to_model_projs[t], m.model_to_latent_projs[t])]) for p in mod.parameters()]
+        return list(zip(ext(self.ema_model), ext(self.model)))
 
     def get_current_decay(self) -> float:
         epoch = max(int(self.step) - self.update_after_step - 1, 0)
@@ -62,6 +70,8 @@ class EMA(nn.Module):
         src, dst = self.model.store.flat, self.ema_model.store.flat
         capi.check(capi.lib().tfx_ema_update(dst.data_ptr(), src.data_ptr(), dst.numel(), float(decay), self.model._stream()), 'tfx_ema_update')
         self.ema_model.store.mark_dirty()
+        for dst, src in self._external_pairs():                      # few, small: plain lerp
+            dst.lerp_(src.to(dst.dtype), 1. - float(decay))
 
     def forward(self, *args, **kwargs):
         return self.ema_model(*args, **kwargs)

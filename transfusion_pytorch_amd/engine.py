@@ -178,10 +178,18 @@ class Plan:
         self.fe = z(I1, md.kf); self.cond = e(I1, 4 * d); self.pre = e(I1, 4 * d)
         self.tables = z(I1, nt3, dtype=torch.float32)
         self.lat = {}
+        self.ext, self.ext_add = set(md.ext_types) & set(R), set(md.pos_types) & set(R)
         for t, r in R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64)
+            if t in self.ext:
+                # `pre_post_transformer_enc_dec` type (T:1451-1494): the token rows are produced by the user's encoder in PyTorch (`tok`), the
+                # final embedding rows go back out to the user's decoder; `gemb` receives d loss / d (those embedding rows) before the backward
+                self.lat[t] = dict(tok=z(r, d), gemb=z(r, d))
+                continue
             self.lat[t] = dict(x=e(r, dl, dtype=torch.float32), eps=e(r, dl, dtype=torch.float32), xt=z(r, dlp),
                                flow=e(r, dl, dtype=torch.float32), pred=e(r, dl, dtype=torch.float32), dpred=z(r, dlp))
+        for t in self.ext_add:
+            self.lat[t]['add'] = z(R[t], d)      # additive token rows: the axial positional embedding (T:1384-1403, T:3173-3176), bf16
         self.acc = z(max(8, 2 + 2 * len(md.dim_latents)), dtype=torch.float32)      # [ce sum, ce count, flow sse per type..., velocity sse per type...]
         self.vel = LaunchList()                         # optional launches: velocity-consistency MSE against an EMA teacher's flows (T:3394-3418)
         self.cos_tab = self.sin_tab = None
@@ -259,14 +267,20 @@ class Plan:
         pp = ps.ptr
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
-            self._k(L, 'tfx_noise_mix', 'tfx_noise_mix_args', R=r, dl=dl, x=lt['x'], eps=lt['eps'], row_inst=self.row_inst[t],
-                    inst_time=self.inst_time, xt=lt['xt'], ld_xt=dlp, flow=lt['flow'])
-            self.noise_args[t] = L[-1][1]
-            if dl == d:       # nn.Identity latent_to_model (T:1478): the noised rows ARE the tokens - scatter them into the stream
-                self._raw(L, capi.lib().tfx_scatter_rows_bf16, lt['xt'].data_ptr(), dlp, d, self.hid[0].data_ptr(), d, self.row_tok[t].data_ptr(), r)
+            if t in self.ext:     # rows from the user's encoder: scatter them into the stream
+                self._raw(L, capi.lib().tfx_scatter_rows_bf16, lt['tok'].data_ptr(), d, d, self.hid[0].data_ptr(), d, self.row_tok[t].data_ptr(), r)
             else:
-                self._nt(L, algo_k=dl, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
-                         bias=pp(f'latent_to_model_projs.{t}.bias'), rowmap=self.row_tok[t])
+                self._k(L, 'tfx_noise_mix', 'tfx_noise_mix_args', R=r, dl=dl, x=lt['x'], eps=lt['eps'], row_inst=self.row_inst[t],
+                        inst_time=self.inst_time, xt=lt['xt'], ld_xt=dlp, flow=lt['flow'])
+                self.noise_args[t] = L[-1][1]
+                if dl == d:       # nn.Identity latent_to_model (T:1478): the noised rows ARE the tokens - scatter them into the stream
+                    self._raw(L, capi.lib().tfx_scatter_rows_bf16, lt['xt'].data_ptr(), dlp, d, self.hid[0].data_ptr(), d, self.row_tok[t].data_ptr(), r)
+                else:
+                    self._nt(L, algo_k=dl, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
+                             bias=pp(f'latent_to_model_projs.{t}.bias'), rowmap=self.row_tok[t])
+            if t in self.ext_add:     # tokens += positional embedding rows (T:3173-3176): identity GEMM, mapped RESID epilogue
+                self._nt(L, A=lt['add'], lda=d, B=S['eye'], ldb=d, M=r, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.hid[0], ldc=d,
+                         R=self.hid[0], ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
         self._k(L, 'tfx_embed_fwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, table=S['embed'], x=self.hid[0])
         if I > 0:
             self._k(L, 'tfx_fourier', 'tfx_fourier_args', I=I, half=d // 2, times=self.inst_time, w=ps.fourier_w, out=self.fe, ld=md.kf)
@@ -321,34 +335,38 @@ class Plan:
             # the dropped rows (-1) clamped to 0, so the gather never reads out of bounds (those rows are ignored by the caller)
             self.row_src = {t: torch.zeros(r, device=self.ps.device, dtype=torch.int32) for t, r in self.R.items()}
             for t, r in self.R.items():
+                if t in self.ext:
+                    continue
                 dl = md.dim_latents[t]; lt = self.lat[t]
                 self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_src[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
             self._clean_launch, self.clean_mode = {}, 'model'
             if md.model_output_clean:        # decode: always the model-space form (T:2446-2456), see below
                 for t, r in self.R.items():
-                    self._clean_model_space(L, t, r, self.row_src[t])
+                    if t not in self.ext:
+                        self._clean_model_space(L, t, r, self.row_src[t])
             self.fwd_pred_end = len(L)
             return
-        for t, r in self.R.items():          # flow predictions first, so that a loss-free forward can stop at fwd_pred_end
+        native = {t: r for t, r in self.R.items() if t not in self.ext}      # types whose projections / losses run here
+        for t, r in native.items():          # flow predictions first, so that a loss-free forward can stop at fwd_pred_end
             dl = md.dim_latents[t]; lt = self.lat[t]
             self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_tok[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
         self._clean_launch, self.clean_mode = {}, 'latent'
         if md.model_output_clean:            # pred <- (pred - noised) / max(1 - t, eps): the model predicts the clean latent (MP:100-126)
-            for t, r in self.R.items():
+            for t, r in native.items():
                 self._clean_model_space(L, t, r, self.row_tok[t])
         self.fwd_pred_end = len(L)
         self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
                                        dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
         L.append(('tfx_ce_fwd_bwd', self._ce_args))
         self._mse_args = {}
-        for t, r in self.R.items():
+        for t, r in native.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
             clean = dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}
             self._mse_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['flow'], grad_scale=0.0,
                                                dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + t), **clean)
             L.append(('tfx_mse_fwd_bwd', self._mse_args[t]))
         self._vel_args = {}
-        for t, r in self.R.items():          # second target on the same prediction; dpred accumulates.  Run only when a teacher is given
+        for t, r in native.items():          # second target on the same prediction; dpred accumulates.  Run only when a teacher is given
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
             lt['vel'] = torch.zeros(r, dl, device=self.ps.device, dtype=torch.float32)
             self._vel_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['vel'], grad_scale=0.0,
@@ -440,6 +458,8 @@ class Plan:
         if md.model_output_clean:
             C = self.clean_bwd
             for t, r in self.R.items():
+                if t in self.ext:
+                    continue
                 dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
                 lt['ndpred'] = torch.zeros(r, dlp, device=self.ps.device, dtype=BF16)
                 self._raw(C, lib.tfx_scale_bf16_copy, lt['dpred'].data_ptr(), lt['ndpred'].data_ptr(), r * dlp, -1.0)
@@ -454,6 +474,10 @@ class Plan:
         self._tn(L, T, md.vocab, d, A=self.dlogits, lda=md.vp, a_cols=md.vp, B=self.embed, ldb=d, b_cols=d, C=gp('to_text_logits.weight'), ldc=d)
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            if t in self.ext:     # d loss / d (embedding rows handed to the user's decoder), from autograd: dembed[row_tok] += gemb
+                self._nt(L, A=lt['gemb'], lda=d, B=S['eye'], ldb=d, M=r, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.dembed, ldc=d,
+                         R=self.dembed, ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
+                continue
             self._nt(L, algo_k=dl, A=lt['dpred'], lda=dlp, B=S[f'outp_t{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_RESID'], C=self.dembed, ldc=d,
                      R=self.dembed, ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
             self._tn(L, r, dl, d, A=lt['dpred'], lda=dlp, a_cols=dlp, B=self.embed, ldb=d, b_cols=d, b_rowmap=self.row_tok[t],
@@ -558,8 +582,8 @@ class Plan:
         self._tn(L, T, md.vocab, d, A=self.onehot, lda=md.vp, a_cols=md.vp, B=self.dx0, ldb=d, b_cols=d, C=gp('text_embed.weight'), ldc=d)
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
-            if dl == d:
-                continue                                   # Identity latent_to_model: no parameters (the data gradient is not needed)
+            if dl == d or t in self.ext:
+                continue                                   # Identity latent_to_model / the user's encoder: no parameters here (`dx0` rows go back through autograd)
             self._tn(L, r, d, dl, A=self.dx0, lda=d, a_cols=d, a_rowmap=self.row_tok[t], B=lt['xt'], ldb=dlp, b_cols=dlp,
                      C=gp(f'latent_to_model_projs.{t}.weight'), ldc=dl)
             self._raw(L, lib.tfx_colsum_bf16, self.dx0.data_ptr(), d, r, d, None, self.row_tok[t].data_ptr(), gp(f'latent_to_model_projs.{t}.bias'))

@@ -88,6 +88,11 @@ class FusedAdam:
         self.always_sync = False        # run the collective even at world size 1 (exercises the RCCL path on a 1-GPU box)
         self.m = self.v = self.sumsq = None
         self.reducer = None             # set by `overlap_grad_sync`: the exchange then runs in layer groups during the backward
+        # parameters that live OUTSIDE the flat buffer: the positional-embedding MLPs and the user's pre / post transformer encoder-decoder
+        # modules (PyTorch modules with autograd gradients).  They are few and small: a stock Adam steps them, under the SAME global clip
+        # coefficient (their squared gradient norm is added to the flat buffer's before the fused kernel reads it)
+        self.ext_params = list(model.external_parameters()) if hasattr(model, 'external_parameters') else []
+        self.ext_opt = torch.optim.Adam(self.ext_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if self.ext_params else None
 
     def overlap_grad_sync(self, groups: int = 4):
         """exchange the gradients in `groups` layer groups DURING the backward (GradReducer) instead of one all-reduce after it"""
@@ -110,6 +115,13 @@ class FusedAdam:
                 self.reducer.begin()
             else:
                 dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM, group=self.group)
+            grads = [p.grad for p in self.ext_params if p.grad is not None]
+            if grads:                                      # the external parameters: one more (small) collective over their coalesced gradients
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
         return world
 
     def step(self):
@@ -123,18 +135,31 @@ class FusedAdam:
         stream = torch.cuda.current_stream(ps.flat.device).cuda_stream
         self.step_count += 1
         max_norm = float(self.max_grad_norm) if self.max_grad_norm else 0.
+        gscale = (1.0 / world) if (self.average and world > 1) else 1.0
+        ext_grads = [p.grad for p in self.ext_params if p.grad is not None]
         if max_norm > 0:
             self.sumsq.zero_()
             capi.check(capi.lib().tfx_sumsq(ps.grad.data_ptr(), ps.numel, self.sumsq.data_ptr(), stream), 'tfx_sumsq')
+            if ext_grads:
+                self.sumsq += torch.stack([g.float().pow(2).sum() for g in ext_grads]).sum()
+        if ext_grads:                                       # same scaling as adam_k: grad_scale * min(1, max_norm / (|g| grad_scale + 1e-6)), on the device
+            coef = torch.full((), gscale, device=ps.flat.device)
+            if max_norm > 0:
+                coef = coef * (max_norm / (self.sumsq[0].sqrt() * gscale + 1e-6)).clamp(max=1.)
+            for g in ext_grads:
+                g.mul_(coef)
+            self.ext_opt.step()
         a = capi.make_args('tfx_adam_args', p=ps.flat, g=ps.grad, m=self.m, v=self.v, n=ps.numel, lr=self.lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, max_norm=max_norm,
-                           grad_scale=(1.0 / world) if (self.average and world > 1) else 1.0, step=self.step_count, sumsq=self.sumsq)
+                           grad_scale=gscale, step=self.step_count, sumsq=self.sumsq)
         capi.call('tfx_adam_step', a, stream)
         # the master changed behind autograd's back: bump the version counters so the bf16 shadows are rebuilt
         ps._shadow_version = None
 
     def zero_grad(self, set_to_none: bool = True):
         ps = self.model.store
+        if self.ext_opt is not None:
+            self.ext_opt.zero_grad(set_to_none=set_to_none)
         if set_to_none:
             for p in ps.params.values():
                 p.grad = None

@@ -36,6 +36,9 @@ class ModelDims:
     ff_expansion_factor: float = 4.
     model_output_clean: bool = False      # T:1297: the model predicts the clean latent; flows are derived (MP:100-126)
     clean_eps: float = 1e-2               # T:1319 `eps`: floor of (1 - t) in that conversion
+    pos_types: tuple = ()                 # modality types whose tokens get an additive axial positional embedding (T:1384-1403): rows computed by the host MLP
+    ext_types: tuple = ()                 # modality types whose latent <-> model maps are user modules (`pre_post_transformer_enc_dec`, T:1451-1494):
+                                          # their token rows come in from / their embedding rows go out to PyTorch; no projection parameters here
 
     @property
     def num_modalities(self): return len(self.dim_latents)
@@ -93,6 +96,8 @@ def param_specs(md: ModelDims):
                   (f'{p}.3.pseudo_queries', (d,)), (f'{p}.3.norm_keys.gamma', (d,))]
     specs.append(('transformer.norm.gamma', (d,)))
     for t, dl in enumerate(md.dim_latents):
+        if t in md.ext_types:
+            continue
         if dl != d:                                                                 # T:1478
             specs += [(f'latent_to_model_projs.{t}.weight', (d, dl)), (f'latent_to_model_projs.{t}.bias', (d,))]
         specs.append((f'model_to_latent_projs.{t}.weight', (dl, d)))
@@ -344,8 +349,13 @@ class ParamStore:
             if b1 is None:
                 b1 = self.shadows[f'ff1b{i}'] = torch.zeros(2 * dip, device=self.device)
             capi.check(capi.lib().tfx_gather_f32(self.ptr(f'{p}.2.fn.net.0.bias'), gmap.data_ptr(), b1.data_ptr(), 2 * dip, stream), 'gather_f32')
+        if (md.pos_types or md.ext_types) and 'eye' not in self.shadows:
+            # identity matrix: `C[rowmap[r]] += A[r]` (additive token rows, gradients of rows handed out) is the NT GEMM's mapped RESID epilogue with B = I
+            self.shadows['eye'] = torch.eye(d, device=self.device, dtype=torch.bfloat16)
         for t, dl in enumerate(md.dim_latents):
             dlp = pad_to(dl, 64)
+            if t in md.ext_types:
+                continue
             if dl != d:
                 C(stream, self.ptr(f'latent_to_model_projs.{t}.weight'), dl, d, dl, S(f'in{t}', d, dlp))
             C(stream, self.ptr(f'model_to_latent_projs.{t}.weight'), d, dl, d, S(f'outp{t}', dl, d))

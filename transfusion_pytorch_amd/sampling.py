@@ -177,8 +177,9 @@ class Sampler:
 
     # ------------------------------------------------------------------ main
     def sample_many(self, prompts, max_length, text_temperature, text_min_p, fixed_modality_shape, force_modality_at_start,
-                    init_modality_noise, modality_steps, cfg_scale):
+                    init_modality_noise, modality_steps, cfg_scale, pos_emb_in_decode=False):
         m, md, dev = self.m, self.md, self.dev
+        self.pos_emb_in_decode = pos_emb_in_decode
         m._require_gpu()
         if prompts is None:
             prompts = [None]
@@ -397,6 +398,14 @@ class Sampler:
             p.row_tok[t].copy_(up(row_tok[t])); p.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
             p.row_inst[t].copy_(up(np.repeat(np.arange(B, dtype=np.int32), Lmax)))
             p.set_noise(t, None)
+        for t in p.ext_add:                      # axial positional embedding of the blocks being decoded (constant over the ODE steps); zeros = none
+            add = p.lat[t]['add']
+            add.zero_()
+            if getattr(self, 'pos_emb_in_decode', False):
+                for i in group:
+                    st = states[i]
+                    if st.curr_modality_id == t:
+                        add[i * Lmax:i * Lmax + st.modality_length].copy_(self.m._pos_rows(t, [st.modality_shape]))
 
     def _run(self, p, stream, lo, hi):
         """replay a range of a decode plan: eagerly the first time (one-off kernel attribute setup happens outside any capture), as a

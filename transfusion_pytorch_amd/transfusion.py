@@ -17,6 +17,7 @@ from torch import nn
 from . import capi
 from .engine import Plan
 from .packing import fast_signature, is_int_tensor, scan_batch, token_maps, token_segments
+from .axial import ContinuousAxialPositionalEmbedding
 from .params import ModelDims, ParamStore
 
 
@@ -63,19 +64,46 @@ class Transformer:
         self.dim, self.depth, self.dim_head, self.heads, self.ff_expansion_factor = dim, depth, dim_head, heads, ff_expansion_factor
 
 
+class _MoveDim(nn.Module):
+    """the Rearrange('b d ... -> b ... d') / Rearrange('b ... d -> b d ...') the reference wraps around channel-first encoders / decoders (T:1487-1491)"""
+
+    def __init__(self, src, dst):
+        super().__init__()
+        self.src, self.dst = src, dst
+
+    def forward(self, x):
+        return x.movedim(self.src, self.dst)
+
+
 class _NativeLoss(torch.autograd.Function):
-    """connects the engine's hand-written backward to `loss.backward()`."""
+    """connects the engine's hand-written backward to autograd.
+
+    Beyond the scalar loss it carries the rows that cross the PyTorch / engine line for modality types whose maps live in PyTorch:
+      inputs  `rows` - token rows PyTorch produced for the engine, one per entry of spec['in'] = [('tok' | 'add', type)]: the user's encoder
+                       output (`pre_post_transformer_enc_dec`) or the axial positional embedding rows; their gradient is d loss / d x0 at those rows
+      outputs        - the final-embedding rows of spec['out'] types, for the user's decoder; their incoming gradient seeds the backward next to the loss"""
 
     @staticmethod
-    def forward(ctx, anchor, model, loss):
-        ctx.model = model
-        ctx.step_id = model._step_id
-        return loss.clone()
+    def forward(ctx, anchor, model, loss, spec, *rows):
+        ctx.model, ctx.step_id, ctx.spec = model, model._step_id, spec
+        plan = model._live[0]
+        outs = [loss.clone()]
+        for t in spec['out']:
+            outs.append(plan.embed.index_select(0, plan.row_tok[t].long().clamp(min=0)).float())
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, grad_out):
-        ctx.model._native_backward(grad_out, ctx.step_id)
-        return None, None, None
+    def backward(ctx, grad_loss, *grad_rows):
+        model, spec = ctx.model, ctx.spec
+        plan = model._live[0]
+        for t, g in zip(spec['out'], grad_rows):
+            plan.lat[t]['gemb'].copy_(g)
+        model._native_backward(grad_loss, ctx.step_id)
+        back = [plan.dx0.index_select(0, plan.row_tok[t].long().clamp(min=0)).float() for _, t in spec['in']]
+        return (None, None, None, None, *back)
+
+
+_NO_ROWS = {'in': [], 'out': []}
 
 
 class Transfusion(nn.Module):
@@ -90,6 +118,7 @@ class Transfusion(nn.Module):
         super().__init__()
         self._init_kwargs = dict(num_text_tokens=num_text_tokens, transformer=transformer, model_output_clean=model_output_clean, dim_latent=dim_latent,
                                  channel_first_latent=channel_first_latent, add_pos_emb=add_pos_emb, modality_default_shape=modality_default_shape,
+                                 pre_post_transformer_enc_dec=pre_post_transformer_enc_dec,
                                  modality_encoder=modality_encoder, modality_decoder=modality_decoder,
                                  modality_encoder_decoder_requires_batch_dim=modality_encoder_decoder_requires_batch_dim,
                                  fallback_to_default_shape_if_invalid=fallback_to_default_shape_if_invalid, modality_num_dim=modality_num_dim,
@@ -99,8 +128,7 @@ class Transfusion(nn.Module):
         assert modality_processing in PROCESSING_STRATEGIES, \
             f'unknown modality processing strategy `{modality_processing}`, available: {list(PROCESSING_STRATEGIES)}'      # MP:1254-1256
         self.modality_processing = modality_processing
-        unsupported = dict(add_pos_emb=any(cast_tuple(add_pos_emb)), pre_post_transformer_enc_dec=pre_post_transformer_enc_dec is not None,
-                           reconstruction_loss_weight=reconstruction_loss_weight > 0.)
+        unsupported = dict(reconstruction_loss_weight=reconstruction_loss_weight > 0.)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f'Transfusion options outside the native hot path (SURVEY.md section 8): {bad}')
@@ -145,14 +173,55 @@ class Transfusion(nn.Module):
         self.model_output_clean = bool(model_output_clean)
         self.odeint_kwargs = dict(odeint_kwargs)
 
+        # axial positional embedding per modality type (T:1384-1403): a host MLP produces the rows, the engine adds them into the token stream
+        self.add_pos_emb = cast_tuple(add_pos_emb, self.num_modalities)
+        assert len(self.add_pos_emb) == self.num_modalities
+        self.pos_emb_mlp = nn.ModuleList([])
+        for flag, ndim in zip(self.add_pos_emb, self.modality_num_dim):
+            if not flag:
+                self.pos_emb_mlp.append(None)
+                continue
+            assert ndim is not None, '`modality_num_dim` must be set if you wish to automatically inject axial positional embeddings'     # T:1396
+            self.pos_emb_mlp.append(ContinuousAxialPositionalEmbedding(dim=dim, num_axial_dims=ndim))
+        # learnable encoder / decoder pairs around the transformer (`pre_post_transformer_enc_dec`, the paper's U-Net down / up, T:1451-1494):
+        # they REPLACE latent_to_model / model_to_latent of their type and run in PyTorch; the engine takes their token rows and returns
+        # the embedding rows (and the gradients both ways)
+        ppe = pre_post_transformer_enc_dec
+        if isinstance(ppe, tuple) and len(ppe) == 2 and all(isinstance(m, nn.Module) for m in ppe):
+            ppe = (ppe,)                                                                     # one (encoder, decoder) pair, T:1453-1454
+        ppe = cast_tuple(ppe, self.num_modalities)
+        assert len(ppe) == self.num_modalities
+        ext_modules = {}
+        for t, pair in enumerate(ppe):
+            if pair is None:
+                continue
+            pre, post = pair
+            assert pre is not None and post is not None, 'pre_post_transformer_enc_dec takes (encoder, decoder) pairs'
+            if self.channel_first_latent[t]:                                                # T:1487-1491
+                pre, post = nn.Sequential(pre, _MoveDim(1, -1)), nn.Sequential(_MoveDim(-1, 1), post)
+            ext_modules[t] = (pre, post)
+        if ext_modules and self.model_output_clean:
+            raise NotImplementedError('model_output_clean together with pre_post_transformer_enc_dec is not wired in the native path')
+
         self.md = ModelDims(num_text_tokens=num_text_tokens, dim=dim, depth=transformer.depth, heads=transformer.heads,
-                            dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor, model_output_clean=bool(model_output_clean), clean_eps=float(eps))
+                            dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor, model_output_clean=bool(model_output_clean), clean_eps=float(eps),
+                            pos_types=tuple(t for t, f in enumerate(self.add_pos_emb) if f), ext_types=tuple(sorted(ext_modules)))
         self.store = ParamStore(self.md, self)
+        if ext_modules:       # the reference's attribute names: latent_to_model_projs[t] / model_to_latent_projs[t] ARE the user's modules (T:1493-1494)
+            for name in ('latent_to_model_projs', 'model_to_latent_projs'):
+                if not hasattr(self, name):
+                    setattr(self, name, nn.ModuleList())
+                ml = getattr(self, name)
+                while len(ml) < self.num_modalities:
+                    ml.append(None)
+            for t, (pre, post) in ext_modules.items():
+                self.latent_to_model_projs[t], self.model_to_latent_projs[t] = pre, post
+        self._ext = set(ext_modules)
         # state_dict names of a channel-first type's projections: the reference wraps them in nn.Sequential(Rearrange, Linear) / (Linear,
         # Rearrange) (T:1481-1483), i.e. `latent_to_model_projs.t.1.*` and `model_to_latent_projs.t.0.*`: translate on load and on save
         self._key_renames = {}
         for t, cf in enumerate(self.channel_first_latent):
-            if cf:
+            if cf and t not in self._ext:
                 self._key_renames[f'latent_to_model_projs.{t}.weight'] = f'latent_to_model_projs.{t}.1.weight'
                 self._key_renames[f'latent_to_model_projs.{t}.bias'] = f'latent_to_model_projs.{t}.1.bias'
                 self._key_renames[f'model_to_latent_projs.{t}.weight'] = f'model_to_latent_projs.{t}.0.weight'
@@ -201,6 +270,13 @@ class Transfusion(nn.Module):
     def parameters_without_encoder_decoder(self):                     # T:1650-1655
         return set(self.parameters()) - set(self.modality_encoder.parameters()) - set(self.modality_decoder.parameters())
 
+    def external_parameters(self):
+        """learnable parameters outside the flat native buffer: the axial positional-embedding MLPs and the user's pre / post transformer
+        encoder-decoder modules (optim.FusedAdam steps them with a stock Adam under the same global clip)"""
+        mods = [m for m in self.pos_emb_mlp if m is not None]
+        mods += [m for t in sorted(self._ext) for m in (self.latent_to_model_projs[t], self.model_to_latent_projs[t])]
+        return [p for m in mods for p in m.parameters() if p.requires_grad]
+
     def _apply_fn_modality_type(self, fn, samples, modality_type):
         """apply_fn_modality_type (T:542-582): run `fn` on every modality of one type in a list of samples, same-shaped tensors stacked"""
         single = bool(samples) and not isinstance(samples[0], list)
@@ -246,14 +322,74 @@ class Transfusion(nn.Module):
             for part in sample:
                 if torch.is_tensor(part) and part.is_floating_point():
                     part = (0, part)
-                if isinstance(part, tuple) and self.channel_first_latent[part[0]]:
-                    part = (part[0], part[1].movedim(0, -1))
+                if isinstance(part, tuple) and self.channel_first_latent[part[0]] and part[0] not in self._ext:
+                    part = (part[0], part[1].movedim(0, -1))          # (`ext` types stay in the layout their encoder takes)
                 s.append(part)
             out.append(s)
         return out
 
     def _from_channel_last(self, ty, x):
         return x.movedim(-1, 0) if self.channel_first_latent[ty] else x
+
+    # ------------------------------------------------------------------ rows PyTorch computes for the engine: positional embedding, user encoders
+    def _pos_rows(self, t, shapes):
+        """axial positional embedding rows (sum of lengths, dim) of modality type t for instances of the given (projected) axial shapes, in scan
+        order (T:2795-2796; MP:1003-1045 evaluates the same per-axis MLPs once at the maximum extents and slices - same values)"""
+        mlp, cache, out = self.pos_emb_mlp[t], {}, []
+        for shp in shapes:
+            shp = tuple(int(a) for a in shp)
+            assert len(shp) == mlp.num_axial_dims, f'received modalities of ndim {len(shp)} but expected {mlp.num_axial_dims}'     # T:2786
+            if shp not in cache:
+                cache[shp] = mlp(shp, flatten=True)
+            out.append(cache[shp])
+        return out[0] if len(out) == 1 else torch.cat(out)
+
+    def _ext_preprocess(self, modalities, times, return_loss):
+        """`pre_post_transformer_enc_dec` types in the interleaved forward: noising and the user's encoder run in PyTorch, one instance at a
+        time in scan order (process_instance, MP:715-745; a conv / U-Net encoder mixes tokens, so instances are never concatenated, MP:626-632).
+        Returns the batch with those parts replaced by shape-only placeholders of the PROJECTED axial shape - positions, the meta shape string and
+        the token count use that one (MP:738-741) - and per type the token rows / flow targets / shapes in scan order."""
+        dev, d = self.device, self.md.dim
+        ctx = {t: dict(tok=[], flow=[], shape=[]) for t in self._ext}
+        out = []
+        for bi, sample in enumerate(modalities):
+            m, row = 0, []
+            for part in sample:
+                if torch.is_tensor(part) and part.is_floating_point():
+                    part = (0, part)
+                if isinstance(part, tuple):
+                    ty, x = int(part[0]), part[1]
+                    if ty in self._ext:
+                        c = ctx[ty]
+                        x = x.to(dev, torch.float32)
+                        if return_loss:
+                            tt = times[bi, m]
+                            ov = self._noise_override
+                            eps = ov[ty][len(c['tok'])].to(dev, torch.float32) if ov is not None else torch.randn_like(x)
+                            noised, flow = x * tt + eps * (1. - tt), x - eps                # MP:717-719
+                            c['flow'].append(flow)
+                        else:
+                            noised = x
+                        pre = self.latent_to_model_projs[ty]
+                        tok = pre(noised[None])[0] if self.channel_first_latent[ty] else pre(noised)       # MP:729-732
+                        assert tok.shape[-1] == d, f'the encoder of modality {ty} must produce model-dimension ({d}) tokens'
+                        c['tok'].append(tok.reshape(-1, d)); c['shape'].append(tuple(tok.shape[:-1]))
+                        part = (ty, torch.empty((*tok.shape[:-1], self.dim_latents[ty]), device='meta'))
+                    m += 1
+                row.append(part)
+            out.append(row)
+        return out, ctx
+
+    def _ext_flow_loss(self, t, rows, ctx):
+        """flow loss of an `ext` type: the user's decoder on each instance's embedding rows (add_temp_batch_dim(model_to_latent), T:3300-3301),
+        then ONE mse over all instances of the type packed together (T:3356-3364)"""
+        post, d = self.model_to_latent_projs[t], self.md.dim
+        preds, lo = [], 0
+        for shape in ctx['shape']:
+            L = int(np.prod(shape))
+            preds.append(post(rows[lo:lo + L].reshape(1, *shape, d))[0].reshape(-1))
+            lo += L
+        return torch.nn.functional.mse_loss(torch.cat(preds), torch.cat([f.reshape(-1) for f in ctx['flow']]))
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -331,6 +467,9 @@ class Transfusion(nn.Module):
         """inference forward over explicit samples (nothing added, no noising): fills and runs a non-training plan up to the
         fp32 logits.  Returns (plan, structure).  Used by the sampler's prefills (T:2194-2201, T:2389-2406)."""
         self._require_gpu()
+        if self._ext:
+            raise NotImplementedError('decoding (sample / sample_many / the kv-cache forward) with pre_post_transformer_enc_dec modality types is not '
+                                      'wired in the native path - use forward() / forward_modality() / generate_modality_only()')
         dev, stream = self.device, self._stream()
         sig, user_text, latents = fast_signature(samples)
         key = (sig, 'plain', add_meta, pad_n)
@@ -368,6 +507,9 @@ class Transfusion(nn.Module):
                 r = R[t]
                 plan.row_tok[t][:r].copy_(S['row_tok'][t]); plan.row_inst[t][:r].copy_(S['row_inst'][t])
                 plan.lat[t]['x'][:r].copy_(torch.cat(latents[t]).to(dev, torch.float32))
+                if t in plan.ext_add:                                 # prompted modalities carry their axial positional embedding (T:3173-3176)
+                    P = S['P']
+                    plan.lat[t]['add'][:r].copy_(self._pos_rows(t, [P.inst_shape[g] for g in range(I) if int(P.inst_type[g]) == t]))
             plan.set_noise(t, None)
         Plan.run(plan.fwd, stream, 0, plan.fwd_logits_end)
         return plan, S
@@ -424,6 +566,19 @@ class Transfusion(nn.Module):
         stream = self._stream()
         ps, md = self.store, self.md
 
+        # ---- modality types whose encoder / decoder are user modules: their part of the packing happens in PyTorch, BEFORE the structure scan
+        ext_ctx = None
+        if self._ext:
+            if ema is not None or return_only_pred_flows:
+                raise NotImplementedError('velocity consistency is not wired for pre_post_transformer_enc_dec modality types')
+            is_mod = lambda p: isinstance(p, tuple) or (torch.is_tensor(p) and p.is_floating_point())
+            if times is None:                                                              # T:3075-3082 (drawn before the packing, as there)
+                num_mod = np.array([sum(1 for p in sample if is_mod(p)) for sample in modalities], dtype=np.int64)
+                fn = num_modalities_to_times_fn
+                times = fn(torch.from_numpy(num_mod).to(dev)) if fn is not None else self._default_times(num_mod)
+            times = times.to(dev, torch.float32)
+            modalities, ext_ctx = self._ext_preprocess(modalities, times, return_loss)
+
         # ---- structure: one cheap signature pass; everything derived from it is cached ON THE DEVICE per signature
         sig, user_text, latents = fast_signature(modalities)
         add_meta = return_loss or not return_embed           # MP:330: `return_embed` (the decode-time call) packs WITHOUT [meta][shape][som] ... [eom]
@@ -473,8 +628,18 @@ class Transfusion(nn.Module):
             plan.labels.copy_(lab.reshape(-1))
         if I > 0:
             plan.inst_time.copy_(times[S['inst_b'], S['inst_m']])
+        rows_in = []                                                      # rows PyTorch hands to the engine: (kind, type, tensor with autograd history)
         for t in R:
             lt = plan.lat[t]
+            if t in plan.ext_add:                                         # axial positional embedding of the (projected) instance shapes
+                rows = self._pos_rows(t, [P.inst_shape[g] for g in range(I) if int(P.inst_type[g]) == t])
+                lt['add'].copy_(rows.detach())
+                rows_in.append(('add', t, rows))
+            if t in plan.ext:
+                rows = torch.cat(ext_ctx[t]['tok']) if len(ext_ctx[t]['tok']) > 1 else ext_ctx[t]['tok'][0]
+                lt['tok'].copy_(rows.detach())
+                rows_in.append(('tok', t, rows))
+                continue
             lt['x'].copy_(torch.cat(latents[t]), non_blocking=True)          # one cat on the source device, one transfer
             if return_loss:
                 if self._noise_override is not None:
@@ -509,6 +674,8 @@ class Transfusion(nn.Module):
         total = float(P.total_tokens)
         mse_scales = {}
         for t, r in R.items():
+            if t in plan.ext:
+                continue
             w_t = float(tm.is_type[t]) / total                                              # T:3343
             mse_scales[t] = 2.0 * self.flow_loss_weight * w_t / (r * md.dim_latents[t])
         plan.set_loss_scales(self.text_loss_weight / total, mse_scales)
@@ -520,10 +687,12 @@ class Transfusion(nn.Module):
         acc = plan.acc
         text_loss = acc[0] / acc[1].clamp(min=1.)
         loss = self.text_loss_weight * acc[0] / total
-        flow_losses = []
+        flow_losses = {}
         for t, r in sorted(R.items()):
+            if t in plan.ext:
+                continue
             fl = acc[2 + t] / (r * md.dim_latents[t])
-            flow_losses.append(fl)
+            flow_losses[t] = fl
             loss = loss + self.flow_loss_weight * fl * (float(tm.is_type[t]) / total)
 
         velocity_losses = None
@@ -553,10 +722,19 @@ class Transfusion(nn.Module):
 
         self._step_id += 1
         self._live = (plan, self._step_id)
+        ext_out = sorted(plan.ext)
         if torch.is_grad_enabled():
             if self._anchor is None or self._anchor.device != dev:
                 self._anchor = torch.zeros((), device=dev, requires_grad=True)
-            loss = _NativeLoss.apply(self._anchor, self, loss)
+            spec = {'in': [(k, t) for k, t, _ in rows_in], 'out': ext_out} if (rows_in or ext_out) else _NO_ROWS
+            loss, *emb_rows = _NativeLoss.apply(self._anchor, self, loss, spec, *[r for _, _, r in rows_in])
+        else:
+            emb_rows = [plan.embed.index_select(0, plan.row_tok[t].long().clamp(min=0)).float() for t in ext_out]
+        for t, rows in zip(ext_out, emb_rows):                                              # the user's decoders and their flow losses, in PyTorch
+            fl = self._ext_flow_loss(t, rows, ext_ctx[t])
+            flow_losses[t] = fl
+            loss = loss + self.flow_loss_weight * fl * (float(tm.is_type[t]) / total)
+        flow_losses = [flow_losses[t] for t in sorted(flow_losses)]
         if not return_breakdown and not return_times:
             return loss
         ret = (loss,)
@@ -685,9 +863,13 @@ class Transfusion(nn.Module):
                 kve = np.full(T, n_cached + L, np.int32)                   # own prefix + the whole (bidirectional) block
                 rot = np.full(T, seen, np.int32)                           # all tokens of the instance share one rotary position (T:3206)
                 row_tok = {t: np.full(T, -1, np.int32) for t in range(self.num_modalities)}
+                for t in plan.ext_add:
+                    plan.lat[t]['add'].zero_()
                 for i, (ty, x) in enumerate(tys):
                     row_tok[ty][i * L:(i + 1) * L] = np.arange(i * L, (i + 1) * L)
                     plan.lat[ty]['x'][i * L:(i + 1) * L].copy_(x.reshape(L, -1).to(dev, torch.float32))
+                    if ty in plan.ext_add:                                # the decoded block's positional embedding (T:3179-3180 under the decode slice T:1167-1176)
+                        plan.lat[ty]['add'][i * L:(i + 1) * L].copy_(self._pos_rows(ty, [tuple(x.shape[:-1])]))
                 up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
                 for t in row_tok:
                     plan.row_tok[t].copy_(up(row_tok[t])); plan.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
@@ -763,7 +945,7 @@ class Transfusion(nn.Module):
         if torch.is_grad_enabled():
             if self._anchor is None or self._anchor.device != dev:
                 self._anchor = torch.zeros((), device=dev, requires_grad=True)
-            loss = _NativeLoss.apply(self._anchor, self, loss)
+            loss = _NativeLoss.apply(self._anchor, self, loss, _NO_ROWS)[0]
         return loss
 
     # ------------------------------------------------------------------ pure flow path (T:2710-2869)
@@ -789,13 +971,38 @@ class Transfusion(nn.Module):
             with torch.no_grad():
                 self.modality_encoder[t].eval()
                 modalities = self.modality_encoder[t](modalities).detach()
-        if self.channel_first_latent[t]:
-            modalities = modalities.movedim(1, -1)                                         # (b, d, *axial) -> (b, *axial, d)
-        x = modalities.to(dev, torch.float32)
-        dl = md.dim_latents[t]
-        assert x.shape[-1] == dl, f'last dimension must be dim_latent = {dl}'
-        b = x.shape[0]
-        L = int(np.prod(x.shape[1:-1])) if x.ndim > 2 else 1
+        ext = t in self._ext
+        if ext and ema is not None:
+            raise NotImplementedError('velocity consistency is not wired for pre_post_transformer_enc_dec modality types')
+        b = modalities.shape[0]
+        if times is None:
+            times = torch.rand(b, device=dev)                                              # T:2746-2747
+        times = times.to(dev, torch.float32).reshape(b)
+        if ema is not None and return_loss:                                                # T:2752-2755
+            orig_times = times.clone()
+            times = times * (1. - velocity_consistency_delta_time)
+        dl, d = md.dim_latents[t], md.dim
+        tok = flow_ext = None
+        if ext:
+            # the user's encoder / decoder replace latent_to_model / model_to_latent (T:1493-1494): noising, encoder, decoder and the loss are
+            # PyTorch; the transformer over the encoder's tokens (and its backward) is the native engine
+            raw = modalities.to(torch.float32)
+            if return_loss:
+                tt = times.view(b, *([1] * (raw.ndim - 1)))
+                eps = self._noise_override[t].to(dev, torch.float32).view(raw.shape) if self._noise_override is not None else torch.randn_like(raw)
+                noised, flow_ext = tt * raw + (1. - tt) * eps, raw - eps                   # T:2756-2762
+            else:
+                noised = raw
+            tok = self.latent_to_model_projs[t](noised)                                     # (b, *axial', dim)
+            assert tok.shape[-1] == d, f'the encoder of modality {t} must produce model-dimension ({d}) tokens'
+            axial = tuple(tok.shape[1:-1])
+        else:
+            if self.channel_first_latent[t]:
+                modalities = modalities.movedim(1, -1)                                     # (b, d, *axial) -> (b, *axial, d)
+            x = modalities.to(dev, torch.float32)
+            assert x.shape[-1] == dl, f'last dimension must be dim_latent = {dl}'
+            axial = tuple(x.shape[1:-1])
+        L = int(np.prod(axial)) if axial else 1
         rows = b * L
         key = ('modality', b, L, t)
         S = self._struct_cache.get(key)
@@ -816,32 +1023,41 @@ class Transfusion(nn.Module):
             plan.row_tok[t].copy_(S['row_tok']); plan.row_inst[t].copy_(S['tok_inst'])
             plan.text_ids.zero_()
             plan.loaded_structure = S
-        if times is None:
-            times = torch.rand(b, device=dev)                                              # T:2746-2747
-        times = times.to(dev, torch.float32).reshape(b)
-        if ema is not None and return_loss:                                                # T:2752-2755
-            orig_times = times.clone()
-            times = times * (1. - velocity_consistency_delta_time)
         plan.inst_time.copy_(times)
         lt = plan.lat[t]
-        lt['x'].copy_(x.reshape(rows, dl))
+        rows_in = []
+        if t in plan.ext_add:                                                              # T:2781-2796: the same (L, dim) embedding for every sample
+            assert len(axial) == self.pos_emb_mlp[t].num_axial_dims, f'received modalities of ndim {len(axial)} but expected {self.pos_emb_mlp[t].num_axial_dims}'
+            pos = self._pos_rows(t, [axial]).repeat(b, 1)
+            lt['add'].copy_(pos.detach())
+            rows_in.append(('add', t, pos))
+        if ext:
+            tok_rows = tok.reshape(rows, d)
+            lt['tok'].copy_(tok_rows.detach())
+            rows_in.append(('tok', t, tok_rows))
+        else:
+            lt['x'].copy_(x.reshape(rows, dl))
         if not return_loss:
+            if ext:
+                Plan.run(plan.fwd, stream, 0, plan.fwd_embed_end)
+                return self.model_to_latent_projs[t](plan.embed.view(b, *axial, d).float())
             plan.set_noise(t, None)                                                  # T:2759-2760: no noising
             Plan.run(plan.fwd, stream, 0, plan.fwd_pred_end)
             out = lt['pred'].view(x.shape).clone()
             return out.movedim(-1, 1) if self.channel_first_latent[t] else out
-        if self._noise_override is not None:
-            lt['eps'].copy_(self._noise_override[t].reshape(rows, dl))
-        else:
-            lt['eps'].normal_()                                                            # T:2753
-        plan.set_noise(t, lt['eps'].data_ptr())
+        if not ext:
+            if self._noise_override is not None:
+                lt['eps'].copy_(self._noise_override[t].reshape(rows, dl))
+            else:
+                lt['eps'].normal_()                                                            # T:2753
+            plan.set_noise(t, lt['eps'].data_ptr())
         plan.labels.fill_(-1)
-        plan.set_loss_scales(0.0, {t: 2.0 / (rows * dl)})
+        plan.set_loss_scales(0.0, {} if ext else {t: 2.0 / (rows * dl)})
         plan.set_ce_vocab(md.vocab)
         self._bwd_scale = None
         plan.acc.zero_()
         Plan.run(plan.fwd, stream)
-        flow_loss = plan.acc[2 + t] / (rows * dl)                                          # T:2817
+        flow_loss = torch.zeros((), device=dev) if ext else plan.acc[2 + t] / (rows * dl)   # T:2817
         loss = flow_loss
         velocity_loss = None
         if ema is not None:
@@ -865,10 +1081,18 @@ class Transfusion(nn.Module):
             loss = loss + self.velocity_consistency_loss_weight * velocity_loss              # T:2858-2862
         self._step_id += 1
         self._live = (plan, self._step_id)
+        emb_rows = None
         if torch.is_grad_enabled():
             if self._anchor is None or self._anchor.device != dev:
                 self._anchor = torch.zeros((), device=dev, requires_grad=True)
-            loss = _NativeLoss.apply(self._anchor, self, loss)
+            spec = {'in': [(k, ty) for k, ty, _ in rows_in], 'out': [t] if ext else []} if rows_in else _NO_ROWS
+            loss, *emb_rows = _NativeLoss.apply(self._anchor, self, loss, spec, *[r for _, _, r in rows_in])
+        elif ext:
+            emb_rows = [plan.embed.float()]
+        if ext:                                                                            # the user's decoder and the flow loss, in PyTorch (T:2806-2817)
+            pred = self.model_to_latent_projs[t](emb_rows[0].view(b, *axial, d))
+            flow_loss = torch.nn.functional.mse_loss(pred, flow_ext)
+            loss = loss + flow_loss
         if not return_loss_breakdown:
             return loss
         zero = torch.zeros((), device=dev)
@@ -924,7 +1148,7 @@ class Transfusion(nn.Module):
         lib, stream = capi.lib(), self._stream()
         sp = ctypes.c_void_p(stream)
         # fp32 scalar read on the device; exactly 1.0 (plain loss.backward()) skips the pass over the seeds
-        for seed in [plan.dlogits] + [lt['dpred'] for lt in plan.lat.values()]:
+        for seed in [plan.dlogits] + [lt['dpred'] for lt in plan.lat.values() if 'dpred' in lt]:
             capi.check(lib.tfx_scale_bf16_dev(seed.data_ptr(), seed.numel(), go.data_ptr(), sp), 'tfx_scale_bf16_dev')
         plan.dtables.zero_()
         if self.md.model_output_clean and plan.clean_mode == 'model' and len(plan.clean_bwd):
@@ -946,7 +1170,10 @@ class Transfusion(nn.Module):
     @torch.no_grad()
     def sample_many(self, prompts=None, max_length=2048, text_temperature=1., text_min_p=0.1, fixed_modality_shape=None,
                     force_modality_at_start=None, init_modality_noise=None, modality_steps=16, return_unprocessed_modalities=False,
-                    cfg_scale=3.):
+                    cfg_scale=3., _pos_emb_in_decode=False):
+        """T:2082-2583.  `_pos_emb_in_decode`: with `add_pos_emb`, the reference's two samplers differ - `sample_many` feeds the ODE evaluations
+        the bare projected latents (project_to_model, T:2436-2444 / T:2472-2475: no positional embedding), while `sample_one`, going through
+        `forward()`, adds it (T:3179-3180).  Each entry point keeps its own reference's behaviour; prompted modalities carry it in both (T:2194)."""
         from .sampling import Sampler
         was_training = self.training
         self.eval()                                              # @temp_eval in the reference
@@ -964,7 +1191,8 @@ class Transfusion(nn.Module):
                 prompts = norm
             out = Sampler(self).sample_many(prompts, max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
                                             fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
-                                            init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale)
+                                            init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale,
+                                            pos_emb_in_decode=_pos_emb_in_decode)
             if special:
                 out = [[(p[0], self._from_channel_last(p[0], p[1])) if isinstance(p, tuple) else p for p in sample] for sample in out]
                 if not return_unprocessed_modalities:
@@ -981,7 +1209,7 @@ class Transfusion(nn.Module):
         return self.sample_many([prompt], max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
                                 fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
                                 init_modality_noise=init_modality_noise, modality_steps=modality_steps,
-                                return_unprocessed_modalities=return_unprocessed_modalities, cfg_scale=cfg_scale)[0]
+                                return_unprocessed_modalities=return_unprocessed_modalities, cfg_scale=cfg_scale, _pos_emb_in_decode=True)[0]
 
     sample = sample_one
 
@@ -1066,8 +1294,10 @@ class Transfusion(nn.Module):
 
     def _clone_architecture(self):
         """a fresh model with this one's constructor arguments on the same device (weights NOT copied)"""
+        import copy
         kw = dict(self._init_kwargs)
         kw['transformer'] = self.transformer_config
+        kw['pre_post_transformer_enc_dec'] = copy.deepcopy(kw.get('pre_post_transformer_enc_dec'))     # learnable: the copy owns its own modules
         m = Transfusion(**kw)
         return m.to(self.device) if self.device.type == 'cuda' else m
 
