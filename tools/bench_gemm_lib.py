@@ -1,0 +1,21 @@
+"""Library yardstick for the NT GEMM shapes of the training step: torch.matmul (hipBLASLt / rocBLAS under PyTorch-ROCm) against tfx_gemm_nt on the
+same random bf16 operands.  NOT part of the product (no library GEMM is linked into libtfx_hip.so): it tells how far the hand-written kernels are
+from what AMD's tuned library reaches at these shapes.   python tools/bench_gemm_lib.py"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transfusion_pytorch_amd import capi
+from bench_gemm import timeit, st, dev, BF
+
+T = 65536
+for (N, K) in [(1544, 512), (512, 512), (2816, 512), (512, 1408), (1408, 512), (1536, 1024), (1024, 1024), (4096, 4096)]:
+    M = T if N * K < 4096 * 4096 else 8192
+    A = torch.randn(M, K, device=dev).to(BF); B = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
+    C = torch.empty(M, N, device=dev, dtype=BF)
+    a = capi.make_args('tfx_gemm_nt_args', A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS['TFX_EPI_BF16'], C=C, ldc=N)
+    t_own = timeit(lambda: capi.call('tfx_gemm_nt', a, st()))
+    Bt = B.t()
+    t_lib = timeit(lambda: torch.matmul(A, Bt, out=C))
+    fl = 2 * M * N * K
+    print(f'NT {M}x{N}x{K}: tfx {t_own * 1e6:8.1f} us {fl / t_own / 1e12:7.1f} TF/s | torch.matmul {t_lib * 1e6:8.1f} us {fl / t_lib / 1e12:7.1f} TF/s | tfx / lib = {t_lib / t_own:.2f}x')
