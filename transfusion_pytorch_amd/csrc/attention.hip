@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(tfx_attn_args p) {
 #pragma unroll
   for (int e = 0; e < 8; e++) { float d = bf2f(d8[e]); dl += d * bf2f(o8[e]); e8[e] = f2bf(d * g); }
   *(bf16x8*)(p.do_eff + (size_t)t * p.ld_do + h * DH + sub * 8) = e8;
-  dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+  dl = group8_sum(dl);
   if (sub == 0) {
     const unsigned bb = t / (unsigned)p.n, i = t - bb * p.n;
     p.delta[((size_t)bb * p.h + h) * p.n + i] = dl;

@@ -19,6 +19,44 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 TFX_DEV float bf2f(bf16 v) { return (float)v; }
 TFX_DEV bf16 f2bf(float v) { return (bf16)v; }   // round-to-nearest-even
 
+// Wave-wide reductions on the VALU's DPP path (no LDS): `__shfl_xor` compiles to ds_bpermute_b32 - an LDS round trip of ~50+ cycles per step,
+// six steps per reduction, and the token-wise kernels chain several reductions per token.  Quad swaps, half-row / row mirrors, then
+// row_bcast15 / row_bcast31 (gfx9 DPP controls) leave the total in lane 63; v_readlane makes it wave-uniform.
+// -DTFX_BPERMUTE_REDUCE keeps the shuffle form (A/B).
+#ifndef TFX_BPERMUTE_REDUCE
+#define TFX_DPP_STEP(OP, V, CTRL, ROWMASK, IDENT)                                                                     \
+  V = OP(V, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(IDENT)),            \
+                                                                    __builtin_bit_cast(int, V), CTRL, ROWMASK, 0xf, false)))
+TFX_DEV float dpp_add_(float a, float b) { return a + b; }
+TFX_DEV float dpp_max_(float a, float b) { return fmaxf(a, b); }
+TFX_DEV float wave_sum(float v) {
+  TFX_DPP_STEP(dpp_add_, v, 0xB1, 0xf, 0.f);      // quad_perm [1,0,3,2]
+  TFX_DPP_STEP(dpp_add_, v, 0x4E, 0xf, 0.f);      // quad_perm [2,3,0,1]
+  TFX_DPP_STEP(dpp_add_, v, 0x141, 0xf, 0.f);     // row_half_mirror
+  TFX_DPP_STEP(dpp_add_, v, 0x140, 0xf, 0.f);     // row_mirror: every lane of a 16-lane row holds the row sum
+  TFX_DPP_STEP(dpp_add_, v, 0x142, 0xa, 0.f);     // row_bcast15 into rows 1, 3
+  TFX_DPP_STEP(dpp_add_, v, 0x143, 0xc, 0.f);     // row_bcast31 into rows 2, 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+TFX_DEV float wave_max(float v) {
+  TFX_DPP_STEP(dpp_max_, v, 0xB1, 0xf, -INFINITY);
+  TFX_DPP_STEP(dpp_max_, v, 0x4E, 0xf, -INFINITY);
+  TFX_DPP_STEP(dpp_max_, v, 0x141, 0xf, -INFINITY);
+  TFX_DPP_STEP(dpp_max_, v, 0x140, 0xf, -INFINITY);
+  TFX_DPP_STEP(dpp_max_, v, 0x142, 0xa, -INFINITY);
+  TFX_DPP_STEP(dpp_max_, v, 0x143, 0xc, -INFINITY);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// sum over each aligned group of 8 lanes, in all 8 of them (per-head reductions: 8 lanes x 8 elements = one 64-wide head)
+TFX_DEV float group8_sum(float v) {
+  TFX_DPP_STEP(dpp_add_, v, 0xB1, 0xf, 0.f);
+  TFX_DPP_STEP(dpp_add_, v, 0x4E, 0xf, 0.f);
+  TFX_DPP_STEP(dpp_add_, v, 0x141, 0xf, 0.f);
+  return v;
+}
+#undef TFX_DPP_STEP
+#else
+TFX_DEV float group8_sum(float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; }
 TFX_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -29,6 +67,7 @@ TFX_DEV float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+#endif
 
 // XCD-aware, bijective block remap (cdna_hip_programming.md T1): each of the 8 XCDs (private L2)
 // gets a contiguous chunk of tile ids so neighbouring tiles share operand panels in L2.

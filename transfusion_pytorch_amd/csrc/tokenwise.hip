@@ -476,22 +476,32 @@ template <int NC> __global__ __launch_bounds__(256) void attnres_fwd_k(tfx_attnr
 #pragma unroll
     for (int e = 0; e < 8; e++) { w.v[i][e] = (1.f + w.v[i][e]) * pq.v[i][e]; o.v[i][e] = 0.f; }
   float m = -INFINITY, den = 0.f;
-  for (int l = 0; l < p.L; l++) {
-    Row<NC> h; load_row(h, p.hiddens + (size_t)l * p.stride_h + (size_t)t * d, d, lane);
-    float nsq = 0.f, dt = 0.f;
+  constexpr int PF = NC == 1 ? 4 : 2;          // rows requested before the first of them is reduced (see attnres_bwd_k)
+  for (int l0 = 0; l0 < p.L; l0 += PF) {
+    RowRaw<NC> hr[PF];
 #pragma unroll
-    for (int i = 0; i < NC; i++)
+    for (int j = 0; j < PF; j++)
+      if (l0 + j < p.L) load_raw(hr[j], p.hiddens + (size_t)(l0 + j) * p.stride_h + (size_t)t * d, d, lane);
 #pragma unroll
-      for (int e = 0; e < 8; e++) { nsq += h.v[i][e] * h.v[i][e]; dt += h.v[i][e] * w.v[i][e]; }
-    nsq = wave_sum(nsq); dt = wave_sum(dt);
-    const float s = dt / fmaxf(sqrtf(nsq), 1e-12f);
-    const float mn = fmaxf(m, s);
-    const float al = __expf(m - mn), ex = __expf(s - mn);
-    den = den * al + ex; m = mn;
+    for (int j = 0; j < PF; j++) {
+      if (l0 + j < p.L) {
+        Row<NC> h; widen(h, hr[j]);
+        float nsq = 0.f, dt = 0.f;
 #pragma unroll
-    for (int i = 0; i < NC; i++)
+        for (int i = 0; i < NC; i++)
 #pragma unroll
-      for (int e = 0; e < 8; e++) o.v[i][e] = o.v[i][e] * al + ex * h.v[i][e];
+          for (int e = 0; e < 8; e++) { nsq += h.v[i][e] * h.v[i][e]; dt += h.v[i][e] * w.v[i][e]; }
+        nsq = wave_sum(nsq); dt = wave_sum(dt);
+        const float s = dt / fmaxf(sqrtf(nsq), 1e-12f);
+        const float mn = fmaxf(m, s);
+        const float al = __expf(m - mn), ex = __expf(s - mn);
+        den = den * al + ex; m = mn;
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) o.v[i][e] = o.v[i][e] * al + ex * h.v[i][e];
+      }
+    }
   }
   const float inv = 1.f / den;
 #pragma unroll
@@ -522,41 +532,63 @@ template <int NC> __global__ __launch_bounds__(256) void attnres_bwd_k(tfx_attnr
 #pragma unroll
         for (int e = 0; e < 8; e++) g.v[i][e] += g2.v[i][e];
     }
-    // pass 1: lane l keeps (score, inverse norm, <g,h_l>) of hidden l   (L <= 64)
+    // pass 1: lane l keeps (score, inverse norm, <g,h_l>) of hidden l   (L <= 64).  Rows are requested PF at a time (raw bf16) before the
+    // first of them is reduced: one wave then keeps PF rows in flight instead of one (the kernel is request-latency bound otherwise)
     float s_l = -INFINITY, inv_l = 0.f, da_l = 0.f;
-    for (int l = 0; l < p.L; l++) {
-      Row<NC> h; load_row(h, p.hiddens + (size_t)l * p.stride_h + (size_t)t * d, d, lane);
-      float nsq = 0.f, dt = 0.f, da = 0.f;
+    constexpr int PF = NC == 1 ? 4 : 2;
+    for (int l0 = 0; l0 < p.L; l0 += PF) {
+      RowRaw<NC> hr[PF];
 #pragma unroll
-      for (int i = 0; i < NC; i++)
+      for (int j = 0; j < PF; j++)
+        if (l0 + j < p.L) load_raw(hr[j], p.hiddens + (size_t)(l0 + j) * p.stride_h + (size_t)t * d, d, lane);
 #pragma unroll
-        for (int e = 0; e < 8; e++) { nsq += h.v[i][e] * h.v[i][e]; dt += h.v[i][e] * w.v[i][e]; da += h.v[i][e] * g.v[i][e]; }
-      nsq = wave_sum(nsq); dt = wave_sum(dt); da = wave_sum(da);
-      const float inv = 1.f / fmaxf(sqrtf(nsq), 1e-12f);
-      if (lane == l) { s_l = dt * inv; inv_l = inv; da_l = da; }
+      for (int j = 0; j < PF; j++) {
+        if (l0 + j < p.L) {
+          Row<NC> h; widen(h, hr[j]);
+          float nsq = 0.f, dt = 0.f, da = 0.f;
+#pragma unroll
+          for (int i = 0; i < NC; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { nsq += h.v[i][e] * h.v[i][e]; dt += h.v[i][e] * w.v[i][e]; da += h.v[i][e] * g.v[i][e]; }
+          nsq = wave_sum(nsq); dt = wave_sum(dt); da = wave_sum(da);
+          const float inv = 1.f / fmaxf(sqrtf(nsq), 1e-12f);
+          if (lane == l0 + j) { s_l = dt * inv; inv_l = inv; da_l = da; }
+        }
+      }
     }
     const float mx = wave_max(s_l);
     const float ex = (lane < p.L) ? __expf(s_l - mx) : 0.f;
     const float a_l = ex / wave_sum(ex);
     const float dsum = wave_sum(a_l * da_l);
     const float ds_l = a_l * (da_l - dsum);
-    // pass 2
-    for (int l = 0; l < p.L; l++) {
-      const float a = __shfl(a_l, l, 64), ds = __shfl(ds_l, l, 64), inv = __shfl(inv_l, l, 64), s = __shfl(s_l, l, 64);
-      const bf16* hp = p.hiddens + (size_t)l * p.stride_h + (size_t)t * d;
-      bf16* dp = p.dhiddens + (size_t)l * p.stride_dh + (size_t)t * d;
-      Row<NC> h, dh; load_row(h, hp, d, lane);
-      if (!p.first) load_row(dh, dp, d, lane);
-      const float k1 = ds * inv, k2 = ds * s * inv * inv;
+    // pass 2: the rows of hidden l + 1 (and its gradient, when accumulating) are requested before hidden l is updated
+    RowRaw<NC> hq[2], dq[2];
+    load_raw(hq[0], p.hiddens + (size_t)t * d, d, lane);
+    if (!p.first) load_raw(dq[0], p.dhiddens + (size_t)t * d, d, lane);
+    for (int l = 0; l < p.L; l += 2) {
 #pragma unroll
-      for (int i = 0; i < NC; i++)
+      for (int b = 0; b < 2; b++) {
+        const int ll = l + b;
+        if (ll < p.L) {
+          if (ll + 1 < p.L) {
+            load_raw(hq[b ^ 1], p.hiddens + (size_t)(ll + 1) * p.stride_h + (size_t)t * d, d, lane);
+            if (!p.first) load_raw(dq[b ^ 1], p.dhiddens + (size_t)(ll + 1) * p.stride_dh + (size_t)t * d, d, lane);
+          }
+          const float a = __shfl(a_l, ll, 64), ds = __shfl(ds_l, ll, 64), inv = __shfl(inv_l, ll, 64), sc = __shfl(s_l, ll, 64);
+          Row<NC> h, dh; widen(h, hq[b]);
+          if (!p.first) widen(dh, dq[b]);
+          const float k1 = ds * inv, k2 = ds * sc * inv * inv;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          float v = a * g.v[i][e] + k1 * w.v[i][e] - k2 * h.v[i][e];
-          dh.v[i][e] = p.first ? v : dh.v[i][e] + v;
-          pw.v[i][e] += k1 * h.v[i][e];
+          for (int i = 0; i < NC; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              float v = a * g.v[i][e] + k1 * w.v[i][e] - k2 * h.v[i][e];
+              dh.v[i][e] = p.first ? v : dh.v[i][e] + v;
+              pw.v[i][e] += k1 * h.v[i][e];
+            }
+          store_row(dh, p.dhiddens + (size_t)ll * p.stride_dh + (size_t)t * d, d, lane);
         }
-      store_row(dh, dp, d, lane);
+      }
     }
   }
   // d gamma = dw * pq ; d pq = dw * (1 + gamma)
@@ -620,7 +652,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args 
   float v[8], q = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
-  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+  q = group8_sum(q);
   const float r = (p.norm_scale > 0.f ? p.norm_scale : 8.f) / fmaxf(sqrtf(q), 1e-12f) * (which == 0 ? p.q_scale : 1.f);
   const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
   const int pos = p.rot_pos[t];
@@ -658,7 +690,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args 
     float v[8], q = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
-    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+    q = group8_sum(q);
     const float nrm = fmaxf(sqrtf(q), 1e-12f), inv = 1.f / nrm;
     const float sc = (which == 0 ? p.q_scale : 1.f) * (p.norm_scale > 0.f ? p.norm_scale : 8.f);
     const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
@@ -678,7 +710,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args 
       dyn[2 * i] = ga * ca; dyn[2 * i + 1] = gb * cb;
       S += dyn[2 * i] * v[2 * i] + dyn[2 * i + 1] * v[2 * i + 1];
     }
-    S += __shfl_xor(S, 1, 64); S += __shfl_xor(S, 2, 64); S += __shfl_xor(S, 4, 64);
+    S = group8_sum(S);
     const float k = S * inv * inv * inv;
     bf16x8 o;
 #pragma unroll
