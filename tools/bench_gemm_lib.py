@@ -19,3 +19,19 @@ for (N, K) in [(1544, 512), (512, 512), (2816, 512), (512, 1408), (1408, 512), (
     t_lib = timeit(lambda: torch.matmul(A, Bt, out=C))
     fl = 2 * M * N * K
     print(f'NT {M}x{N}x{K}: tfx {t_own * 1e6:8.1f} us {fl / t_own / 1e12:7.1f} TF/s | torch.matmul {t_lib * 1e6:8.1f} us {fl / t_lib / 1e12:7.1f} TF/s | tfx / lib = {t_lib / t_own:.2f}x')
+
+# weight-gradient shapes: C[N, K] = A[M, N]^T B[M, K], contraction over the M = 65536 tokens (tfx_gemm_tn: split-M + fp32 atomics)
+for (N, K) in [(512, 512), (2816, 512), (512, 1408), (1544, 512), (1024, 1024), (1024, 4096)]:
+    M = T
+    A = torch.randn(M, N, device=dev).to(BF); B = torch.randn(M, K, device=dev).to(BF)
+    C = torch.zeros(N, K, device=dev)
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    best = None
+    for splits in ((1,) if tiles >= 512 else (8, 16, 32, 64)):
+        a = capi.make_args('tfx_gemm_tn_args', A=A, lda=N, a_cols=N, B=B, ldb=K, b_cols=K, M=M, N=N, K=K, C=C, ldc=K, k_valid=K, splits=splits, accumulate=1, alpha=1.0)
+        t = timeit(lambda: capi.call('tfx_gemm_tn', a, st()))
+        best = t if best is None else min(best, t)
+    At = A.t(); Cb = torch.empty(N, K, device=dev, dtype=BF)
+    t_lib = timeit(lambda: torch.matmul(At, B, out=Cb))
+    fl = 2 * M * N * K
+    print(f'TN {M}: {N}x{K}: tfx {best * 1e6:8.1f} us {fl / best / 1e12:7.1f} TF/s | torch.matmul {t_lib * 1e6:8.1f} us {fl / t_lib / 1e12:7.1f} TF/s | tfx / lib = {t_lib / best:.2f}x')
