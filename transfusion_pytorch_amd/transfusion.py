@@ -972,8 +972,6 @@ class Transfusion(nn.Module):
                 self.modality_encoder[t].eval()
                 modalities = self.modality_encoder[t](modalities).detach()
         ext = t in self._ext
-        if ext and ema is not None:
-            raise NotImplementedError('velocity consistency is not wired for pre_post_transformer_enc_dec modality types')
         b = modalities.shape[0]
         if times is None:
             times = torch.rand(b, device=dev)                                              # T:2746-2747
@@ -1060,7 +1058,18 @@ class Transfusion(nn.Module):
         flow_loss = torch.zeros((), device=dev) if ext else plan.acc[2 + t] / (rows * dl)   # T:2817
         loss = flow_loss
         velocity_loss = None
-        if ema is not None:
+        if ema is not None and ext:
+            # same term for a type whose maps are user modules: the teacher's flow comes back in the raw layout, the mse is PyTorch's
+            was_training = ema.training
+            ema.eval()
+            try:
+                with torch.no_grad():
+                    teacher = ema.forward_modality(raw, times=orig_times + velocity_consistency_delta_time, modality_type=t, encode_modality=False, return_loss=False)
+                    velocity_loss = torch.nn.functional.mse_loss(flow_ext, teacher)
+            finally:
+                ema.train(was_training)
+            loss = loss + self.velocity_consistency_loss_weight * velocity_loss
+        elif ema is not None:
             # T:2823-2836: mse(FLOW TARGET, teacher flow at t + delta on the clean input) - no gradient reaches the student through it
             was_training = ema.training
             ema.eval()
@@ -1300,6 +1309,9 @@ class Transfusion(nn.Module):
         kw['pre_post_transformer_enc_dec'] = copy.deepcopy(kw.get('pre_post_transformer_enc_dec'))     # learnable: the copy owns its own modules
         m = Transfusion(**kw)
         return m.to(self.device) if self.device.type == 'cuda' else m
+
+    def create_dataloader(self, *args, **kwargs):                   # T:1676-1679
+        return create_dataloader(*args, **kwargs)
 
     def create_ema(self, beta=0.99, *ema_kwargs):                   # T:1681-1699
         from .ema import EMA
