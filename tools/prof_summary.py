@@ -1,5 +1,5 @@
 """Compact summary of a rocprofv3 kernel trace (csv): per kernel (short name) and optionally per grid size.
-    python tools/prof_summary.py gpurun_out/prof2/r2_kernel_trace.csv [--by-grid SUBSTR] [--steps N]"""
+    python tools/prof_summary.py gpurun_out/prof2/r2_kernel_trace.csv [--by-grid SUBSTR] [--steps N | --steady]"""
 import csv
 import re
 import sys
@@ -21,6 +21,16 @@ def main():
     by_grid = sys.argv[sys.argv.index('--by-grid') + 1] if '--by-grid' in sys.argv else None
     steps = int(sys.argv[sys.argv.index('--steps') + 1]) if '--steps' in sys.argv else 1
     rows = list(csv.DictReader(open(path)))
+    if '--steady' in sys.argv:
+        # steady state only: the kernels between the first and the last optimizer launch (`adam_k` closes a training step) - model construction,
+        # warm-up allocation and the synthetic-batch generator (hundreds of tiny at:: kernels) stay out of the per-step figures
+        rows.sort(key=lambda r: int(r['Start_Timestamp']))
+        marks = [i for i, r in enumerate(rows) if 'adam_k' in r['Kernel_Name']]
+        assert len(marks) >= 2, 'need at least two optimizer launches for --steady'
+        spans = [(a + 1, b + 1) for a, b in zip(marks[:-1], marks[1:])]
+        small = min(b - a for a, b in spans)
+        spans = [(a, b) for a, b in spans if b - a <= 1.5 * small]          # drop bench.py's structure-miss step (thousands of tiny upload kernels)
+        rows, steps = [r for a, b in spans for r in rows[a:b]], len(spans)
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     for r in rows:
         nm = short(r['Kernel_Name'])
