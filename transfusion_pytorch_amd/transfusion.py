@@ -8,6 +8,7 @@ Unsupported reference options raise NotImplementedError - there is no silent PyT
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import NamedTuple
 
 import numpy as np
@@ -38,6 +39,9 @@ def default_to_modality_shape_fn(maybe_shape_str):       # T:176-177
 
 def cast_tuple(t, length=1):
     return t if isinstance(t, tuple) else ((t,) * length)
+
+
+_TRAIN_PAD = max(1, int(os.environ.get('TFX_TRAIN_PAD', '64')))
 
 
 class KVCacheView(torch.Tensor):
@@ -429,8 +433,12 @@ class Transfusion(nn.Module):
         P = self._scan(modalities, add_sos_eos=return_loss, add_meta=add_meta)
         b = P.b
         n = P.n_full - 1 if return_loss else P.n_full
+        n_true = n
         if pad_n > 1 and n % pad_n:
-            n_new = (n + pad_n - 1) // pad_n * pad_n
+            # padding columns sit AFTER every real token of a row: causal attention keeps them out of the real tokens' sight, they carry label -1
+            # (no loss, zero gradient) and text id -1 (embedded as id 0); `total_tokens` and the loss weights count real tokens only
+            n = (n + pad_n - 1) // pad_n * pad_n
+            n_new = n + 1 if return_loss else n                  # the training layout keeps one extra column: labels are ids shifted by one (T:3144)
             old = P.n_full
             th = np.full((b, n_new), -1, dtype=np.int32); th[:, :old] = P.text_host; P.text_host = th
             cd = np.zeros((b, n_new), dtype=bool); cd[:, :old] = P.cfg_droppable; P.cfg_droppable = cd
@@ -438,7 +446,7 @@ class Transfusion(nn.Module):
             for t in P.row_pos:
                 rp = P.row_pos[t].astype(np.int64)
                 P.row_pos[t] = ((rp // old) * n_new + (rp % old)).astype(np.int32)
-            P.n_full = n = n_new
+            P.n_full = n_new
         tm = token_maps(P, n, self.num_modalities)
         seg_start, seg_len = token_segments(tm.tok_inst)
         D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -449,7 +457,7 @@ class Transfusion(nn.Module):
             rb, rl = rp // P.n_full, rp % P.n_full
             row_tok[t] = D(np.where(rl < n, rb * n + rl, -1).astype(np.int32))
         tok_inst = D(tm.tok_inst)
-        S = dict(P=P, tm=tm, b=b, n=n, I=len(P.inst_b), R=R, num_mod=np.bincount(P.inst_b, minlength=b),
+        S = dict(P=P, tm=tm, b=b, n=n, n_true=n_true, I=len(P.inst_b), R=R, num_mod=np.bincount(P.inst_b, minlength=b),
                  text_host=D(P.text_host), text_dest=D(P.text_dest), cfg_droppable=D(P.cfg_droppable), tok_inst=tok_inst,
                  kv_end=D(tm.kv_end.reshape(-1)), q_start=D(tm.q_start.reshape(-1)), rot_pos=D(tm.rot_pos.reshape(-1)),
                  is_mod=tok_inst >= 0, minus1=torch.full((b, n), -1, dtype=torch.int32, device=dev),
@@ -587,9 +595,12 @@ class Transfusion(nn.Module):
         if S is None:
             while len(self._struct_cache) >= 32:                      # least recently used structure goes first (dict order = use order)
                 self._struct_cache.pop(next(iter(self._struct_cache)))
-            S = self._build_structure(modalities, return_loss, add_meta=add_meta)
+            # training lengths are bucketed to multiples of 64 (TFX_TRAIN_PAD; 1 = exact): ragged data then shares a handful of plans - a plan
+            # owns every activation of the step and its launch lists, building one costs far more than the padding columns
+            S = self._build_structure(modalities, return_loss, add_meta=add_meta, pad_n=_TRAIN_PAD if return_loss else 1)
         self._struct_cache[skey] = S
         P, tm, b, n, I, R = S['P'], S['tm'], S['b'], S['n'], S['I'], S['R']
+        self._live_n_true = S['n_true']
 
         # ---- times (T:3075-3082)
         if times is None:
