@@ -230,6 +230,13 @@ typedef struct {
   /* model_output_clean (T:1297, MP:100-126): `pred` already holds (out - noised) / max(1 - t, clean_eps) (tfx_output_to_flow);
    * the gradient wrt the model output carries the same 1 / max(1 - t, clean_eps).  row_inst NULL = off */
   const int32_t* row_inst; const float* inst_time; float clean_eps;
+  /* reconstruction loss (`reconstruction_loss_weight`, MP:177-200 / T:2840-2853): recon_w non-NULL switches the residual to
+   *   (1 - t) pred - c flow,   t = recon_time[recon_inst[row]],   c = t (recon_mode 0: target = the noised latent, interleaved forward)
+   *                                                               c = 1 (recon_mode 1: target = the clean latent, forward_modality)
+   * - algebraically noised - (noise + pred (1 - t)) resp. clean - (noise + pred (1 - t)) with flow = clean - noise - and weights every row by
+   * recon_w[row] (1 / (instances of the type x rows of the instance): the reference averages per-instance means); acc += sum w r^2,
+   * d pred (+)= grad_scale w (1 - t) r */
+  const float* recon_w; const int32_t* recon_inst; const float* recon_time; int32_t recon_mode;
 } tfx_mse_args;
 int tfx_mse_fwd_bwd(const tfx_mse_args* a, void* stream);
 /* model_output_clean: pred[r][c] <- (pred[r][c] - noised[r][c]) / max(1 - t_r, clean_eps), noised = eps ? x*t + eps*(1-t) : x,

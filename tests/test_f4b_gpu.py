@@ -172,3 +172,51 @@ def test_unet_encoder_decoder_around_the_transformer_matches_reference_golden():
 
 def prompt_ids():
     return torch.randint(0, 256, (4,)).cuda()
+
+
+def test_reconstruction_loss_matches_reference_golden():
+    """`reconstruction_loss_weight > 0` (T:1522-1525): interleaved forward (per type the mean over instances of mse(noised, noise + pred (1 - t)),
+    MP:177-200, T:3420-3431 - the native residual kernel adds its gradient to the same flow-prediction seeds), forward_modality without decoder
+    (target = the clean latent, gradient) and through a frozen decoder (no gradient, T:2845-2848).  Golden tests/golden/recon1.pt."""
+    from oracle.cases import build_case, default_shapes
+    from oracle.make_golden_f4 import enc_dec, f4_case
+    from oracle.make_golden_recon import WEIGHT, recon_inputs
+    from transfusion_pytorch_amd import Transfusion
+    g = torch.load(os.path.join(GOLDEN, 'recon1.pt'), weights_only=False)
+    cfg, sd, batch, times, noise = build_case('small2')
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents, modality_default_shape=default_shapes(cfg), reconstruction_loss_weight=WEIGHT,
+                        prob_uncond=0., transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    model._noise_override = {t: v.cuda() for t, v in noise.items()}
+    loss, bd = model(to_cuda(batch), times=times, return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    print('[recon] interleaved step')
+    close(loss, g['loss'], 'loss'); close(bd.text, g['text_loss'], 'text')
+    for i, (a, r) in enumerate(zip(bd.flow, g['flow_losses'])):
+        close(a, r, f'flow{i}')
+    assert len(bd.recon) == len(g['recon']) == 2
+    for i, (a, r) in enumerate(zip(bd.recon, g['recon'])):
+        close(a, r, f'recon{i}')
+    check_grads(model, g['grad_norms'], g['grad_heads'], 'interleaved')
+    for p in model.parameters():
+        p.grad = None
+    xm, nm, tm = recon_inputs()
+    model._noise_override = {0: nm.reshape(-1, cfg.dim_latents[0]).cuda()}
+    lm, (fl, vl, rl) = model.forward_modality(xm.cuda(), times=tm, modality_type=0, return_loss_breakdown=True)
+    lm.backward()
+    print('[recon] forward_modality')
+    close(lm, g['fm_loss'], 'loss'); close(fl, g['fm_flow'], 'flow'); close(rl, g['fm_recon'], 'recon')
+    check_grads(model, g['fm_grad_norms'], g['fm_grad_heads'], 'forward_modality')
+    # through the frozen decoder of the f4 golden: a value without gradient
+    cfg4, sd4, _, _, _, xm4, nm4, tm4, _ = f4_case()
+    enc, dec = enc_dec()
+    m4 = Transfusion(num_text_tokens=cfg4.num_text_tokens, dim_latent=16, channel_first_latent=True, modality_default_shape=(4,), modality_encoder=enc, modality_decoder=dec,
+                     reconstruction_loss_weight=WEIGHT, prob_uncond=0., transformer=dict(dim=cfg4.dim, depth=cfg4.depth, dim_head=cfg4.dim_head, heads=cfg4.heads))
+    m4.load_state_dict(sd4, strict=False)
+    m4 = m4.cuda().train()
+    m4._noise_override = {0: nm4.movedim(1, -1).reshape(-1, 16).cuda()}
+    l4, (f4, v4, r4) = m4.forward_modality(xm4.cuda(), times=tm4, return_loss_breakdown=True)
+    print('[recon] forward_modality through the frozen decoder')
+    close(l4, g['dec_loss'], 'loss'); close(f4, g['dec_flow'], 'flow'); close(r4, g['dec_recon'], 'recon')

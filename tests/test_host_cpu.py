@@ -126,8 +126,9 @@ def test_unsupported_options_raise_and_no_cpu_fallback():
     with pytest.raises(NotImplementedError):
         Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1, dim_head=128))   # kernels hold 64 columns per head
     Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=2, dim_head=8, use_flex_attn=True))   # small heads run zero-padded; flex = backend name only
+    assert Transfusion(num_text_tokens=8, dim_latent=16, reconstruction_loss_weight=0.1, transformer=dict(dim=64, depth=1, heads=1)).has_recon_loss
     with pytest.raises(NotImplementedError):
-        Transfusion(num_text_tokens=8, dim_latent=16, reconstruction_loss_weight=0.1, transformer=dict(dim=64, depth=1, heads=1))
+        Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1, dropout=0.1))
     with pytest.raises(AssertionError):                   # T:1396: the positional embedding needs the number of axial dimensions
         Transfusion(num_text_tokens=8, dim_latent=16, add_pos_emb=True, transformer=dict(dim=64, depth=1, heads=1))
     m = Transfusion(num_text_tokens=8, dim_latent=16, transformer=dict(dim=64, depth=1, heads=1))

@@ -800,8 +800,15 @@ __global__ __launch_bounds__(256) void mse_k(tfx_mse_args p) {
     const int r = (int)(i / p.ld_d), c = (int)(i % p.ld_d);
     float g = 0.f;
     if (c < p.dl) {
-      float df = p.pred[(size_t)r * p.ld_pred + c] - p.flow[(size_t)r * p.dl + c];
-      s += df * df; g = df * p.grad_scale;
+      const float pr = p.pred[(size_t)r * p.ld_pred + c], fl = p.flow[(size_t)r * p.dl + c];
+      if (p.recon_w) {
+        const float t = p.recon_time[p.recon_inst[r]], w = p.recon_w[r];
+        const float df = (1.f - t) * pr - (p.recon_mode ? 1.f : t) * fl;
+        s += w * df * df; g = df * (p.grad_scale * w * (1.f - t));
+      } else {
+        const float df = pr - fl;
+        s += df * df; g = df * p.grad_scale;
+      }
       if (p.row_inst) g *= 1.f / fmaxf(1.f - p.inst_time[p.row_inst[r]], p.clean_eps);
     }
     p.dpred[i] = f2bf(p.accumulate ? g + bf2f(p.dpred[i]) : g);

@@ -190,8 +190,9 @@ class Plan:
                                flow=e(r, dl, dtype=torch.float32), pred=e(r, dl, dtype=torch.float32), dpred=z(r, dlp))
         for t in self.ext_add:
             self.lat[t]['add'] = z(R[t], d)      # additive token rows: the axial positional embedding (T:1384-1403, T:3173-3176), bf16
-        self.acc = z(max(8, 2 + 2 * len(md.dim_latents)), dtype=torch.float32)      # [ce sum, ce count, flow sse per type..., velocity sse per type...]
+        self.acc = z(max(8, 2 + 3 * len(md.dim_latents)), dtype=torch.float32)      # [ce sum, ce count, flow sse per type..., velocity sse per type..., weighted recon sse per type...]
         self.vel = LaunchList()                         # optional launches: velocity-consistency MSE against an EMA teacher's flows (T:3394-3418)
+        self.rec = LaunchList()                         # optional launches: reconstruction loss on the same predictions (MP:177-200, T:2840-2853)
         self.cos_tab = self.sin_tab = None
         self.fwd, self.bwd = LaunchList(), LaunchList()
         self.noise_args = {}
@@ -373,6 +374,15 @@ class Plan:
                                                dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + len(md.dim_latents) + t), accumulate=1,
                                                **(dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}))
             self.vel.append(('tfx_mse_fwd_bwd', self._vel_args[t]))
+        self._rec_args = {}
+        for t, r in native.items():          # third target on the same prediction: the reconstruction residual, per-row weights filled per step
+            dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
+            lt['recw'] = torch.zeros(r, device=self.ps.device, dtype=torch.float32)
+            self._rec_args[t] = capi.make_args('tfx_mse_args', R=r, dl=dl, pred=lt['pred'], ld_pred=dl, flow=lt['flow'], grad_scale=0.0,
+                                               dpred=lt['dpred'], ld_d=dlp, acc=self.acc.data_ptr() + 4 * (2 + 2 * len(md.dim_latents) + t), accumulate=1,
+                                               recon_w=lt['recw'], recon_inst=self.row_inst[t], recon_time=self.inst_time, recon_mode=0,
+                                               **(dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}))
+            self.rec.append(('tfx_mse_fwd_bwd', self._rec_args[t]))
 
     def _clean_model_space(self, L, t, r, rowmap):
         """`model_output_clean` (T:1297).  Two conversions exist in the reference:

@@ -128,14 +128,12 @@ class Transfusion(nn.Module):
                                  fallback_to_default_shape_if_invalid=fallback_to_default_shape_if_invalid, modality_num_dim=modality_num_dim,
                                  to_modality_shape_fn=to_modality_shape_fn, ignore_index=ignore_index, flow_loss_weight=flow_loss_weight,
                                  text_loss_weight=text_loss_weight, velocity_consistency_loss_weight=velocity_consistency_loss_weight,
-                                 odeint_kwargs=odeint_kwargs, eps=eps, prob_uncond=prob_uncond, modality_processing=modality_processing)
+                                 reconstruction_loss_weight=reconstruction_loss_weight, odeint_kwargs=odeint_kwargs, eps=eps, prob_uncond=prob_uncond, modality_processing=modality_processing)
         assert modality_processing in PROCESSING_STRATEGIES, \
             f'unknown modality processing strategy `{modality_processing}`, available: {list(PROCESSING_STRATEGIES)}'      # MP:1254-1256
         self.modality_processing = modality_processing
-        unsupported = dict(reconstruction_loss_weight=reconstruction_loss_weight > 0.)
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
-            raise NotImplementedError(f'Transfusion options outside the native hot path (SURVEY.md section 8): {bad}')
+        self.reconstruction_loss_weight = float(reconstruction_loss_weight)                 # T:1522-1525
+        self.has_recon_loss = self.reconstruction_loss_weight > 0.
         if odeint_kwargs.get('method', 'midpoint') != 'midpoint':
             raise NotImplementedError('only the fixed-grid midpoint solver is implemented')
         if isinstance(transformer, dict):
@@ -354,7 +352,7 @@ class Transfusion(nn.Module):
         Returns the batch with those parts replaced by shape-only placeholders of the PROJECTED axial shape - positions, the meta shape string and
         the token count use that one (MP:738-741) - and per type the token rows / flow targets / shapes in scan order."""
         dev, d = self.device, self.md.dim
-        ctx = {t: dict(tok=[], flow=[], shape=[]) for t in self._ext}
+        ctx = {t: dict(tok=[], flow=[], shape=[], eps=[], noised=[], time=[]) for t in self._ext}
         out = []
         for bi, sample in enumerate(modalities):
             m, row = 0, []
@@ -371,7 +369,7 @@ class Transfusion(nn.Module):
                             ov = self._noise_override
                             eps = ov[ty][len(c['tok'])].to(dev, torch.float32) if ov is not None else torch.randn_like(x)
                             noised, flow = x * tt + eps * (1. - tt), x - eps                # MP:717-719
-                            c['flow'].append(flow)
+                            c['flow'].append(flow); c['eps'].append(eps); c['noised'].append(noised); c['time'].append(tt)
                         else:
                             noised = x
                         pre = self.latent_to_model_projs[ty]
@@ -386,14 +384,19 @@ class Transfusion(nn.Module):
 
     def _ext_flow_loss(self, t, rows, ctx):
         """flow loss of an `ext` type: the user's decoder on each instance's embedding rows (add_temp_batch_dim(model_to_latent), T:3300-3301),
-        then ONE mse over all instances of the type packed together (T:3356-3364)"""
+        then ONE mse over all instances of the type packed together (T:3356-3364); with a reconstruction loss also the mean over the instances of
+        mse(noised, noise + pred (1 - t)) (MP:177-200, T:3422-3426).  Returns (flow loss, reconstruction loss | None)."""
         post, d = self.model_to_latent_projs[t], self.md.dim
         preds, lo = [], 0
         for shape in ctx['shape']:
             L = int(np.prod(shape))
-            preds.append(post(rows[lo:lo + L].reshape(1, *shape, d))[0].reshape(-1))
+            preds.append(post(rows[lo:lo + L].reshape(1, *shape, d))[0])
             lo += L
-        return torch.nn.functional.mse_loss(torch.cat(preds), torch.cat([f.reshape(-1) for f in ctx['flow']]))
+        fl = torch.nn.functional.mse_loss(torch.cat([p.reshape(-1) for p in preds]), torch.cat([f.reshape(-1) for f in ctx['flow']]))
+        rec = None
+        if self.has_recon_loss:
+            rec = sum(torch.nn.functional.mse_loss(nz, eps + p * (1. - tt)) for p, nz, eps, tt in zip(preds, ctx['noised'], ctx['eps'], ctx['time'])) / len(preds)
+        return fl, rec
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -464,6 +467,10 @@ class Transfusion(nn.Module):
                  inst_b=D(P.inst_b), inst_m=D(P.inst_m), row_tok=row_tok, row_inst={t: D(P.row_inst[t]) for t in R},
                  seg_start=D(seg_start), seg_len=D(seg_len))
         S['num_mod_dev'] = D(S['num_mod'].astype(np.float32))
+        if self.has_recon_loss and return_loss:
+            # reconstruction loss = mean over the instances of a type of the per-instance mse (T:3422-3426): every row weighs 1 / (instances x its rows)
+            n_inst = np.bincount(P.inst_type, minlength=self.num_modalities).astype(np.float64)
+            S['recw'] = {t: D((1. / (n_inst[t] * P.inst_len[P.row_inst[t]].astype(np.float64))).astype(np.float32)) for t in R}
         P.user_text, P.latents = None, None          # the cache keeps structure only, never the caller's tensors
         return S
 
@@ -731,6 +738,23 @@ class Transfusion(nn.Module):
                 velocity_losses.append(vl)
                 loss = loss + self.velocity_consistency_loss_weight * vl * (float(tm.is_type[t]) / total)
 
+        recon_losses = {}
+        if self.has_recon_loss:                                                            # T:3420-3431
+            M = self.num_modalities
+            for t, r in sorted(R.items()):
+                if t in plan.ext:
+                    continue
+                w_t = float(tm.is_type[t]) / total
+                plan.lat[t]['recw'].copy_(S['recw'][t])
+                ra = plan._rec_args[t]
+                ra.recon_mode, ra.grad_scale = 0, 2.0 * self.reconstruction_loss_weight * w_t / md.dim_latents[t]
+            Plan.run(plan.rec, stream)
+            for t, r in sorted(R.items()):
+                if t in plan.ext:
+                    continue
+                recon_losses[t] = plan.acc[2 + 2 * M + t] / md.dim_latents[t]
+                loss = loss + self.reconstruction_loss_weight * recon_losses[t] * (float(tm.is_type[t]) / total)
+
         self._step_id += 1
         self._live = (plan, self._step_id)
         ext_out = sorted(plan.ext)
@@ -742,15 +766,19 @@ class Transfusion(nn.Module):
         else:
             emb_rows = [plan.embed.index_select(0, plan.row_tok[t].long().clamp(min=0)).float() for t in ext_out]
         for t, rows in zip(ext_out, emb_rows):                                              # the user's decoders and their flow losses, in PyTorch
-            fl = self._ext_flow_loss(t, rows, ext_ctx[t])
+            fl, rec = self._ext_flow_loss(t, rows, ext_ctx[t])
             flow_losses[t] = fl
             loss = loss + self.flow_loss_weight * fl * (float(tm.is_type[t]) / total)
+            if rec is not None:
+                recon_losses[t] = rec
+                loss = loss + self.reconstruction_loss_weight * rec * (float(tm.is_type[t]) / total)
         flow_losses = [flow_losses[t] for t in sorted(flow_losses)]
+        recon_losses = [recon_losses[t] for t in sorted(recon_losses)] if self.has_recon_loss else None
         if not return_breakdown and not return_times:
             return loss
         ret = (loss,)
         if return_breakdown:
-            ret = (*ret, LossBreakdown(loss, text_loss, flow_losses, velocity_losses, None))
+            ret = (*ret, LossBreakdown(loss, text_loss, flow_losses, velocity_losses, recon_losses))
         if return_times:
             ret = (*ret, times)
         return ret
@@ -978,6 +1006,7 @@ class Transfusion(nn.Module):
         t = 0 if modality_type is None else int(modality_type)
         dev, stream, md = self.device, self._stream(), self.md
         modalities = modalities.to(dev)
+        orig_modalities = modalities                                                       # the reconstruction target (T:2722, T:2850-2853)
         if encode_modality and self.modality_encoder[t] is not None:                       # T:2735-2738
             with torch.no_grad():
                 self.modality_encoder[t].eval()
@@ -1099,6 +1128,28 @@ class Transfusion(nn.Module):
             Plan.run(plan.vel, stream)
             velocity_loss = plan.acc[2 + self.num_modalities + t] / (rows * dl)
             loss = loss + self.velocity_consistency_loss_weight * velocity_loss              # T:2858-2862
+        recon_loss = None
+        dec = self.modality_decoder[t]
+        if self.has_recon_loss:                                                            # T:2840-2853
+            assert encode_modality, 'the reconstruction loss needs the un-encoded modality as its target'
+        if self.has_recon_loss and not ext:
+            if dec is None:
+                # recon = noise + pred (1 - t) against the clean latent: the native residual kernel (mode 1), gradient into the same seeds
+                if self.modality_encoder[t] is not None:
+                    raise ValueError('reconstruction loss with a modality encoder needs the matching modality decoder')
+                lt['recw'].fill_(1. / rows)
+                ra = plan._rec_args[t]
+                ra.recon_mode, ra.grad_scale = 1, 2.0 * self.reconstruction_loss_weight / dl
+                Plan.run(plan.rec, stream)
+                recon_loss = plan.acc[2 + 2 * self.num_modalities + t] / dl
+            else:
+                # through the frozen decoder, without gradients (T:2845-2848): a reported term
+                with torch.no_grad():
+                    tt = times.view(b, *([1] * (x.ndim - 1)))
+                    rec = lt['eps'].view(x.shape) + lt['pred'].view(x.shape) * (1. - tt)
+                    dec.eval()
+                    recon_loss = torch.nn.functional.mse_loss(dec(rec.movedim(-1, 1) if self.channel_first_latent[t] else rec), orig_modalities.float())
+            loss = loss + self.reconstruction_loss_weight * recon_loss
         self._step_id += 1
         self._live = (plan, self._step_id)
         emb_rows = None
@@ -1113,10 +1164,18 @@ class Transfusion(nn.Module):
             pred = self.model_to_latent_projs[t](emb_rows[0].view(b, *axial, d))
             flow_loss = torch.nn.functional.mse_loss(pred, flow_ext)
             loss = loss + flow_loss
+            if self.has_recon_loss:
+                rec = eps + pred * (1. - tt)
+                if dec is not None:
+                    with torch.no_grad():
+                        dec.eval()
+                        rec = dec(rec)
+                recon_loss = torch.nn.functional.mse_loss(rec, orig_modalities.float())
+                loss = loss + self.reconstruction_loss_weight * recon_loss
         if not return_loss_breakdown:
             return loss
         zero = torch.zeros((), device=dev)
-        return loss, (flow_loss.detach(), velocity_loss.detach() if velocity_loss is not None else zero, zero)
+        return loss, (flow_loss.detach(), velocity_loss.detach() if velocity_loss is not None else zero, recon_loss.detach() if recon_loss is not None else zero)
 
     @torch.no_grad()
     def generate_modality_only(self, batch_size=1, modality_type=None, fixed_modality_shape=None, modality_steps=16,
