@@ -1,0 +1,314 @@
+"""The scenarios of the reference's own end-to-end tests (tests/test_transfusion.py) on the native model: same constructor arguments, inputs and
+calls, same assertions - only the model width differs (dim 64 instead of 16: the kernels need dim % 64 == 0), and the model lives on the GPU.
+Each test names the reference test it restates.  SelfMaskedRepTraining (test_self_flow, test_e2e_self_flow_with_cfg) is outside SURVEY section 8
+and has no counterpart here; the flex-attention parametrisations select a backend of the reference and are covered by `use_flex_attn=True` once."""
+import copy
+from functools import partial
+
+import pytest
+import torch
+from torch import nn, randint, randn, tensor
+
+pytestmark = pytest.mark.gpu
+
+from transfusion_pytorch_amd import (Transfusion, apply_fn_modality_type, exists, filter_with_inverse,                     # noqa: E402
+                                     random_modality_length_to_time_fn, stack_same_shape_tensors_with_inverse)
+
+DIM = 64
+
+
+def cu(x):
+    """move a sample / batch / prompt to the GPU (the reference's tests run on the CPU and let the model move things)"""
+    if torch.is_tensor(x):
+        return x.cuda()
+    if isinstance(x, tuple):
+        return (x[0], cu(x[1]))
+    if isinstance(x, list):
+        return [cu(p) for p in x]
+    return x
+
+
+@pytest.mark.parametrize('cache_kv', (False, True))
+@pytest.mark.parametrize('reconstruction_loss_weight', (0., 0.1))
+@pytest.mark.parametrize('model_output_clean', (False, True))
+def test_transfusion(cache_kv, reconstruction_loss_weight, model_output_clean):           # tests/test_transfusion.py:25-74
+    randint_ = partial(randint, 0, 8)
+    model = Transfusion(num_text_tokens=8, dim_latent=(16, 16), modality_default_shape=((8,), (4,)), reconstruction_loss_weight=reconstruction_loss_weight,
+                        model_output_clean=model_output_clean, transformer=dict(dim=DIM, depth=1, use_flex_attn=True)).cuda()
+    batch = [[randint_((16,)), (0, randn(4, 16)), randint_((8,)), (1, randn(6, 16))],
+             [randint_((16,)), randn(7, 16), randint_((5,)), (1, randn(2, 16)), randint_((9,))]]
+    loss = model(cu(batch))
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None for p in model.parameters() if p.requires_grad)
+    prime = [tensor(model.som_ids[0]).cuda()]
+    assert len(model.sample(prime, max_length=4, cache_kv=cache_kv)) > 0
+
+
+def test_auto_modality_transform():                                                     # :76-112
+    randint_ = partial(randint, 0, 8)
+    model = Transfusion(num_text_tokens=8, dim_latent=16, channel_first_latent=True, modality_default_shape=(2, 2), transformer=dict(dim=DIM, depth=1)).cuda()
+    batch = [[randint_((16,)), randn(16, 2, 2), randint_((8,)), randn(16, 2, 2)],
+             [randint_((16,)), randn(16, 2, 2), randint_((5,)), randn(16, 2, 2), randint_((9,))]]
+    model(cu(batch)).backward()
+    model.sample([tensor(model.som_ids[0]).cuda()], max_length=4)
+
+
+@pytest.mark.parametrize('return_loss', (False, True))
+def test_text(return_loss):                                                             # :114-141
+    model = Transfusion(num_text_tokens=256, dim_latent=16, channel_first_latent=True, modality_default_shape=(8,), transformer=dict(dim=DIM, depth=1)).cuda()
+    out = model(randint(0, 256, (2, 64)).cuda(), return_loss=return_loss)
+    assert out.shape == (() if return_loss else (2, 64, model.vocab_size()))
+
+
+@pytest.mark.parametrize('channel_first', (False, True))
+def test_modality_only(channel_first):                                                  # :143-169
+    model = Transfusion(num_text_tokens=256, dim_latent=(16, 16), channel_first_latent=channel_first, modality_default_shape=(8,), transformer=dict(dim=DIM, depth=1)).cuda()
+    images = randn(2, 4, 4, 16)
+    if channel_first:
+        images = images.movedim(-1, 1)
+    loss = model(images.cuda(), return_loss=True, modality_type=1)
+    loss.backward()
+    out = model.generate_modality_only(modality_type=1)
+    assert out.shape == ((1, 16, 8) if channel_first else (1, 8, 16))
+
+
+@pytest.mark.parametrize('custom_time_fn', (False, True))
+def test_text_image_end_to_end(custom_time_fn):                                          # :171-228
+    model = Transfusion(num_text_tokens=4, dim_latent=16, channel_first_latent=True, modality_default_shape=((4, 4),),
+                        modality_encoder=nn.Conv2d(3, 16, 3, padding=1), modality_decoder=nn.Conv2d(16, 3, 3, padding=1), transformer=dict(dim=DIM, depth=1)).cuda()
+    batch = [[randint(0, 4, (16,)), randn(3, 8, 8), randint(0, 4, (8,)), randn(3, 7, 7)],
+             [randint(0, 4, (16,)), randn(3, 8, 5), randint(0, 4, (5,)), randn(3, 2, 16), randint(0, 4, (9,))]]
+
+    def all_ones(num_modalities):
+        return torch.ones((num_modalities.shape[0], int(num_modalities.amax())), device=num_modalities.device)
+
+    loss = model(cu(batch), num_modalities_to_times_fn=all_ones if custom_time_fn else None)
+    loss.backward()
+    model.sample(max_length=4)
+
+
+def test_velocity_consistency():                                                        # :230-273
+    model = Transfusion(num_text_tokens=12, dim_latent=16, channel_first_latent=True, modality_default_shape=(4, 4),
+                        modality_encoder=nn.Conv2d(3, 16, 3, padding=1), modality_decoder=nn.Conv2d(16, 3, 3, padding=1), transformer=dict(dim=DIM, depth=1)).cuda()
+    ema_model = copy.deepcopy(model)
+    assert ema_model.store.flat.data_ptr() != model.store.flat.data_ptr() and torch.equal(ema_model.store.flat, model.store.flat)
+    batch = [[randint(0, 12, (16,)), randn(3, 8, 8), randint(0, 12, (8,)), randn(3, 7, 7)],
+             [randint(0, 12, (16,)), randn(3, 8, 5), randint(0, 12, (5,)), randn(3, 2, 16), randint(0, 12, (9,))]]
+    loss, breakdown = model(cu(batch), velocity_consistency_ema_model=ema_model, return_breakdown=True)
+    loss.backward()
+    assert exists(breakdown.velocity)
+
+
+def test_axial_pos_emb():                                                               # :275-304
+    model = Transfusion(num_text_tokens=256, dim_latent=(16, 16), modality_default_shape=((2, 2), (2,)), fallback_to_default_shape_if_invalid=True,
+                        add_pos_emb=True, modality_num_dim=(2, 1), transformer=dict(dim=DIM, depth=1)).cuda()
+    batch = [[randint(0, 256, (16,)), (0, randn(2, 3, 16)), randint(0, 256, (8,)), (1, randn(6, 16))],
+             [randint(0, 256, (16,)), randn(1, 4, 16), randint(0, 256, (5,)), (1, randn(2, 16)), randint(0, 256, (9,))]]
+    model(cu(batch)).backward()
+    assert all(p.grad is not None for p in model.pos_emb_mlp.parameters())
+    model.sample(max_length=4)
+
+
+def test_modality_only_with_unet():                                                     # :308-335
+    model = Transfusion(num_text_tokens=10, dim_latent=4, modality_default_shape=(14, 14),
+                        pre_post_transformer_enc_dec=(nn.Conv2d(4, DIM, 3, 2, 1), nn.ConvTranspose2d(DIM, 4, 3, 2, 1, output_padding=1)),
+                        channel_first_latent=True, add_pos_emb=True, modality_num_dim=2, velocity_consistency_loss_weight=0.1,
+                        transformer=dict(dim=DIM, depth=1, dim_head=8, heads=2)).cuda()
+    model(randn(1, 4, 14, 14).cuda()).backward()
+    assert model.generate_modality_only().shape == (1, 4, 14, 14)
+
+
+def test_helper_functions():                                                            # :337-389
+    data = [torch.zeros(3, 5), torch.zeros(2, 3), torch.zeros(3, 5), torch.zeros(2, 3), torch.zeros(4, 5), torch.zeros(4, 5)]
+    data = [d + i for i, d in enumerate(data)]
+    stacked, inverse = stack_same_shape_tensors_with_inverse(data)
+    back = inverse({k: v + 1 for k, v in stacked.items()})
+    assert all(torch.allclose(a + 1, b) for a, b in zip(data, back))
+    evens, inverse = filter_with_inverse(lambda el: el % 2 == 0, [0, 1, 2, 3, 4])
+    assert inverse([el * 10 for el in evens]) == [0, 1, 20, 3, 40]
+    mods = [[torch.zeros(3, 5)], [torch.zeros(1, 5)], [(1, torch.zeros(3, 5))], [(1, torch.zeros(2, 5))], [(0, torch.zeros(1, 5)), (1, torch.zeros(3, 5))]]
+    mods = apply_fn_modality_type(lambda x: x + 1, mods)
+    mods = apply_fn_modality_type(lambda x: x + 2, mods, modality_type=1)
+    assert (mods[0][0][-1] == 1).all() and (mods[2][0][-1] == 2).all()
+
+
+def test_zero_dimensional():                                                            # :391-416
+    model = Transfusion(num_text_tokens=256, dim_latent=16, modality_default_shape=(), transformer=dict(dim=DIM, depth=1)).cuda()
+    batch = [[randint(0, 256, (16,)), randn(16), randint(0, 256, (8,)), randn(16)],
+             [randint(0, 256, (16,)), randn(16), randint(0, 256, (5,)), randn(16), randint(0, 256, (9,))]]
+    model(cu(batch)).backward()
+    model.sample(prompt=randn(16).cuda(), max_length=4)
+
+
+@pytest.mark.parametrize('cache_kv', (False, True))
+@pytest.mark.parametrize('prob_uncond', (0.0, 0.5, 1.0))
+def test_classifier_free_guidance(cache_kv, prob_uncond):                                # :452-492
+    model = Transfusion(num_text_tokens=16, dim_latent=8, prob_uncond=prob_uncond, modality_default_shape=(4,), transformer=dict(dim=DIM, depth=1)).cuda()
+    batch = [[randint(0, 16, (8,)), randn(4, 8), randint(0, 16, (4,))], [randint(0, 16, (6,)), randn(4, 8), randint(0, 16, (5,))]]
+    model.train()
+    model(cu(batch)).backward()
+    prompt = [randint(0, 16, (4,)).cuda()]
+    assert len(model.sample(prompt, max_length=8, cfg_scale=1.0, cache_kv=cache_kv)) > 0
+    assert len(model.sample(prompt, max_length=8, cfg_scale=3.0, cache_kv=cache_kv)) > 0
+
+
+def test_e2e_multimodal_cfg_sampling():                                                  # :494-525
+    model = Transfusion(num_text_tokens=16, dim_latent=8, prob_uncond=0.2, modality_default_shape=(4,), transformer=dict(dim=DIM, depth=1)).cuda()
+    batch = [[randint(0, 16, (8,)), randn(4, 8), randint(0, 16, (4,))], [randint(0, 16, (6,)), randn(4, 8), randint(0, 16, (5,))]]
+    model(cu(batch), num_modalities_to_times_fn=random_modality_length_to_time_fn).backward()
+    sample = model.sample([tensor([model.som_ids[0]]).cuda()], max_length=16, cfg_scale=2.5, cache_kv=True)
+    assert len(sample) >= 3
+
+
+def test_generate_text_only():                                                          # :559-576
+    model = Transfusion(num_text_tokens=256, transformer=dict(dim=DIM, depth=2, dim_head=8, heads=2)).cuda().eval()
+    prompt = torch.randint(0, 256, (1, 8)).cuda()
+    cached = model.generate_text_only(prompt, 24, temperature=0., cache_kv=True)
+    uncached = model.generate_text_only(prompt, 24, temperature=0., cache_kv=False)
+    assert cached.shape == (1, 16) and torch.equal(cached, uncached)
+
+
+def test_sample_cache_kv_equivalence():                                                 # :578-598
+    model = Transfusion(num_text_tokens=256, modality_default_shape=(4,), transformer=dict(dim=DIM, depth=2, dim_head=8, heads=2)).cuda().eval()
+    prompt = torch.randint(0, 256, (1, 8)).cuda()
+    torch.manual_seed(42)
+    a = model.sample(prompt=prompt, max_length=16, cache_kv=True, text_temperature=0.)
+    torch.manual_seed(42)
+    b = model.sample(prompt=prompt, max_length=16, cache_kv=False, text_temperature=0.)
+    assert torch.equal(a[0], b[0])
+
+
+def test_e2e_multiple_modalities_interleaved():                                          # :600-662
+    model = Transfusion(num_text_tokens=16, dim_latent=(16, 16), modality_default_shape=((4,), (3, 3)), transformer=dict(dim=DIM, depth=2, dim_head=8, heads=2)).cuda().eval()
+    mod0, mod1 = model.get_modality_info(0), model.get_modality_info(1)
+    prompt = [randint(0, 16, (3,)), tensor([model.meta_id]), model.char_tokenizer('4'), tensor([mod0.som_id]), (0, randn(4, 16)), tensor([mod0.eom_id]),
+              randint(0, 16, (2,)), tensor([model.meta_id]), model.char_tokenizer('3,3'), tensor([mod1.som_id]), (1, randn(3, 3, 16)), tensor([mod1.eom_id]), randint(0, 16, (2,))]
+    torch.manual_seed(42)
+    a = model.sample(prompt=cu(prompt), max_length=10, cache_kv=True, text_temperature=0., modality_steps=2)
+    torch.manual_seed(42)
+    b = model.sample(prompt=cu(prompt), max_length=10, cache_kv=False, text_temperature=0., modality_steps=2)
+    assert len(a) == len(b)
+    for pa, pb in zip(a, b):
+        if isinstance(pa, tuple):
+            assert pa[0] == pb[0] and torch.allclose(pa[1], pb[1], atol=1e-4)
+        else:
+            assert torch.equal(pa, pb)
+
+
+def make_sampling_model(num_modalities=1, channel_first=False):                           # :757-767 region
+    if num_modalities == 1:
+        return Transfusion(num_text_tokens=16, dim_latent=8, modality_default_shape=(4,), channel_first_latent=channel_first,
+                           transformer=dict(dim=DIM, depth=2, dim_head=8, heads=2)).cuda().eval()
+    return Transfusion(num_text_tokens=16, dim_latent=(8, 16), modality_default_shape=((4,), (3, 3)), transformer=dict(dim=DIM, depth=2, dim_head=8, heads=2)).cuda().eval()
+
+
+def assert_sample_equivalence(model, prompt_batch, **kwargs):                            # :757-783
+    kwargs.setdefault('text_temperature', 0.)
+    kwargs.setdefault('modality_steps', 4)
+    cache_kv = kwargs.pop('cache_kv', True)
+    one = [model.sample_one(p, cache_kv=cache_kv, **kwargs) for p in prompt_batch]
+    many = model.sample_many(prompt_batch, **kwargs)
+    assert len(one) == len(many)
+    for o, m in zip(one, many):
+        assert len(o) == len(m)
+        for po, pm in zip(o, m):
+            if isinstance(po, tuple):
+                assert po[0] == pm[0] and torch.allclose(po[1], pm[1], atol=1e-4)
+            else:
+                assert torch.equal(po, pm)
+
+
+@pytest.mark.parametrize('cfg_scale', (1., 3.))
+@pytest.mark.parametrize('channel_first', (False, True))
+def test_sample_many_equivalent_to_sample_one(cfg_scale, channel_first):                  # :785-808
+    model = make_sampling_model(channel_first=channel_first)
+    noise = torch.randn(32 if channel_first else 16, 8).cuda()
+    prime = tensor([model.som_ids[0]]).cuda()
+    t1, t2 = randint(0, 16, (3,)).cuda(), randint(0, 16, (2,)).cuda()
+    for prompt_batch in ([[prime], [prime]], [[t1], [t2]], [[t1], [t2], [prime]]):
+        assert_sample_equivalence(model, prompt_batch, init_modality_noise=noise, max_length=16, cfg_scale=cfg_scale)
+
+
+def test_sample_many_batched_multimodal():                                               # :810-833
+    model = make_sampling_model(num_modalities=2)
+    outs = model.sample_many([[tensor([model.som_ids[0]]).cuda()], [tensor([model.som_ids[1]]).cuda()], [tensor([model.som_ids[0]]).cuda()]],
+                             init_modality_noise=torch.randn(32, 16).cuda(), max_length=16, text_temperature=0., cfg_scale=3., modality_steps=4)
+    assert len(outs) == 3
+    for sample in outs:
+        assert isinstance(sample[1], tuple) and sample[1][1].shape in ((4, 8), (3, 3, 16))
+
+
+def test_sample_many_modality_prompt():                                                  # :835-847
+    model = make_sampling_model()
+    img = randn(4, 8).cuda()
+    outs = model.sample_many([(0, img), (0, img)], max_length=10, text_temperature=0., cfg_scale=1.)
+    assert len(outs) == 2
+    for sample in outs:
+        assert len(sample) == 3 and isinstance(sample[1], tuple) and torch.allclose(sample[1][1], img)
+
+
+def test_sample_many_encoder_decoder():                                                  # :849-876
+    model = Transfusion(num_text_tokens=16, dim_latent=8, channel_first_latent=True, modality_default_shape=(4, 4), modality_encoder=nn.Conv2d(3, 8, 3, padding=1),
+                        modality_decoder=nn.Conv2d(8, 3, 3, padding=1), transformer=dict(dim=DIM, depth=2, dim_head=8, heads=2)).cuda().eval()
+    img = randn(3, 8, 8).cuda()
+    outs = model.sample_many([(0, img), (0, img)], max_length=20, text_temperature=0., cfg_scale=1., modality_steps=4)
+    assert len(outs) == 2
+    for sample in outs:
+        assert isinstance(sample[1], tuple) and sample[1][1].shape == (3, 8, 8)
+
+
+def test_sample_many_empty_and_mixed_prompts():                                          # :878-888
+    model = make_sampling_model()
+    prime = tensor([model.som_ids[0]]).cuda()
+    assert len(model.sample_many([None, None], max_length=6, text_temperature=0., cfg_scale=1.)) == 2
+    outs = model.sample_many([[None], [prime]], max_length=12, text_temperature=0., cfg_scale=1., modality_steps=4)
+    assert len(outs) == 2 and isinstance(outs[1][1], tuple)
+
+
+def test_sample_many_stochastic_text_distribution():                                     # :890-905
+    model = make_sampling_model()
+    prime, noise = tensor([model.som_ids[0]]).cuda(), torch.randn(16, 8).cuda()
+    torch.manual_seed(0)
+    o1 = model.sample_many([[prime]], init_modality_noise=noise, max_length=20, text_temperature=1.0, cfg_scale=1., modality_steps=4)
+    torch.manual_seed(1)
+    o2 = model.sample_many([[prime]], init_modality_noise=noise, max_length=20, text_temperature=1.0, cfg_scale=1., modality_steps=4)
+    assert not torch.equal(o1[0][-1], o2[0][-1])
+
+
+def make_video_action_model():                                                          # :911-923
+    return Transfusion(num_text_tokens=16, dim_latent=(16, 8), modality_default_shape=((4, 4, 4), (16,)), channel_first_latent=(True, False),
+                       transformer=dict(dim=DIM, depth=2, dim_head=8, heads=2)).cuda().eval()
+
+
+def test_sample_force_modality_at_start():                                               # :925-959
+    model = make_video_action_model()
+    text, video = randint(0, 16, (3,)).cuda(), randn(16, 4, 4, 4).cuda()
+    kw = dict(force_modality_at_start=(1, (32,)), max_length=64, text_temperature=0., cfg_scale=1., modality_steps=4)
+    sample = model.sample_one([text, (0, video)], **kw)
+    assert isinstance(sample[1], tuple) and sample[1][0] == 0 and torch.allclose(sample[1][1], video)
+    assert isinstance(sample[3], tuple) and sample[3][0] == 1 and sample[3][1].shape == (32, 8)
+    (many,) = model.sample_many([[text, (0, video)]], **kw)
+    assert isinstance(many[3], tuple) and many[3][0] == 1 and many[3][1].shape == (32, 8)
+
+
+def test_sample_force_modality_at_start_without_shape():                                  # :961-985
+    model = make_sampling_model(num_modalities=2)
+    outs = model.sample_many([[tensor([model.som_ids[0]]).cuda()]], force_modality_at_start=1, init_modality_noise=torch.randn(16, 16).cuda(), max_length=32,
+                             text_temperature=0., cfg_scale=1., modality_steps=4)
+    assert len(outs) == 1 and isinstance(outs[0][1], tuple) and outs[0][1][0] == 1 and outs[0][1][1].shape == (3, 3, 16)
+
+
+def test_sample_force_modality_at_start_heterogeneous_prompts():                           # :987-1018
+    model = make_video_action_model()
+    t1, t2 = randint(0, 16, (2,)).cuda(), randint(0, 16, (5,)).cuda()
+    v1, v2, v3 = randn(16, 4, 4, 4).cuda(), randn(16, 2, 4, 4).cuda(), randn(16, 6, 4, 4).cuda()
+    outs = model.sample_many([[t1, (0, v1)], [t2, (0, v2)], [(0, v3)]], force_modality_at_start=(1, (32,)), max_length=128, text_temperature=0., cfg_scale=1., modality_steps=4)
+    assert len(outs) == 3
+    for sample in outs:
+        assert isinstance(sample[-2], tuple) and sample[-2][0] == 1 and sample[-2][1].shape == (32, 8)
+
+
+def test_sample_force_modality_at_start_equivalent_sample_one_many():                      # :1020-1037
+    model = make_video_action_model()
+    text, video, noise = randint(0, 16, (3,)).cuda(), randn(16, 4, 4, 4).cuda(), torch.randn(32, 8).cuda()
+    assert_sample_equivalence(model, [[text, (0, video)], [text, (0, video)]], force_modality_at_start=(1, (32,)), init_modality_noise=noise, max_length=64, cfg_scale=1.)

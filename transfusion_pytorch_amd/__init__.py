@@ -7,6 +7,12 @@ from .transfusion import (
     LossBreakdown,
     print_modality_sample,
     create_dataloader,
+    exists,
+    apply_fn_modality_type,
+    stack_same_shape_tensors_with_inverse,
+    filter_with_inverse,
+    random_modality_length_to_time_fn,
+    default_modality_length_to_time_fn,
 )
 
 from .ema import EMA

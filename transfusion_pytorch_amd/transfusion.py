@@ -33,6 +33,74 @@ class LossBreakdown(NamedTuple):            # T:105-110
 from .modality_processing import PROCESSING_STRATEGIES, ProcessedModalityBatch, process_modalities      # noqa: E402  the registry seam (MP:1050-1058)
 
 
+def exists(v):                                            # T:130-131
+    return v is not None
+
+
+def random_modality_length_to_time_fn(num_modalities):    # T:181-184: an independent uniform time per modality slot
+    return torch.rand((num_modalities.shape[0], int(num_modalities.amax()) if num_modalities.numel() else 0), device=num_modalities.device)
+
+
+def default_modality_length_to_time_fn(num_modalities):   # T:186-200 (the model's default draws the same numbers: Transfusion._default_times)
+    b, dev = num_modalities.shape[0], num_modalities.device
+    m = int(num_modalities.amax()) if num_modalities.numel() else 0
+    if m == 0:
+        return torch.empty((b, 0), device=dev, dtype=torch.float)
+    decoded = torch.floor(torch.rand(b, device=dev) * num_modalities.float())
+    cur = torch.rand(b, device=dev)
+    return torch.where(torch.arange(m, device=dev)[None, :] < decoded[:, None], torch.full((), 0.5, device=dev), cur[:, None].expand(b, m))
+
+
+def char_tokenize(text: str, offset: int = 0):            # T:242-249: one token per character of a shape string
+    return torch.tensor([ord(c) + offset for c in text], dtype=torch.long)
+
+
+def stack_same_shape_tensors_with_inverse(tensors):       # T:476-519
+    """group tensors by shape, stack each group; `inverse(dict shape -> batched result)` puts the rows back in the original order"""
+    slots, groups = [], {}
+    for x in tensors:
+        key = tuple(x.shape)
+        slots.append((key, len(groups.setdefault(key, []))))
+        groups[key].append(x)
+    counts = {k: len(v) for k, v in groups.items()}
+
+    def inverse(batched):
+        assert {k: len(v) for k, v in batched.items()} == counts
+        return [batched[k][i] for k, i in slots]
+    return {k: torch.stack(v) for k, v in groups.items()}, inverse
+
+
+def filter_with_inverse(cond, inp):                       # T:521-548
+    """elements of `inp` satisfying `cond`; `inverse(new elements)` returns `inp` with those positions replaced"""
+    picked = [i for i, el in enumerate(inp) if cond(el)]
+
+    def inverse(new):
+        assert len(new) == len(picked)
+        out = list(inp)
+        for i, el in zip(picked, new):
+            out[i] = el
+        return out
+    return [inp[i] for i in picked], inverse
+
+
+def apply_fn_modality_type(fn, modalities, modality_type=0, return_untransformed=False):      # T:550-589
+    """run `fn` on every modality tensor of one type inside a sample or a list of samples, same-shaped tensors stacked into one call; bare
+    float tensors count as type 0.  Structure (lists) is preserved; transformed parts come back as (type, tensor[, original])."""
+    single = not (len(modalities) > 0 and isinstance(modalities[0], list))
+    batch = [modalities] if single else modalities
+    flat = [(0, p) if (torch.is_tensor(p) and p.is_floating_point()) else p for sample in batch for p in sample]
+    chosen, put_back = filter_with_inverse(lambda el: isinstance(el, tuple) and el[0] == modality_type, flat)
+    tensors = [x for _, x in chosen]
+    stacked, unstack = stack_same_shape_tensors_with_inverse(tensors)
+    res = unstack({k: fn(v) for k, v in stacked.items()}) if tensors else []
+    new = [(modality_type, r, x) if return_untransformed else (modality_type, r) for r, x in zip(res, tensors)]
+    flat = put_back(new)
+    out, i = [], 0
+    for sample in batch:
+        out.append(flat[i:i + len(sample)]); i += len(sample)
+    return out[0] if single else out
+
+
 def default_to_modality_shape_fn(maybe_shape_str):       # T:176-177
     return tuple([*map(int, maybe_shape_str.split(','))])
 
@@ -42,6 +110,23 @@ def cast_tuple(t, length=1):
 
 
 _TRAIN_PAD = max(1, int(os.environ.get('TFX_TRAIN_PAD', '64')))
+
+
+class ModalityInfo(NamedTuple):              # T:112-126
+    encoder: object
+    decoder: object
+    latent_to_model: object
+    model_to_latent: object
+    add_pos_emb: bool
+    pos_emb_mlp: object
+    num_dim: object
+    dim_latent: int
+    default_shape: object
+    som_id: int
+    eom_id: int
+    to_shape_fn: object
+    channel_first_latent: bool
+    modality_type: int
 
 
 class KVCacheView(torch.Tensor):
@@ -271,6 +356,39 @@ class Transfusion(nn.Module):
     # ------------------------------------------------------------------ encoders / decoders / channel-first layout
     def parameters_without_encoder_decoder(self):                     # T:1650-1655
         return set(self.parameters()) - set(self.modality_encoder.parameters()) - set(self.modality_decoder.parameters())
+
+    def get_modality_info(self, modality_type=None):                  # T:1547-1590
+        """per-type record with the reference's field names.  `latent_to_model` / `model_to_latent` are the user's modules for
+        `pre_post_transformer_enc_dec` types and None otherwise (the native projections live in the flat parameter buffer: `model_to_latent()`)"""
+        t = 0 if modality_type is None else int(modality_type)
+        ext = t in self._ext
+        return ModalityInfo(encoder=self.modality_encoder[t], decoder=self.modality_decoder[t],
+                            latent_to_model=self.latent_to_model_projs[t] if ext else None, model_to_latent=self.model_to_latent_projs[t] if ext else None,
+                            add_pos_emb=bool(self.add_pos_emb[t]), pos_emb_mlp=self.pos_emb_mlp[t], num_dim=self.modality_num_dim[t], dim_latent=self.dim_latents[t],
+                            default_shape=self.modality_default_shape[t], som_id=self.som_ids[t], eom_id=self.eom_ids[t], to_shape_fn=self.to_modality_shape_fn[t],
+                            channel_first_latent=bool(self.channel_first_latent[t]), modality_type=t)
+
+    def get_all_modality_info(self):                                   # T:1591-1592
+        return [self.get_modality_info(i) for i in range(self.num_modalities)]
+
+    def char_tokenizer(self, text: str):                               # T:1446: characters of a shape string -> token ids behind [meta]
+        return char_tokenize(text, offset=self.meta_id + 1)
+
+    def __deepcopy__(self, memo):
+        """`copy.deepcopy(model)` (the reference's tests build their EMA teachers that way): a fresh model of the same architecture with the
+        parameters copied - plans, launch lists and device index caches hold raw pointers and are rebuilt by the copy on first use"""
+        import copy
+        kw = dict(self._init_kwargs)
+        kw['transformer'] = self.transformer_config
+        for k in ('pre_post_transformer_enc_dec', 'modality_encoder', 'modality_decoder'):
+            kw[k] = copy.deepcopy(kw.get(k), memo)
+        new = Transfusion(**kw)
+        if self.device.type == 'cuda':
+            new = new.to(self.device)
+        new.load_state_dict(self.state_dict())
+        new.train(self.training)
+        memo[id(self)] = new
+        return new
 
     def external_parameters(self):
         """learnable parameters outside the flat native buffer: the axial positional-embedding MLPs and the user's pre / post transformer
@@ -556,6 +674,7 @@ class Transfusion(nn.Module):
             return self.forward_modality(modalities, times=times, modality_type=modality_type, return_loss=return_loss,             # T:2989-2990
                                          velocity_consistency_ema_model=velocity_consistency_ema_model, return_loss_breakdown=return_breakdown)
         is_decoding = decoding_text_or_modality is not None
+        velocity_modalities = modalities                                                   # the EMA teacher gets the caller's raw samples (T:3004-3008): it encodes them itself
         if isinstance(modalities, list) and (any(self.channel_first_latent) or any(e is not None for e in self.modality_encoder)):
             modalities = [list(sample) for sample in modalities]                           # T:3010-3012: never mutate the caller's lists
             if not is_decoding:
@@ -721,7 +840,7 @@ class Transfusion(nn.Module):
             ema._flat_pred_flows = True
             try:
                 with torch.no_grad():
-                    teacher = ema(modalities, times=orig_times + velocity_consistency_delta_time, return_only_pred_flows=True)
+                    teacher = ema(velocity_modalities, times=orig_times + velocity_consistency_delta_time, return_only_pred_flows=True)
             finally:
                 ema._flat_pred_flows = False
                 ema.train(was_training)
