@@ -220,3 +220,31 @@ def test_reconstruction_loss_matches_reference_golden():
     l4, (f4, v4, r4) = m4.forward_modality(xm4.cuda(), times=tm4, return_loss_breakdown=True)
     print('[recon] forward_modality through the frozen decoder')
     close(l4, g['dec_loss'], 'loss'); close(f4, g['dec_flow'], 'flow'); close(r4, g['dec_recon'], 'recon')
+
+
+def test_processing_registry_with_positional_embedding_and_unet_types():
+    """`PROCESSING_STRATEGIES[name](..., need_axial_pos_emb=True)` (MP:1050-1058 with MP:1003-1045 evaluated): the embedding rows of every instance
+    sit at its slots, zeros elsewhere; for a `pre_post_transformer_enc_dec` type the tokens are the user's encoder output at the PROJECTED positions
+    (the reference's `test_unet_encoder_positions_use_projected_lengths`, tests/test_modality_processing.py:482-493)."""
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.modality_processing import PROCESSING_STRATEGIES
+    cfg, sd, batch, times, noises, xm, nm, tm, g0 = unet_case()
+    g = torch.load(os.path.join(GOLDEN, 'f4b_unet.pt'), weights_only=False)
+    enc, dec = unet_modules(cfg.dim)
+    model = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=4, modality_default_shape=(8, 8), channel_first_latent=True,
+                        pre_post_transformer_enc_dec=(enc, dec), add_pos_emb=True, modality_num_dim=2, prob_uncond=0.,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    model.load_state_dict({**sd, **g['ext_sd']}, strict=True)
+    model = model.cuda()
+    model._noise_override = {0: [n.cuda() for n in noises]}
+    with torch.no_grad():
+        out = PROCESSING_STRATEGIES['auto'](to_cuda(batch), times, model, need_axial_pos_emb=True, return_loss=True, return_embed=False)
+    # 8 x 8 and 4 x 8 images through a stride-2 conv: 16- and 8-token instances, spelled "4,4" / "2,4" in the meta string
+    assert [[(t, L) for t, _, L in s] for s in out.modality_positions] == [[(0, 16)], [(0, 8), (0, 16)]]
+    assert out.modality_pos_emb.shape == out.modality_tokens.shape
+    (t0, off, L), = out.modality_positions[0]
+    want = model.pos_emb_mlp[0]((4, 4), flatten=True)
+    assert torch.allclose(out.modality_pos_emb[0, off:off + L], want, atol=1e-6) and float(out.modality_pos_emb[0, :off].abs().max()) == 0.
+    tok = model.latent_to_model_projs[0]((batch[0][1][1].cuda() * times[0, 0] + noises[0].cuda() * (1 - times[0, 0]))[None])[0].reshape(16, cfg.dim)
+    assert rel(out.modality_tokens[0, off:off + L], tok) <= 8e-3                       # bf16 token buffer
+    assert [tuple(f.shape) for f in out.flows[0]] == [(4, 8, 8), (4, 4, 8), (4, 8, 8)]
