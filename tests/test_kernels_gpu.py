@@ -117,10 +117,10 @@ def geglu_perm(dip):
     return is_gate, feat
 
 
-@pytest.mark.parametrize('M', [300, 70000])            # 70000 rows: the ping-pong 256x256 kernel and its staged epilogues
+@pytest.mark.parametrize('M', [300, 130, 70000])       # 70000 rows: the ping-pong 256x256 kernel and its staged epilogues; 130: the split-K decode kernel (K >= 256)
 def test_gemm_nt_geglu_fwd_bwd(M):
     torch.manual_seed(3)
-    d, dip = 128, 192 if M < 1000 else 1024
+    d, dip = (512 if M == 130 else 128), 192 if M < 1000 else 1024
     u = rnd(M, d)
     Wa, Wg = rnd(dip, d, scale=d ** -0.5), rnd(dip, d, scale=d ** -0.5)
     ba, bg = torch.randn(dip, device=DEV), torch.randn(dip, device=DEV)
@@ -137,7 +137,7 @@ def test_gemm_nt_geglu_fwd_bwd(M):
     check('geglu pre-activation (interleaved)', ag, ag_ref, 6e-3)
     check('geglu hidden', hm, a * F.gelu(g), 8e-3)
     # backward epilogue: dh = dy @ W2t^T (here: plain GEMM against random B), d[a|g] from saved ag
-    K2 = 128
+    K2 = 320 if M == 130 else 128
     dy, W2t = rnd(M, K2), rnd(dip, K2, scale=K2 ** -0.5)
     dag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF)
     gemm_nt(A=dy, lda=K2, B=W2t, ldb=K2, M=M, N=dip, K=K2, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip,
