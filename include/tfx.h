@@ -158,9 +158,16 @@ typedef struct {
   tfx_bf16* dqkv; int32_t ld_dqkv;            /* grad wrt pre-norm q,k (written) */
   float* dgamma_q; float* dgamma_k;           /* atomic accumulate */
   float norm_scale;                           /* sqrt(dim_head), the RMSNorm scale T:779-786; 0 = 8 (dim_head 64) */
+  /* forward, decode steps (optional): KV-cache append fused in (T:1005-1016) - token t's k~ (H*64 columns) and v (the H*64 columns behind k in
+   * `qkv`) are also written to cache row cache_pos[t] ([k~ | v], ld_cache elements per row; cache_pos < 0 = skip).  A decode step is launch-bound
+   * (~4.5 us per kernel whatever its size): this removes two launches per layer */
+  tfx_bf16* cache; int32_t ld_cache; const int32_t* cache_pos;
 } tfx_qk_norm_rope_args;
 int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* stream);
 int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* stream);
+/* decode steps: AdaLN output side of one wrapper + AdaLN input side of the next in ONE launch (out = x + y * scale is written, then normalised and
+ * modulated into `pre->u` exactly as tfx_adaln_pre_fwd would read it back: same bf16 rounding of `out`).  post->T/d/tok_inst must equal pre's. */
+int tfx_adaln_post_pre_fwd(const tfx_adaln_post_args* post, const tfx_adaln_pre_args* pre, void* stream);
 
 typedef struct {
   int32_t T, d, L;                            /* L = number of hiddens h_0..h_{L-1} */
@@ -175,6 +182,10 @@ typedef struct {
 } tfx_attnres_args;
 int tfx_attnres_fwd(const tfx_attnres_args* a, void* stream);
 int tfx_attnres_bwd(const tfx_attnres_args* a, void* stream);
+/* decode steps: the END of a layer in one launch - feed-forward AdaLN output side (writes hidden L - 1 = post->out), the layer's AttentionResidual
+ * over hiddens 0 .. L - 1 (writes ar->out), and - when `pre` is non-NULL - the input side of the NEXT layer's attention wrapper on that output.
+ * Same roundings as the three separate launches (every written row is re-read as bf16).  post->out must be hidden L - 1 of `ar`, pre->x == ar->out. */
+int tfx_layer_end_fwd(const tfx_adaln_post_args* post, const tfx_attnres_args* ar, const tfx_adaln_pre_args* pre, void* stream);
 
 typedef struct {
   int32_t T, d;
@@ -325,7 +336,7 @@ enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_
        TFX_OP_ADAM_STEP = 22, TFX_OP_DECODE_ATTN = 23,
        /* positional entry points (args = tfx_raw_args) */
        TFX_OP_OUTPUT_TO_FLOW = 32, TFX_OP_GATHER_F32 = 33, TFX_OP_ONEHOT_BF16 = 34, TFX_OP_SCATTER_ROWS_BF16 = 35, TFX_OP_F32_TO_BF16 = 36,
-       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41, TFX_OP_CAST_BLOCK_BF16 = 42, TFX_OP_SCALE_BF16_COPY = 43,
+       TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41, TFX_OP_CAST_BLOCK_BF16 = 42, TFX_OP_SCALE_BF16_COPY = 43, TFX_OP_ADALN_POST_PRE_FWD = 44, TFX_OP_LAYER_END_FWD = 45,
        /* stream control (args = any non-NULL pointer; `stream` = event slot 0..63):
           FORK: the library's side stream waits for everything enqueued so far on the caller's stream;
           JOIN_RECORD: mark "everything enqueued so far on the side stream";  JOIN_WAIT: the caller's stream waits for that mark;

@@ -653,3 +653,62 @@ def test_allreduce_entry_points_world1():
     finally:
         capi.check(lib.tfx_allreduce_destroy(), 'destroy')
     assert lib.tfx_allreduce_run(g.data_ptr(), 16, ctypes.c_void_p(stream())) != 0        # no communicator: refused
+
+
+@pytest.mark.parametrize('T,d,L', [(300, 512, 3), (130, 1024, 9)])
+def test_decode_fused_launches_equal_the_separate_kernels(T, d, L):
+    """decode plans fuse launches (a decode step is launch-bound): `tfx_adaln_post_pre_fwd` = adaln_post + adaln_pre, `tfx_layer_end_fwd` =
+    adaln_post + AttentionResidual + adaln_pre, `tfx_qk_norm_rope_fwd` with `cache` = norm / rope + the two KV-cache scatters.  Every stored row is
+    rounded to bf16 before it is used again, so the fused results must equal the separate kernels' BIT FOR BIT."""
+    import ctypes
+    torch.manual_seed(0)
+    I = 7
+    inst = torch.randint(-1, I, (T,), device=DEV, dtype=torch.int32)
+    table = torch.randn(I, 6 * d, device=DEV) * 0.5
+    ls, gt = torch.randn(d, device=DEV) * 0.1, torch.randn(d, device=DEV) * 0.1
+    x, y = rnd(T, d), rnd(T, d)
+    mk = lambda: (torch.zeros(T, d, device=DEV, dtype=BF), torch.zeros(T, d, device=DEV, dtype=BF), torch.zeros(T, device=DEV), torch.zeros(T, device=DEV))
+    # ---- post + pre
+    out_a, u_a, mean_a, rstd_a = mk(); out_b, u_b, mean_b, rstd_b = mk()
+    post = lambda out: capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x, y=y, out=out, tok_inst=inst, table=table, ld_table=6 * d, layerscale=ls)
+    pre = lambda xin, u, mean, rstd: capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=xin, u=u, tok_inst=inst, table=table.data_ptr() + 4 * 3 * d, ld_table=6 * d,
+                                                    gamma_text=gt, mean=mean, rstd=rstd)
+    capi.call('tfx_adaln_post_fwd', post(out_a), stream()); capi.call('tfx_adaln_pre_fwd', pre(out_a, u_a, mean_a, rstd_a), stream())
+    pa, pb = post(out_b), pre(out_b, u_b, mean_b, rstd_b)
+    assert capi.lib().tfx_adaln_post_pre_fwd(ctypes.byref(pa), ctypes.byref(pb), ctypes.c_void_p(stream())) == 0
+    assert torch.equal(out_a, out_b) and torch.equal(u_a, u_b) and torch.equal(mean_a, mean_b) and torch.equal(rstd_a, rstd_b)
+    # ---- layer end: post -> hidden L-1, AttentionResidual over L hiddens, pre of the next layer
+    Ha, Hb = rnd(L, T, d, scale=2.0), None
+    Hb = Ha.clone()
+    gam, pq = torch.randn(d, device=DEV) * 0.3, torch.randn(d, device=DEV) * 0.5
+    res_a, u_a, mean_a, rstd_a = mk(); res_b, u_b, mean_b, rstd_b = mk()
+    post2 = lambda H: capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x, y=y, out=H[L - 1], tok_inst=inst, table=table, ld_table=6 * d, layerscale=ls)
+    ar = lambda H, out: capi.make_args('tfx_attnres_args', T=T, d=d, L=L, hiddens=H, stride_h=T * d, gamma=gam, pq=pq, out=out)
+    capi.call('tfx_adaln_post_fwd', post2(Ha), stream()); capi.call('tfx_attnres_fwd', ar(Ha, res_a), stream())
+    capi.call('tfx_adaln_pre_fwd', pre(res_a, u_a, mean_a, rstd_a), stream())
+    a1, a2, a3 = post2(Hb), ar(Hb, res_b), pre(res_b, u_b, mean_b, rstd_b)
+    assert capi.lib().tfx_layer_end_fwd(ctypes.byref(a1), ctypes.byref(a2), ctypes.byref(a3), ctypes.c_void_p(stream())) == 0
+    assert torch.equal(Ha, Hb) and torch.equal(res_a, res_b) and torch.equal(u_a, u_b) and torch.equal(mean_a, mean_b)
+    res_c = torch.zeros_like(res_b); Hc = Ha.clone()
+    a1, a2 = post2(Hc), ar(Hc, res_c)
+    assert capi.lib().tfx_layer_end_fwd(ctypes.byref(a1), ctypes.byref(a2), None, ctypes.c_void_p(stream())) == 0 and torch.equal(res_c, res_a)
+    bad = ar(Hc, res_c); bad.L = L - 1                         # post->out is not the last hidden of the mix: refused
+    assert capi.lib().tfx_layer_end_fwd(ctypes.byref(a1), ctypes.byref(bad), None, ctypes.c_void_p(stream())) == -3
+    # ---- qk norm + rope with the KV-cache append
+    H = 4; HD = H * 64; ld = 3 * HD + 8
+    qkv = rnd(T, ld, scale=1.5)
+    gq, gk = torch.randn(64, device=DEV) * 0.3, torch.randn(64, device=DEV) * 0.3
+    pos = torch.randint(0, 900, (T,), device=DEV, dtype=torch.int32)
+    freqs = 1. / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(1024).float()[:, None] * freqs[None]
+    cos_t, sin_t = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    cpos = torch.randperm(2 * T, device=DEV)[:T].to(torch.int32); cpos[::11] = -1
+    qk_a, qk_b = torch.zeros(T, 2 * HD, device=DEV, dtype=BF), torch.zeros(T, 2 * HD, device=DEV, dtype=BF)
+    cache_a, cache_b = torch.zeros(2 * T, 2 * HD, device=DEV, dtype=BF), torch.zeros(2 * T, 2 * HD, device=DEV, dtype=BF)
+    base = dict(T=T, H=H, qkv=qkv, ld_qkv=ld, ld_qk=2 * HD, gamma_q=gq, gamma_k=gk, rot_pos=pos, cos_tab=cos_t, sin_tab=sin_t, q_scale=0.125)
+    capi.call('tfx_qk_norm_rope_fwd', capi.make_args('tfx_qk_norm_rope_args', qk=qk_a, **base), stream())
+    sp = ctypes.c_void_p(stream())
+    capi.check(capi.lib().tfx_scatter_rows_bf16(qk_a.data_ptr() + 2 * HD, 2 * HD, HD, cache_a.data_ptr(), 2 * HD, cpos.data_ptr(), T, sp), 'scatter k')
+    capi.check(capi.lib().tfx_scatter_rows_bf16(qkv.data_ptr() + 2 * 2 * HD, ld, HD, cache_a.data_ptr() + 2 * HD, 2 * HD, cpos.data_ptr(), T, sp), 'scatter v')
+    capi.call('tfx_qk_norm_rope_fwd', capi.make_args('tfx_qk_norm_rope_args', qk=qk_b, cache=cache_b, ld_cache=2 * HD, cache_pos=cpos, **base), stream())
+    assert torch.equal(qk_a, qk_b) and torch.equal(cache_a, cache_b)

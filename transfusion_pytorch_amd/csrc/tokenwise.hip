@@ -210,6 +210,52 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_post_fwd_k(tfx_ad
   store_row(x, p.out + (size_t)t * d, d, lane);
 }
 
+// decode steps: output side of one wrapper + input side of the next, one token per wave (see include/tfx.h tfx_adaln_post_pre_fwd)
+template <int NC> __global__ __launch_bounds__(256) void adaln_post_pre_fwd_k(tfx_adaln_post_args p, tfx_adaln_pre_args q) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T) return;
+  const int d = p.d;
+  Row<NC> x, y, s, g, b;
+  load_row(x, p.x + (size_t)t * d, d, lane);
+  load_row(y, p.y + (size_t)t * d, d, lane);
+  const int inst = p.tok_inst[t];
+  if (inst < 0) { load_vec(s, p.layerscale, d, lane); load_vec(g, q.gamma_text, d, lane); }
+  else {
+    load_vec(s, p.table + (size_t)inst * p.ld_table + 2 * d, d, lane);
+    load_vec(g, q.table + (size_t)inst * q.ld_table, d, lane); load_vec(b, q.table + (size_t)inst * q.ld_table + d, d, lane);
+  }
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float sc = inst < 0 ? 1.f + s.v[i][e] : sigmoidf_(s.v[i][e]);
+      x.v[i][e] = bf2f(f2bf(x.v[i][e] + y.v[i][e] * sc));            // what tfx_adaln_pre_fwd would read back
+      sm += x.v[i][e];
+    }
+  store_row(x, p.out + (size_t)t * d, d, lane);
+  const float mean = wave_sum(sm) / d;
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < d)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { float dv = x.v[i][e] - mean; qq += dv * dv; }
+  }
+  const float rstd = rsqrtf(wave_sum(qq) / d + 1e-5f);
+  if (lane == 0) { q.mean[t] = mean; q.rstd[t] = rstd; }
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float xh = (x.v[i][e] - mean) * rstd;
+      x.v[i][e] = xh * (1.f + g.v[i][e]) + (inst < 0 ? 0.f : b.v[i][e]);
+    }
+  store_row(x, q.u + (size_t)t * d, d, lane);
+}
+
 template <int NC> __global__ __launch_bounds__(256) void adaln_post_bwd_k(tfx_adaln_post_args p) {
   __shared__ float smem[WAVES * NC * 512];
   const int lane = threadIdx.x & 63;
@@ -511,6 +557,89 @@ template <int NC> __global__ __launch_bounds__(256) void attnres_fwd_k(tfx_attnr
   store_row(o, p.out + (size_t)t * d, d, lane);
 }
 
+// decode steps: end of a layer in one launch (include/tfx.h tfx_layer_end_fwd): h = x + y * scale ; out = AttentionResidual(h_0 .. h_{L-2}, h) ;
+// u = AdaLN-pre(out) for the next layer.  One token per wave; every stored row is rounded to bf16 before it is used again, as a re-read would.
+template <int NC> __global__ __launch_bounds__(256) void layer_end_fwd_k(tfx_adaln_post_args p, tfx_attnres_args a, tfx_adaln_pre_args q, int has_pre) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  if (t >= p.T) return;
+  const int d = p.d;
+  const int inst = p.tok_inst[t];
+  Row<NC> hn, w, o;
+  {
+    Row<NC> y, s;
+    load_row(hn, p.x + (size_t)t * d, d, lane);
+    load_row(y, p.y + (size_t)t * d, d, lane);
+    if (inst < 0) load_vec(s, p.layerscale, d, lane);
+    else load_vec(s, p.table + (size_t)inst * p.ld_table + 2 * d, d, lane);
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float sc = inst < 0 ? 1.f + s.v[i][e] : sigmoidf_(s.v[i][e]);
+        hn.v[i][e] = bf2f(f2bf(hn.v[i][e] + y.v[i][e] * sc));
+      }
+    store_row(hn, p.out + (size_t)t * d, d, lane);
+  }
+  {
+    Row<NC> pq; load_vec(w, a.gamma, d, lane); load_vec(pq, a.pq, d, lane);
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { w.v[i][e] = (1.f + w.v[i][e]) * pq.v[i][e]; o.v[i][e] = 0.f; }
+  }
+  float m = -INFINITY, den = 0.f;
+  for (int l = 0; l < a.L; l++) {
+    Row<NC> h;
+    if (l + 1 < a.L) load_row(h, a.hiddens + (size_t)l * a.stride_h + (size_t)t * d, d, lane);
+    else h = hn;
+    float nsq = 0.f, dt = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { nsq += h.v[i][e] * h.v[i][e]; dt += h.v[i][e] * w.v[i][e]; }
+    nsq = wave_sum(nsq); dt = wave_sum(dt);
+    const float s = dt / fmaxf(sqrtf(nsq), 1e-12f);
+    const float mn = fmaxf(m, s);
+    const float al = __expf(m - mn), ex = __expf(s - mn);
+    den = den * al + ex; m = mn;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) o.v[i][e] = o.v[i][e] * al + ex * h.v[i][e];
+  }
+  const float inv = 1.f / den;
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { o.v[i][e] = bf2f(f2bf(o.v[i][e] * inv)); sm += o.v[i][e]; }
+  store_row(o, a.out + (size_t)t * d, d, lane);
+  if (!has_pre) return;
+  Row<NC> g, b;
+  if (inst < 0) load_vec(g, q.gamma_text, d, lane);
+  else { load_vec(g, q.table + (size_t)inst * q.ld_table, d, lane); load_vec(b, q.table + (size_t)inst * q.ld_table + d, d, lane); }
+  const float mean = wave_sum(sm) / d;
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    int c = lane + 64 * i;
+    if (c * 8 < d)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { float dv = o.v[i][e] - mean; qq += dv * dv; }
+  }
+  const float rstd = rsqrtf(wave_sum(qq) / d + 1e-5f);
+  if (lane == 0) { q.mean[t] = mean; q.rstd[t] = rstd; }
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float xh = (o.v[i][e] - mean) * rstd;
+      o.v[i][e] = xh * (1.f + g.v[i][e]) + (inst < 0 ? 0.f : b.v[i][e]);
+    }
+  store_row(o, q.u + (size_t)t * d, d, lane);
+}
+
 template <int NC> __global__ __launch_bounds__(256) void attnres_bwd_k(tfx_attnres_args p) {
   __shared__ float smem[WAVES * NC * 512];
   const int lane = threadIdx.x & 63;
@@ -643,12 +772,17 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args 
   const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned vid = gid >> 3;
   const int sub = gid & 7;
-  const unsigned twoH = 2u * p.H, nvec = (unsigned)p.T * twoH;
+  const unsigned twoH = (p.cache ? 3u : 2u) * p.H, nvec = (unsigned)p.T * twoH;      // with a cache the v vectors ride along (copied, not normalised)
   if (vid >= nvec) return;
   const int t = (int)(vid / twoH), rem = (int)(vid - (unsigned)t * twoH);
   const int which = rem >= p.H;
   const int col = rem * 64 + sub * 8;          // which*H*64 + h*64 + sub*8
   bf16x8 x = *(const bf16x8*)(p.qkv + (size_t)t * p.ld_qkv + col);
+  if (rem >= 2 * p.H) {                        // v: cache append only
+    const int cp = p.cache_pos[t];
+    if (cp >= 0) *(bf16x8*)(p.cache + (size_t)cp * p.ld_cache + (col - p.H * 64)) = x;
+    return;
+  }
   float v[8], q = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
@@ -666,6 +800,10 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args 
     o[2 * i + 1] = f2bf(b * cs[i] + a * sn[i]);
   }
   *(bf16x8*)(p.qk + (size_t)t * p.ld_qk + col) = o;
+  if (p.cache && which) {
+    const int cp = p.cache_pos[t];
+    if (cp >= 0) *(bf16x8*)(p.cache + (size_t)cp * p.ld_cache + (col - p.H * 64)) = o;
+  }
 }
 
 __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args p) {
@@ -1127,6 +1265,17 @@ int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) {
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }
+int tfx_adaln_post_pre_fwd(const tfx_adaln_post_args* a, const tfx_adaln_pre_args* b, void* s) {
+  if (a->T != b->T || a->d != b->d || a->tok_inst != b->tok_inst || (const void*)a->out != (const void*)b->x) return -2;
+  DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a, *b)); RET();
+}
+int tfx_layer_end_fwd(const tfx_adaln_post_args* a, const tfx_attnres_args* r, const tfx_adaln_pre_args* b, void* s) {
+  if (a->T != r->T || a->d != r->d || r->L < 1 || r->L > 64) return -2;
+  if ((const void*)a->out != (const void*)(r->hiddens + (size_t)(r->L - 1) * r->stride_h)) return -3;
+  if (b && (b->T != a->T || b->d != a->d || b->tok_inst != a->tok_inst || (const void*)b->x != (const void*)r->out)) return -4;
+  tfx_adaln_pre_args none = {};
+  DISPATCH_NC(a->d, hipLaunchKernelGGL(layer_end_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a, *r, b ? *b : none, b ? 1 : 0)); RET();
+}
 int tfx_rmsnorm_fwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_rmsnorm_bwd(const tfx_rmsnorm_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(rmsnorm_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_attnres_fwd(const tfx_attnres_args* a, void* s) { if (a->L > 64) return -2; DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
@@ -1138,7 +1287,7 @@ int tfx_embed_fwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunc
 int tfx_embed_bwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_bwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 
 int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* s) {
-  long long nthreads = (long long)a->T * 2 * a->H * 8;
+  long long nthreads = (long long)a->T * (a->cache ? 3 : 2) * a->H * 8;
   if (nthreads >= (1ll << 31)) return -3;
   hipLaunchKernelGGL(qk_norm_rope_fwd_k, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ST(s), *a); RET();
 }

@@ -290,6 +290,7 @@ class Plan:
             self._nt(L, A=self.cond, lda=4 * d, B=S['ada'], ldb=4 * d, M=I, N=nt3, K=4 * d, epi=E['TFX_EPI_F32'], C=self.tables, ldc=nt3,
                      bias=pp('transformer.layers.0.1.to_film.bias'))
         src = skip_sources(md)
+        fused_pre = {}                        # decode plans: layer -> its attention-side AdaLN-pre args when the previous layer's end launch runs them
         for i in range(D):
             p = f'transformer.layers.{i}'
             x_in = self.xres[i]
@@ -300,33 +301,54 @@ class Plan:
             else:
                 x_a = x_in
             ta, _ = self._tab(i, 0); tf, _ = self._tab(i, 1)
-            self._k(L, 'tfx_adaln_pre_fwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, u=self.ua[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
-                    gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i))
+            a_pre_attn = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x_a, u=self.ua[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
+                                        gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i))
+            if i in fused_pre:                # decode plans: already done by the previous layer's end launch (tfx_layer_end_fwd)
+                assert fused_pre[i].x == a_pre_attn.x and fused_pre[i].u == a_pre_attn.u
+            else:
+                L.append(('tfx_adaln_pre_fwd', a_pre_attn))
             self._nt(L, algo_n=md.nq, A=self.ua[i], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[i], ldc=ldq)
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
+            # decode plans: the KV-cache append (k~ | v rows at `cache_pos`, T:1005-1016) rides in the same launch - a decode step is launch-bound
+            ck = dict(cache=self.cache[i], ld_cache=2 * hd, cache_pos=self.cache_pos) if self.cache is not None else {}
             self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, qk=self.qkr[i], ld_qk=2 * hd,
                     gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
-                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5)
+                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck)
             self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
-            if self.cache is not None:
-                lib = capi.lib()
-                ck = self.cache[i]                                   # [b, maxlen, 2*hd]
-                self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkr, i) + 2 * hd, 2 * hd, hd, ck.data_ptr(), 2 * hd, self.cache_pos.data_ptr(), T)
-                self._raw(L, lib.tfx_scatter_rows_bf16, _p(self.qkvg, i) + 2 * 2 * hd, ldq, hd, ck.data_ptr() + 2 * hd, 2 * hd, self.cache_pos.data_ptr(), T)
             self._k(L, 'tfx_attn_fwd' if self.cache is None else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
             self._nt(L, algo_k=md.hd, A=self.og[i], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[i], ldc=d)
-            self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[i], out=self.xb[i], tok_inst=self.tok_inst,
-                    table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
-            self._k(L, 'tfx_adaln_pre_fwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], u=self.uf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
-                    gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i))
+            a_post = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[i], out=self.xb[i], tok_inst=self.tok_inst,
+                                    table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
+            a_pre = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], u=self.uf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
+                                   gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i))
+            if self.cache is not None:        # decode plans: both sides in one launch
+                self._keep = getattr(self, '_keep', []) + [a_post, a_pre]
+                self._raw(L, capi.lib().tfx_adaln_post_pre_fwd, ctypes.addressof(a_post), ctypes.addressof(a_pre))
+            else:
+                L.append(('tfx_adaln_post_fwd', a_post))
+                L.append(('tfx_adaln_pre_fwd', a_pre))
             self._nt(L, algo_n=2 * md.di, A=self.uf[i], lda=d, B=S[f'ff1{i}'], ldb=d, M=T, N=2 * dip, K=d, epi=E['TFX_EPI_GEGLU'], C=self.ag[i], ldc=2 * dip,
                      C2=self.hm[i], ldc2=dip, bias=S[f'ff1b{i}'])
             self._nt(L, algo_k=md.di, A=self.hm[i], lda=dip, B=S[f'ff2{i}'], ldb=dip, M=T, N=d, K=dip, epi=E['TFX_EPI_BF16'], C=self.yf[i], ldc=d,
                      bias=pp(f'{p}.2.fn.net.3.bias'))
-            self._k(L, 'tfx_adaln_post_fwd', 'tfx_adaln_post_args', T=T, d=d, x=self.xb[i], y=self.yf[i], out=self.hid[i + 1], tok_inst=self.tok_inst,
-                    table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
-            self._k(L, 'tfx_attnres_fwd', 'tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
-                    gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1])
+            a_postf = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=self.xb[i], y=self.yf[i], out=self.hid[i + 1], tok_inst=self.tok_inst,
+                                     table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
+            a_ar = capi.make_args('tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
+                                  gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1])
+            if self.cache is not None:
+                # decode plans: the end of the layer is ONE launch - feed-forward output side, AttentionResidual, and (when the next layer reads
+                # the result directly, i.e. has no U-Net skip projection in front) the next layer's attention-side AdaLN-pre
+                nxt = None
+                if i + 1 < D and not md.has_skip(i + 1):
+                    pn = f'transformer.layers.{i + 1}'
+                    nxt = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xres[i + 1], u=self.ua[i + 1], tok_inst=self.tok_inst, table=self._tab(i + 1, 0)[0],
+                                         ld_table=nt3, gamma_text=pp(f'{pn}.1.layernorm_gamma'), mean=_p(self.stats, 0, i + 1), rstd=_p(self.stats, 1, i + 1))
+                    fused_pre[i + 1] = nxt
+                self._keep = getattr(self, '_keep', []) + [a_postf, a_ar, nxt]
+                self._raw(L, capi.lib().tfx_layer_end_fwd, ctypes.addressof(a_postf), ctypes.addressof(a_ar), ctypes.addressof(nxt) if nxt is not None else None)
+            else:
+                L.append(('tfx_adaln_post_fwd', a_postf))
+                L.append(('tfx_attnres_fwd', a_ar))
         self._k(L, 'tfx_rmsnorm_fwd', 'tfx_rmsnorm_args', T=T, d=d, x=self.xres[D], y=self.embed, gamma=pp('transformer.norm.gamma'))
         self.fwd_embed_end = len(L)          # launches up to here produce `embed` (return_embed / decode paths stop here)
         self._nt(L, A=self.embed, lda=d, B=S['logits'], ldb=d, M=T, N=md.vp, K=d, algo_n=md.vocab, epi=E['TFX_EPI_F32'], C=self.logits, ldc=md.vp)   # zero pad rows: N % 4 == 0 keeps the LDS-DMA kernel
