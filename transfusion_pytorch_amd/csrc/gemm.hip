@@ -802,6 +802,108 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_skinny_kernel(GemmNT p) {
   nt_epilogue<EPI, 1>(p, acc, m0 + wm * 32, n0 + wn * 64, ring + w * 8192);
 }
 
+// Decode-step form of the skinny kernel.  At M = 64 ... 256 rows the weights are what is streamed, a launch has a handful of tiles, and its time is
+// ONE block's walk over K: ~0.36 us per 64-wide K-tile in the kernel above whatever the ring depth or tile width (measured: 5 or 8 tiles in flight,
+// 64 x 128 or 64 x 64 tiles - the same 23 us at K = 2752) - a wave's barrier -> fragment reads -> four dependent MFMAs per accumulator is a serial
+// chain with nothing to overlap it.  So K is split ACROSS THE FOUR WAVES of a block: a 64 x 64 output tile, wave w walks K quarter w in 32-wide
+// slabs through its OWN 4-slot LDS-DMA ring (8 KiB slots, three slabs in flight, no barrier in the loop - the ring is private), and the four
+// partial sums meet in LDS (fragment-major = conflict-free), where waves 0 / 1 add them and run the usual epilogue on 32 rows each.
+// 64-byte LDS rows: 16-byte chunk index XOR ((row >> 2) & 3), applied to the DMA source and to the fragment reads.
+constexpr int SD_BK = 32, SD_ST = 4;
+constexpr int SD_SLOT = (64 + 64) * SD_BK;              // elements per ring slot: A [64][32] then B [64][32]
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_decode_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  bf16* ring = (bf16*)smem_raw + w * SD_ST * SD_SLOT;              // this wave's private ring (32 KiB)
+  const int ntn = (p.N + 63) / 64;
+  const int m0 = (blockIdx.x / ntn) * 64, n0 = (blockIdx.x % ntn) * 64;
+  const int ns = p.K / SD_BK;
+  const int per = (ns + 3) / 4;
+  const int s0 = min(w * per, ns), s1 = min(s0 + per, ns);
+
+  // a slab = 4 + 4 DMA pieces of 16 rows x 64 B; lane l of a piece fetches chunk (l & 3) ^ swz of row 16 j + (l >> 2)
+  const bf16 *ga[4], *ga2[4], *gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int row = j * 16 + (l >> 2);
+    const int c = (l & 3) ^ ((row >> 2) & 3);
+    int rm = min(m0 + row, p.M - 1);
+    if (p.a_rowmap) rm = p.a_rowmap[rm];
+    ga[j] = p.A + (size_t)rm * p.lda + c * 8;
+    ga2[j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
+    gb[j] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + c * 8;
+  }
+  auto issue = [&](int sl) {                               // 8 DMA instructions per slab
+    const int k0 = sl * SD_BK;
+    bf16* slot = ring + ((sl - s0) & (SD_ST - 1)) * SD_SLOT;
+    const bool second = p.A2 && k0 >= p.K1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      glds16_asm(second ? ga2[j] + (k0 - p.K1) : ga[j] + k0, slot + j * 16 * SD_BK);
+      glds16_asm(gb[j] + k0, slot + 64 * SD_BK + j * 16 * SD_BK);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
+  for (int sl = s0; sl < min(s0 + SD_ST - 1, s1); sl++) issue(sl);
+  const int swz = ((l & 31) >> 2) & 3;
+  const int frow = (l & 31) * SD_BK;
+  for (int sl = s0; sl < s1; sl++) {
+    const int ahead = min(SD_ST - 2, s1 - 1 - sl);                 // slabs sl+1 .. sl+ahead may still be in flight
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sl + SD_ST - 1 < s1) issue(sl + SD_ST - 1);                // its slot was last read one iteration ago, by this wave only
+    const bf16* as = ring + ((sl - s0) & (SD_ST - 1)) * SD_SLOT;
+    const bf16* bs = as + 64 * SD_BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int ck = ((ks * 2 + hi) ^ swz) << 3;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) { af[i] = *(const bf16x8*)(as + i * 32 * SD_BK + frow + ck); bfr[i] = *(const bf16x8*)(bs + i * 32 * SD_BK + frow + ck); }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                                // every ring is idle: LDS becomes the reduction space
+  float* red = (float*)smem_raw;                                  // [4 waves][4 fragments][16 registers][64 lanes] = 64 KiB
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) red[((w * 4 + i * 2 + j) * 16 + r) * 64 + l] = acc[i][j][r];
+  __syncthreads();
+  f32x16 sum[1][2];
+  if (w < 2) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++) v += red[((ww * 4 + w * 2 + j) * 16 + r) * 64 + l];
+        sum[0][j][r] = v;
+      }
+  }
+  __syncthreads();                                                // the reduction space becomes the epilogue's staging area (16 KiB per wave)
+  if (w < 2) nt_epilogue<EPI, 1>(p, sum, m0 + w * 32, n0, (bf16*)smem_raw + w * 8192);
+}
+
 constexpr int BM2 = 256, BN2 = 256;     // tile of the ping-pong kernel below
 
 // TN with LDS-DMA: unpadded [64][128] tiles, 16-byte chunk index XOR ((row & 3) << 2) keeps the four rows of a
@@ -1126,6 +1228,18 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
   const bool dma = use_glds() && (p.N & 3) == 0;      // the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups
+  static int dec64 = -1;              // TFX_NT_DECODE=0: the 64 x 128 skinny kernel for every small M (A/B)
+  if (dec64 < 0) { const char* e = getenv("TFX_NT_DECODE"); dec64 = e ? atoi(e) : 1; }
+  const int grid_sd = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  // decode steps (samples x 1 ... x modality length rows): K split across the waves - as long as the 64 x 64 tiles fit the chip in one round
+  // (128 KiB of LDS = one block per CU; 344 tiles at M = 256, N = 5504 measured 19.9 us against 13.7 for the 64 x 128 kernel below)
+  if (dma && p.M <= 256 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) {
+    static bool attr_sd = false;
+    const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
+    if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }
+    hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI>, dim3(grid_sd), dim3(256), smem_sd, s, p);
+    return (int)hipGetLastError();
+  }
   if (dma && p.M <= 512) {                              // few row blocks: latency-bound, deep DMA ring (see gemm_nt_skinny_kernel)
     static bool attr_sk = false;
     const int smem_sk = SK_ST * SK_STAGE * 2;
