@@ -1233,7 +1233,7 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int grid_sd = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   // decode steps (samples x 1 ... x modality length rows): K split across the waves - as long as the 64 x 64 tiles fit the chip in one round
   // (128 KiB of LDS = one block per CU; 344 tiles at M = 256, N = 5504 measured 19.9 us against 13.7 for the 64 x 128 kernel below)
-  if (dma && p.M <= 256 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) {
+  if (dma && p.M <= 512 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) {
     static bool attr_sd = false;
     const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
     if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }

@@ -166,13 +166,22 @@ class Plan:
         # ---- forward activations
         self.hid = e(D + 1, T, d)
         self.xres = [self.hid[0]] + [e(T, d) for _ in range(D)]
-        self.xa = {i: e(T, d) for i in range(D) if md.has_skip(i)}
-        self.stats = e(4, D, T, dtype=torch.float32)          # mean_a, rstd_a, mean_f, rstd_f
-        self.ua = e(D, T, d); self.uf = e(D, T, d)
-        self.qkvg = z(D, T, ldq); self.qkr = e(D, T, 2 * hd); self.og = e(D, T, hd)
-        self.lse = e(D, b, md.heads, n, dtype=torch.float32)
-        self.ya = e(D, T, d); self.xb = e(D, T, d); self.yf = e(D, T, d)
-        self.ag = e(D, T, 2 * dip); self.hm = e(D, T, dip)
+        # A training plan keeps every layer's activations for the backward.  An inference plan (prefill / decode) needs per layer only what
+        # outlives the layer - the hiddens (AttentionResidual reads all of them), the AttentionResidual outputs (U-Net skips), and for a
+        # prefill the rotated keys / values that fill the KV cache afterwards; everything else is ONE buffer shared by all layers (`li` = 0).
+        # At dim 1024 / depth 24 a 64 x 320-token prefill plan is 5 GB this way instead of 25 GB: eight cached plans used to exhaust the 288 GB.
+        nl = D if training else 1
+        nkv = D if (training or cache is None) else 1
+        self._li = (lambda i: i) if training else (lambda i: 0)
+        self._lkv = (lambda i: i) if nkv == D else (lambda i: 0)
+        xa_shared = None if training else e(T, d)
+        self.xa = {i: (e(T, d) if training else xa_shared) for i in range(D) if md.has_skip(i)}
+        self.stats = e(4, nl, T, dtype=torch.float32)         # mean_a, rstd_a, mean_f, rstd_f
+        self.ua = e(nl, T, d); self.uf = e(nl, T, d)
+        self.qkvg = z(nkv, T, ldq); self.qkr = e(nkv, T, 2 * hd); self.og = e(nl, T, hd)
+        self.lse = e(nl, b, md.heads, n, dtype=torch.float32)
+        self.ya = e(nl, T, d); self.xb = e(nl, T, d); self.yf = e(nl, T, d)
+        self.ag = e(nl, T, 2 * dip); self.hm = e(nl, T, dip)
         self.embed = e(T, d)
         self.logits = e(T, md.vp, dtype=torch.float32); self.dlogits = e(T, md.vp)
         self.fe = z(I1, md.kf); self.cond = e(I1, 4 * d); self.pre = e(I1, 4 * d)
@@ -293,6 +302,7 @@ class Plan:
         fused_pre = {}                        # decode plans: layer -> its attention-side AdaLN-pre args when the previous layer's end launch runs them
         for i in range(D):
             p = f'transformer.layers.{i}'
+            li, lkv = self._li(i), self._lkv(i)
             x_in = self.xres[i]
             if md.has_skip(i):
                 self._nt(L, A=x_in, lda=d, A2=self.xres[src[i]], lda2=d, K1=d, B=S[f'skip{i}'], ldb=2 * d, M=T, N=d, K=2 * d,
@@ -301,37 +311,37 @@ class Plan:
             else:
                 x_a = x_in
             ta, _ = self._tab(i, 0); tf, _ = self._tab(i, 1)
-            a_pre_attn = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x_a, u=self.ua[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
-                                        gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i))
+            a_pre_attn = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x_a, u=self.ua[li], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
+                                        gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, li), rstd=_p(self.stats, 1, li))
             if i in fused_pre:                # decode plans: already done by the previous layer's end launch (tfx_layer_end_fwd)
                 assert fused_pre[i].x == a_pre_attn.x and fused_pre[i].u == a_pre_attn.u
             else:
                 L.append(('tfx_adaln_pre_fwd', a_pre_attn))
-            self._nt(L, algo_n=md.nq, A=self.ua[i], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[i], ldc=ldq)
+            self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[lkv], ldc=ldq)
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             # decode plans: the KV-cache append (k~ | v rows at `cache_pos`, T:1005-1016) rides in the same launch - a decode step is launch-bound
             ck = dict(cache=self.cache[i], ld_cache=2 * hd, cache_pos=self.cache_pos) if self.cache is not None else {}
-            self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, qk=self.qkr[i], ld_qk=2 * hd,
+            self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[lkv], ld_qkv=ldq, qk=self.qkr[lkv], ld_qk=2 * hd,
                     gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
                     cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck)
             self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
             self._k(L, 'tfx_attn_fwd' if self.cache is None else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
-            self._nt(L, algo_k=md.hd, A=self.og[i], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[i], ldc=d)
-            a_post = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[i], out=self.xb[i], tok_inst=self.tok_inst,
+            self._nt(L, algo_k=md.hd, A=self.og[li], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[li], ldc=d)
+            a_post = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[li], out=self.xb[li], tok_inst=self.tok_inst,
                                     table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
-            a_pre = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], u=self.uf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
-                                   gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i))
+            a_pre = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[li], u=self.uf[li], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
+                                   gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, li), rstd=_p(self.stats, 3, li))
             if self.cache is not None:        # decode plans: both sides in one launch
                 self._keep = getattr(self, '_keep', []) + [a_post, a_pre]
                 self._raw(L, capi.lib().tfx_adaln_post_pre_fwd, ctypes.addressof(a_post), ctypes.addressof(a_pre))
             else:
                 L.append(('tfx_adaln_post_fwd', a_post))
                 L.append(('tfx_adaln_pre_fwd', a_pre))
-            self._nt(L, algo_n=2 * md.di, A=self.uf[i], lda=d, B=S[f'ff1{i}'], ldb=d, M=T, N=2 * dip, K=d, epi=E['TFX_EPI_GEGLU'], C=self.ag[i], ldc=2 * dip,
-                     C2=self.hm[i], ldc2=dip, bias=S[f'ff1b{i}'])
-            self._nt(L, algo_k=md.di, A=self.hm[i], lda=dip, B=S[f'ff2{i}'], ldb=dip, M=T, N=d, K=dip, epi=E['TFX_EPI_BF16'], C=self.yf[i], ldc=d,
+            self._nt(L, algo_n=2 * md.di, A=self.uf[li], lda=d, B=S[f'ff1{i}'], ldb=d, M=T, N=2 * dip, K=d, epi=E['TFX_EPI_GEGLU'], C=self.ag[li], ldc=2 * dip,
+                     C2=self.hm[li], ldc2=dip, bias=S[f'ff1b{i}'])
+            self._nt(L, algo_k=md.di, A=self.hm[li], lda=dip, B=S[f'ff2{i}'], ldb=dip, M=T, N=d, K=dip, epi=E['TFX_EPI_BF16'], C=self.yf[li], ldc=d,
                      bias=pp(f'{p}.2.fn.net.3.bias'))
-            a_postf = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=self.xb[i], y=self.yf[i], out=self.hid[i + 1], tok_inst=self.tok_inst,
+            a_postf = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=self.xb[li], y=self.yf[li], out=self.hid[i + 1], tok_inst=self.tok_inst,
                                      table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
             a_ar = capi.make_args('tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
                                   gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1])
@@ -341,8 +351,8 @@ class Plan:
                 nxt = None
                 if i + 1 < D and not md.has_skip(i + 1):
                     pn = f'transformer.layers.{i + 1}'
-                    nxt = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xres[i + 1], u=self.ua[i + 1], tok_inst=self.tok_inst, table=self._tab(i + 1, 0)[0],
-                                         ld_table=nt3, gamma_text=pp(f'{pn}.1.layernorm_gamma'), mean=_p(self.stats, 0, i + 1), rstd=_p(self.stats, 1, i + 1))
+                    nxt = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xres[i + 1], u=self.ua[self._li(i + 1)], tok_inst=self.tok_inst, table=self._tab(i + 1, 0)[0],
+                                         ld_table=nt3, gamma_text=pp(f'{pn}.1.layernorm_gamma'), mean=_p(self.stats, 0, self._li(i + 1)), rstd=_p(self.stats, 1, self._li(i + 1)))
                     fused_pre[i + 1] = nxt
                 self._keep = getattr(self, '_keep', []) + [a_postf, a_ar, nxt]
                 self._raw(L, capi.lib().tfx_layer_end_fwd, ctypes.addressof(a_postf), ctypes.addressof(a_ar), ctypes.addressof(nxt) if nxt is not None else None)
@@ -434,9 +444,10 @@ class Plan:
 
     def _attn_kw(self, i, bwd=False):
         md, hd, ldq = self.md, self.md.hdk, self.md.ldq
-        kw = dict(q=self.qkr[i], k=_p(self.qkr, i) + 2 * hd, v=_p(self.qkvg, i) + 2 * 2 * hd, ld_q=2 * hd, ld_k=2 * hd, ld_v=ldq,
-                  gate=_p(self.qkvg, i) + 2 * 3 * hd, ld_gate=ldq, kv_end=self.kv_end, q_start=self.q_start, out=self.og[i], ld_out=hd,
-                  lse=self.lse[i], b=self.b, h=md.heads, n=self.n, softcap=50.0)
+        li, lkv = self._li(i), self._lkv(i)
+        kw = dict(q=self.qkr[lkv], k=_p(self.qkr, lkv) + 2 * hd, v=_p(self.qkvg, lkv) + 2 * 2 * hd, ld_q=2 * hd, ld_k=2 * hd, ld_v=ldq,
+                  gate=_p(self.qkvg, lkv) + 2 * 3 * hd, ld_gate=ldq, kv_end=self.kv_end, q_start=self.q_start, out=self.og[li], ld_out=hd,
+                  lse=self.lse[li], b=self.b, h=md.heads, n=self.n, softcap=50.0)
         if self.cache is not None:
             ck = self.cache[i]
             kw.update(k=ck.data_ptr(), v=ck.data_ptr() + 2 * hd, ld_k=2 * hd, ld_v=2 * hd, n_kv=int(ck.shape[1]))

@@ -209,9 +209,13 @@ class Sampler:
         Lcap = max([math.prod(sh) for sh in m.modality_default_shape if sh is not None] + [math.prod(fixed_modality_shape or (1,)), 16])
         maxlen = (max(s.cache_len for s in states) + max_length + 2 * Lcap + 80) // 64 * 64
         m._decode_plans = {}
-        cache = self._alloc_cache(B, max(maxlen, n0))
+        # classifier-free guidance evaluates every ODE step twice - against the real history and against the null-text one (T:2468-2525).  Both
+        # evaluations share the weights and a decode step is launch-bound, so they run as ONE forward over 2 B rows: the two KV caches are the halves
+        # of one buffer (the text steps use the first half through a view)
+        use_cfg = cfg_scale != 1.
+        joint = self._alloc_cache(2 * B if use_cfg else B, max(maxlen, n0))
+        cache = joint[:, :B]
         self._fill_cache(cache, plan, B, n0)
-        ucache = None
         logits0 = plan.logits.view(B, n0, md.vp)[..., :md.vocab]
         for st in states:
             self._maybe_transition(st, fixed_modality_shape)
@@ -232,7 +236,7 @@ class Sampler:
         while not all(s.phase == 'done' for s in states):
             # ------------------------------------------------ text phase
             while any(s.phase == 'text' for s in states):
-                cache = self._ensure_capacity(cache, states, 1)
+                joint = self._ensure_capacity(joint, states, 1); cache = joint[:, :B]
                 p = self._decode_plan(('text', cache.data_ptr()), B, 1, cache, False)
                 ids = np.zeros(B, np.int32); pos = np.full(B, -1, np.int32); kve = np.ones(B, np.int32); rot = np.zeros(B, np.int32)
                 for i, st in enumerate(states):
@@ -255,35 +259,35 @@ class Sampler:
             if not group:
                 continue
             Lmax = max(states[i].modality_length for i in group)
-            cache = self._ensure_capacity(cache, states, Lmax)
-            use_cfg = cfg_scale != 1.
+            joint = self._ensure_capacity(joint, states, Lmax); cache = joint[:, :B]
             if use_cfg:                                               # null-text history prefill, T:2386-2406
                 hist = [states[i].parts if i in group else [[m.null_text_id]] for i in range(B)]
                 past = max(max(states[i].num_past_modalities for i in group), 1)
                 uplan, US = m._forward_plain(self._as_batch(hist, null_text=True), torch.ones(B, past, device=dev), add_meta=False)
                 un = US['n']
-                if ucache is None or ucache.shape[2] < un + Lmax + 8 or ucache.shape[2] != cache.shape[2]:
-                    ucache = self._alloc_cache(B, max(cache.shape[2], (un + Lmax + 8 + 63) // 64 * 64))
-                self._fill_cache(ucache, uplan, B, un)
+                if joint.shape[2] < un + Lmax + 8:
+                    joint = self._grow(joint, un + Lmax + 8); cache = joint[:, :B]
+                self._fill_cache(joint[:, B:], uplan, B, un)
                 for i in group:
                     states[i].uncond_len = sum(math.prod(p[1].shape[:-1]) if isinstance(p, tuple) else len(p) for p in states[i].parts)
             y = torch.zeros(B, Lmax, max(md.dim_latents), device=dev)
             for i in group:
                 st = states[i]; L, dl = st.modality_length, md.dim_latents[st.curr_modality_id]
                 y[i, :L, :dl] = init_modality_noise[:L, :dl].to(dev) if init_modality_noise is not None else torch.randn(L, dl, device=dev)
-            cp = self._decode_plan(('mod', Lmax, cache.data_ptr()), B, Lmax, cache, True)
-            up = self._decode_plan(('umod', Lmax, ucache.data_ptr()), B, Lmax, ucache, True) if use_cfg else None
-            self._load_modality(cp, states, group, Lmax, cache.shape[2], uncond=False)
-            if use_cfg:
-                self._load_modality(up, states, group, Lmax, ucache.shape[2], uncond=True)
-
+            nb = 2 * B if use_cfg else B
+            jp = self._decode_plan(('mod', nb, Lmax, joint.data_ptr()), nb, Lmax, joint, True)
+            self._load_modality(jp, states, group, Lmax, joint.shape[2], halves=2 if use_cfg else 1)
             type_mask = self._type_masks(states, group, Lmax)
+            if use_cfg:
+                type_mask = {ty: torch.cat([mk, mk]) for ty, mk in type_mask.items()}
 
             def step(t, y_eval, y_base, a):
-                """y_base + a * velocity(t, y_eval): both model evaluations + guidance + the state update (tfx_ode_axpy)"""
-                f = self._eval(cp, type_mask, Lmax, t, y_eval, stream)
-                fu = self._eval(up, type_mask, Lmax, t, y_eval, stream) if use_cfg else None
-                return _ode_axpy(y_base, f, fu, cfg_scale, a, stream)
+                """y_base + a * velocity(t, y_eval): the conditional and the null-text evaluation in one forward (rows [0, B) and [B, 2B)),
+                guidance + the state update fused (tfx_ode_axpy)"""
+                if not use_cfg:
+                    return _ode_axpy(y_base, self._eval(jp, type_mask, Lmax, t, y_eval, stream), None, cfg_scale, a, stream)
+                out = self._eval(jp, type_mask, Lmax, t, torch.cat([y_eval, y_eval]), stream)
+                return _ode_axpy(y_base, out[:B], out[B:], cfg_scale, a, stream)
 
             ts = torch.linspace(0, 1, modality_steps)                  # fixed grid = the linspace itself (odeint midpoint)
             for k in range(modality_steps - 1):
@@ -349,9 +353,10 @@ class Sampler:
 
     def _ensure_capacity(self, cache, states, extra):
         need = max(s.cache_len for s in states) + extra + 1
-        if need <= cache.shape[2]:
-            return cache
-        new = self._alloc_cache(cache.shape[1], (need + 256) // 64 * 64)
+        return cache if need <= cache.shape[2] else self._grow(cache, need + 192)
+
+    def _grow(self, cache, need):
+        new = self._alloc_cache(cache.shape[1], (need + 63) // 64 * 64)
         new[:, :, :cache.shape[2]].copy_(cache)
         self.m._decode_plans = {}
         return new
@@ -373,39 +378,45 @@ class Sampler:
         p.idx[:5].copy_(host, non_blocking=True)
         p.set_rope_tables(*self.m._rope_tables(int(rot.max()) + 1))
 
-    def _load_modality(self, p, states, group, Lmax, maxlen, uncond):
+    def _load_modality(self, p, states, group, Lmax, maxlen, halves=1):
+        """index arrays of a modality decode step.  halves = 2: rows [0, B) run against the real history, rows [B, 2B) against the null-text
+        history (second half of the joint cache, its own prefix lengths) - the two evaluations of classifier-free guidance in one forward"""
         B, md = len(states), self.md
-        T = B * Lmax
+        T = halves * B * Lmax
         ids = np.zeros(T, np.int32); pos = np.full(T, -1, np.int32); kve = np.ones(T, np.int32); rot = np.zeros(T, np.int32)
         tok_inst = np.full(T, -1, np.int32)
         row_tok = {t: np.full(T, -1, np.int32) for t in range(self.m.num_modalities)}
-        for i in range(B):
-            st = states[i]
-            base = st.uncond_len if uncond else st.cache_len
-            kve[i * Lmax:(i + 1) * Lmax] = max(base, 1)
-            if i not in group:
-                continue
-            L, ty = st.modality_length, st.curr_modality_id
-            sl = slice(i * Lmax, i * Lmax + L)
-            kve[i * Lmax:(i + 1) * Lmax] = base + L                    # own prefix + own (bidirectional) modality block, T:2415-2419
-            pos[sl] = i * maxlen + base + np.arange(L)
-            rot[i * Lmax:(i + 1) * Lmax] = st.tokens_seen              # every token of the instance shares one position, T:2411
-            tok_inst[sl] = i
-            row_tok[ty][sl] = np.arange(i * Lmax, i * Lmax + L)
+        for h in range(halves):
+            for i in range(B):
+                st = states[i]
+                r = h * B + i                                              # batch row of the plan = cache row
+                base = st.uncond_len if h == 1 else st.cache_len
+                kve[r * Lmax:(r + 1) * Lmax] = max(base, 1)
+                if i not in group:
+                    continue
+                L, ty = st.modality_length, st.curr_modality_id
+                sl = slice(r * Lmax, r * Lmax + L)
+                kve[r * Lmax:(r + 1) * Lmax] = base + L                    # own prefix + own (bidirectional) modality block, T:2415-2419
+                pos[sl] = r * maxlen + base + np.arange(L)
+                rot[r * Lmax:(r + 1) * Lmax] = st.tokens_seen              # every token of the instance shares one position, T:2411
+                tok_inst[sl] = r
+                row_tok[ty][sl] = np.arange(r * Lmax, r * Lmax + L)
         self._load(p, ids, pos, kve, rot, tok_inst)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
         for t in row_tok:
             p.row_tok[t].copy_(up(row_tok[t])); p.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
-            p.row_inst[t].copy_(up(np.repeat(np.arange(B, dtype=np.int32), Lmax)))
+            p.row_inst[t].copy_(up(np.repeat(np.arange(halves * B, dtype=np.int32), Lmax)))
             p.set_noise(t, None)
         for t in p.ext_add:                      # axial positional embedding of the blocks being decoded (constant over the ODE steps); zeros = none
             add = p.lat[t]['add']
             add.zero_()
             if getattr(self, 'pos_emb_in_decode', False):
-                for i in group:
-                    st = states[i]
-                    if st.curr_modality_id == t:
-                        add[i * Lmax:i * Lmax + st.modality_length].copy_(self.m._pos_rows(t, [st.modality_shape]))
+                for h in range(halves):
+                    for i in group:
+                        st = states[i]
+                        if st.curr_modality_id == t:
+                            r = h * B + i
+                            add[r * Lmax:r * Lmax + st.modality_length].copy_(self.m._pos_rows(t, [st.modality_shape]))
 
     def _run(self, p, stream, lo, hi):
         """replay a range of a decode plan: eagerly the first time (one-off kernel attribute setup happens outside any capture), as a
