@@ -579,3 +579,22 @@ def test_channel_first_latents_with_frozen_encoder_decoder_match_reference_golde
                             fixed_modality_shape=(4,), force_modality_at_start=0, cfg_scale=1.)
     mods = [p for p in res[0] if isinstance(p, tuple)]
     assert len(mods) >= 2 and all(m[1].shape == (3, 4) for m in mods)
+
+
+def test_plan_cache_is_bounded_by_bytes_and_inference_plans_share_layer_buffers(monkeypatch):
+    """a plan owns every activation of its step: the cache evicts least-recently-used plans by total BYTES as well as by count, and an inference
+    plan keeps one set of per-layer scratch buffers for all layers (a training plan keeps them per layer for the backward)"""
+    from transfusion_pytorch_amd import Transfusion
+    m = Transfusion(num_text_tokens=32, dim_latent=16, modality_default_shape=(4,), transformer=dict(dim=64, depth=4, dim_head=8, heads=2)).cuda()
+    batch = lambda n: [[torch.randint(0, 32, (n,)).cuda(), torch.randn(4, 16).cuda()]]
+    loss = m(batch(40)); loss.backward()
+    train_plan = m._live[0]
+    with torch.no_grad():
+        m(batch(40), return_loss=False)
+    infer_plan = next(p for p in m._plans.values() if p is not train_plan)
+    assert train_plan.ua.shape[0] == 4 and infer_plan.ua.shape[0] == 1 and infer_plan.qkr.shape[0] == 4 and infer_plan.nbytes < 0.6 * train_plan.nbytes
+    monkeypatch.setenv('TFX_PLAN_BUDGET_GB', str(2.5 * train_plan.nbytes / 2 ** 30))
+    for n in (100, 170, 230, 300, 360):                       # five more bucketed lengths: only ~2 plans fit the budget
+        m(batch(n)).backward()
+        assert sum(p.nbytes for p in m._plans.values()) <= 2.5 * train_plan.nbytes * 4 and m._live[0] in m._plans.values()
+    assert len(m._plans) <= 3

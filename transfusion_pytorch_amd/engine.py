@@ -152,8 +152,11 @@ class Plan:
         self.T = T = b * n
         dev = ps.device
         d, hd, D, dip, ldq, nt3 = md.dim, md.hdk, md.depth, md.dip, md.ldq, md.nt3
-        z = lambda *s, dtype=BF16: torch.zeros(*s, device=dev, dtype=dtype)
-        e = lambda *s, dtype=BF16: torch.empty(*s, device=dev, dtype=dtype)
+        self.nbytes = 0                     # device bytes this plan owns (the plan cache evicts by total size, Transfusion._plan)
+        def z(*s, dtype=BF16):
+            t = torch.zeros(*s, device=dev, dtype=dtype); self.nbytes += t.numel() * t.element_size(); return t
+        def e(*s, dtype=BF16):
+            t = torch.empty(*s, device=dev, dtype=dtype); self.nbytes += t.numel() * t.element_size(); return t
         I1 = max(I, 1)
         # ---- index arrays (filled per step)
         # per-token index arrays: rows of ONE int32 buffer, so that a decode step uploads its five host-built arrays

@@ -543,6 +543,11 @@ class Transfusion(nn.Module):
             while len(self._plans) >= 8:                             # least recently used plan goes first (dict order = use order)
                 self._plans.pop(next(iter(self._plans)))
             plan = Plan(self.store, b, n, I, R, training=training, dp_groups=dp_groups)
+            # a plan owns every activation of its step (tens of GB for a training plan at dim 1024 / depth 24): besides the count, the cache is
+            # bounded by bytes - TFX_PLAN_BUDGET_GB, default 40 % of the device memory - oldest first, the new plan always stays
+            budget = float(os.environ.get('TFX_PLAN_BUDGET_GB', 0)) * 2 ** 30 or 0.4 * torch.cuda.get_device_properties(self.device).total_memory
+            while self._plans and sum(p.nbytes for p in self._plans.values()) + plan.nbytes > budget:
+                self._plans.pop(next(iter(self._plans)))
         self._plans[key] = plan                                      # (re-)insert at the most recent position
         return plan
 
