@@ -285,7 +285,7 @@ def main():
         # HBM bytes per launch of the roofline kernel family: rocprofv3 PMC passes of this same command, committed under
         # profiles/ (tools/pmc_traffic.sh; FETCH_SIZE x2 gfx950 correction applied there) - counters cannot be read in-process
         traffic, traffic_src = None, None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_traffic.json')
         if os.path.exists(tj) and (args.batch, args.dim, args.depth) == (64, 512, 8):
             tr = json.load(open(tj))
             if tr.get('kernel_family') == args.roofline_kernel:
