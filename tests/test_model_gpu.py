@@ -598,3 +598,28 @@ def test_plan_cache_is_bounded_by_bytes_and_inference_plans_share_layer_buffers(
         m(batch(n)).backward()
         assert sum(p.nbytes for p in m._plans.values()) <= 2.5 * train_plan.nbytes * 4 and m._live[0] in m._plans.values()
     assert len(m._plans) <= 3
+
+
+def test_large_vocabulary_multi_axial_latents_long_ragged_rows_match_live_oracle():
+    """off-grid in other directions: a 5000-token vocabulary (logits / CE over 5134 columns, the one-hot embedding-gradient GEMM), 2-d and 1-d
+    modality shapes in one batch (meta strings "2,3" / "5"), rows of 300+ tokens beside a 20-token row (several 128-query attention tiles with
+    ragged ends, heavy padding) - against the CPU oracle on the same inputs."""
+    from oracle import detdata as D
+    from oracle.transfusion_oracle import OracleConfig
+    cfg = OracleConfig(num_text_tokens=5000, dim=128, depth=2, dim_latents=(16, 24), heads=2, dim_head=64)
+    tx = lambda key, n: D.det_randint(f'big/{key}', (n,), 0, 5000)
+    batch = [[tx('a', 150), (0, D.det_normalish('big/m0', (2, 3, 16))), tx('b', 120), (1, D.det_normalish('big/m1', (5, 24))), tx('c', 40)],
+             [tx('d', 20)],
+             [(1, D.det_normalish('big/m2', (7, 24))), tx('e', 200), (0, D.det_normalish('big/m3', (3, 2, 16)))]]
+    times = D.det_uniform('big/t', (3, 2), 0.05, 0.95)
+    noise = {0: D.det_normalish('big/n0', (12, 16)), 1: D.det_normalish('big/n1', (12, 24))}
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag='big')
+    ref = forward_train(with_grad(sd), cfg, batch, times, noise, return_all=True)
+    sdg = None
+    model = build_native(cfg, sd).train()
+    model._noise_override = {t: v.cuda() for t, v in noise.items()}
+    loss = model(batch, times=times)
+    print(f'  loss native {float(loss.detach()):.6f} oracle {float(ref["loss"].detach()):.6f}')
+    assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-3 * max(1., abs(float(ref['loss'].detach())))
+    plan = model._live[0]
+    assert rel(plan.logits.view(plan.b, plan.n, -1)[:, :model._live_n_true, :cfg.vocab].float().cpu(), ref['logits'].detach()) <= LOGIT_TOL
