@@ -233,9 +233,17 @@ class Sampler:
             if st.num_tokens > max_length:
                 st.phase = 'done'
 
+        import os, time
+        tm = {'text': 0., 'text_steps': 0, 'uncond_prefill': 0., 'ode': 0., 'phases': 0} if os.environ.get('TFX_SAMPLE_TIMING') else None
+        def mark():
+            if tm is None:
+                return 0.
+            torch.cuda.synchronize(); return time.perf_counter()
         while not all(s.phase == 'done' for s in states):
             # ------------------------------------------------ text phase
+            t_a = mark()
             while any(s.phase == 'text' for s in states):
+                if tm is not None: tm['text_steps'] += 1
                 joint = self._ensure_capacity(joint, states, 1); cache = joint[:, :B]
                 p = self._decode_plan(('text', cache.data_ptr()), B, 1, cache, False)
                 ids = np.zeros(B, np.int32); pos = np.full(B, -1, np.int32); kve = np.ones(B, np.int32); rot = np.zeros(B, np.int32)
@@ -255,6 +263,8 @@ class Sampler:
                         st.phase = 'done'; continue
                     self._maybe_transition(st, fixed_modality_shape)
             # ------------------------------------------------ modality phase
+            t_b = mark()
+            if tm is not None: tm['text'] += t_b - t_a
             group = [i for i, s in enumerate(states) if s.phase == 'modality']
             if not group:
                 continue
@@ -270,6 +280,8 @@ class Sampler:
                 self._fill_cache(joint[:, B:], uplan, B, un)
                 for i in group:
                     states[i].uncond_len = sum(math.prod(p[1].shape[:-1]) if isinstance(p, tuple) else len(p) for p in states[i].parts)
+            t_c = mark()
+            if tm is not None: tm['uncond_prefill'] += t_c - t_b; tm['phases'] += 1
             y = torch.zeros(B, Lmax, max(md.dim_latents), device=dev)
             for i in group:
                 st = states[i]; L, dl = st.modality_length, md.dim_latents[st.curr_modality_id]
@@ -294,6 +306,7 @@ class Sampler:
                 t0, dt = float(ts[k]), float(ts[k + 1] - ts[k])
                 y_mid = step(t0, y, y, dt * 0.5)
                 y = step(t0 + dt * 0.5, y_mid, y, dt)
+            if tm is not None: tm['ode'] += mark() - t_c
             for i in group:                                            # commit, T:2531-2556
                 st = states[i]; L, dl, ty = st.modality_length, md.dim_latents[st.curr_modality_id], st.curr_modality_id
                 st.cache_len += L
@@ -302,6 +315,8 @@ class Sampler:
                 st.tokens_seen += 1; st.num_tokens += L; st.num_past_modalities += 1
                 st.phase = 'done' if st.num_tokens > max_length else 'text'
         m._decode_plans = {}
+        if tm is not None:
+            print('[TFX_SAMPLE_TIMING]', {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()})
         return [[(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in st.parts] for st in states]
 
     # ------------------------------------------------------------------ helpers
