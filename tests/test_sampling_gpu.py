@@ -169,3 +169,35 @@ def test_small_heads_cached_decode_is_consistent_with_the_full_forward():
     for b in range(seq.shape[0]):
         for i in range(prompt.shape[1] - 1, seq.shape[1] - 1):
             assert logits[b, i, seq[b, i + 1]].item() >= logits[b, i].max().item() - 0.05, (b, i)
+
+
+def test_incremental_null_text_cache_equals_full_reprefill(monkeypatch):
+    """classifier-free guidance needs the KV cache of the null-text history before every modality.  The reference re-runs the whole history
+    (T:2386-2406); the native sampler appends only what each sample added since its last modality (Sampler._uncond_append) - same keys / values up
+    to the kernels' accumulation order.  A model whose [som] logit is boosted opens many modalities: both forms must produce the same samples."""
+    from transfusion_pytorch_amd import Transfusion
+    torch.manual_seed(0)
+    m = Transfusion(num_text_tokens=16, dim_latent=(8, 16), modality_default_shape=((4,), (3, 3)), transformer=dict(dim=128, depth=2, dim_head=16, heads=4)).cuda().eval()
+    with torch.no_grad():
+        m.to_text_logits.weight[m.som_ids[0]] *= 3.; m.to_text_logits.weight[m.som_ids[1]] *= 3.
+        m.store.mark_dirty()
+    prompts = [[torch.randint(0, 16, (5,)).cuda()], [torch.randint(0, 16, (2,)).cuda(), (1, torch.randn(3, 3, 16).cuda())], None, [torch.randint(0, 16, (9,)).cuda()]]
+    kw = dict(max_length=48, text_temperature=0., init_modality_noise=torch.randn(16, 16).cuda(), modality_steps=3, cfg_scale=3., force_modality_at_start=0)
+    monkeypatch.setenv('TFX_UNCOND_INCREMENTAL', '0')
+    full = m.sample_many(prompts, **kw)
+    monkeypatch.setenv('TFX_UNCOND_INCREMENTAL', '1')
+    inc = m.sample_many(prompts, **kw)
+    n_mod = [sum(isinstance(p, tuple) for p in s) for s in full]
+    print('modalities per sample:', n_mod)
+    assert max(n_mod) >= 3, 'the test needs samples that pass through several modality phases'
+    worst = 0.
+    for a, b in zip(full, inc):
+        assert [isinstance(p, tuple) for p in a] == [isinstance(p, tuple) for p in b]
+        for pa, pb in zip(a, b):
+            if isinstance(pa, tuple):
+                assert pa[0] == pb[0] and pa[1].shape == pb[1].shape
+                worst = max(worst, float((pa[1] - pb[1]).norm() / (pa[1].norm() + 1e-20)))
+            else:
+                assert torch.equal(pa, pb)
+    print(f'decoded modalities, incremental vs full re-prefill: worst relative distance {worst:.2e}')
+    assert worst <= 2e-2

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -34,6 +35,8 @@ class _State:                                   # _SamplingState, T:1270-1287 (t
     phase: str = 'text'
     cache_len: int = 0
     uncond_len: int = 0
+    uncond_parts: int = 0                       # parts of `parts` whose tokens are in the null-text cache (incremental update between modality phases)
+    uncond_pos: int = 0                         # rotary position the next token of the null-text history takes
     tokens_seen: int = 0
     num_past_modalities: int = 0
     curr_modality_id: int | None = None
@@ -270,16 +273,29 @@ class Sampler:
                 continue
             Lmax = max(states[i].modality_length for i in group)
             joint = self._ensure_capacity(joint, states, Lmax); cache = joint[:, :B]
-            if use_cfg:                                               # null-text history prefill, T:2386-2406
-                hist = [states[i].parts if i in group else [[m.null_text_id]] for i in range(B)]
-                past = max(max(states[i].num_past_modalities for i in group), 1)
-                uplan, US = m._forward_plain(self._as_batch(hist, null_text=True), torch.ones(B, past, device=dev), add_meta=False)
-                un = US['n']
-                if joint.shape[2] < un + Lmax + 8:
-                    joint = self._grow(joint, un + Lmax + 8); cache = joint[:, :B]
-                self._fill_cache(joint[:, B:], uplan, B, un)
-                for i in group:
-                    states[i].uncond_len = sum(math.prod(p[1].shape[:-1]) if isinstance(p, tuple) else len(p) for p in states[i].parts)
+            if use_cfg:                                               # null-text history, T:2386-2406
+                flat_len = lambda parts: sum(math.prod(p[1].shape[:-1]) if isinstance(p, tuple) else len(p) for p in parts)
+                incremental = os.environ.get('TFX_UNCOND_INCREMENTAL', '1') != '0' and all(states[i].uncond_parts > 0 for i in group)
+                if incremental:
+                    # the reference re-runs the whole null-text history before every modality (T:2386-2406).  Its keys / values for the part
+                    # already in the cache do not change, so only what each sample appended since its last modality - the decoded block
+                    # (conditioned at t = 1) and the text after it - goes through the model, as ONE multi-token decode step against the cache
+                    need = max(flat_len(states[i].parts) for i in group) + Lmax + 8
+                    if joint.shape[2] < need:
+                        joint = self._grow(joint, need); cache = joint[:, :B]
+                    self._uncond_append(states, group, joint[:, B:], stream)
+                else:
+                    hist = [states[i].parts if i in group else [[m.null_text_id]] for i in range(B)]
+                    past = max(max(states[i].num_past_modalities for i in group), 1)
+                    uplan, US = m._forward_plain(self._as_batch(hist, null_text=True), torch.ones(B, past, device=dev), add_meta=False)
+                    un = US['n']
+                    if joint.shape[2] < un + Lmax + 8:
+                        joint = self._grow(joint, un + Lmax + 8); cache = joint[:, :B]
+                    self._fill_cache(joint[:, B:], uplan, B, un)
+                    for i in group:
+                        st = states[i]
+                        st.uncond_len, st.uncond_parts = flat_len(st.parts), len(st.parts)
+                        st.uncond_pos = sum(1 if isinstance(p, tuple) else len(p) for p in st.parts)       # a modality block takes one rotary position (T:398-415)
             t_c = mark()
             if tm is not None: tm['uncond_prefill'] += t_c - t_b; tm['phases'] += 1
             y = torch.zeros(B, Lmax, max(md.dim_latents), device=dev)
@@ -365,6 +381,61 @@ class Sampler:
             tok = pick(p.logits)
             out[:, step] = tok
         return out
+
+    def _uncond_append(self, states, group, ucache, stream):
+        """append what the samples of `group` added to their histories since their last modality phase - parts[uncond_parts:] : modality blocks
+        (prompt-style: conditioned at t = 1, bidirectional inside the block, one rotary position) and text (every integer token as the null id,
+        causal) - to the null-text KV cache with one decode-style forward; rows / positions as packing.token_maps would lay the full history out"""
+        m, md, B = self.m, self.md, len(states)
+        segs = {i: states[i].parts[states[i].uncond_parts:] for i in group}
+        seg_len = lambda parts: sum(math.prod(p[1].shape[:-1]) if isinstance(p, tuple) else len(p) for p in parts)
+        Lq = max(8, -(-max(seg_len(v) for v in segs.values()) // 8) * 8)           # bucketed: a handful of plans
+        assert all(sum(isinstance(p, tuple) for p in v) <= 1 for v in segs.values()), 'one decoded modality per sample between two phases'
+        maxlen = ucache.shape[2]
+        p = self._decode_plan(('uinc', Lq, ucache.data_ptr()), B, Lq, ucache, True)
+        T = B * Lq
+        ids = np.zeros(T, np.int32); pos = np.full(T, -1, np.int32); kve = np.ones(T, np.int32); rot = np.zeros(T, np.int32)
+        tok_inst = np.full(T, -1, np.int32)
+        row_tok = {t: np.full(T, -1, np.int32) for t in range(m.num_modalities)}
+        for t in p.ext_add:
+            p.lat[t]['add'].zero_()
+        for i in range(B):
+            st = states[i]
+            kve[i * Lq:(i + 1) * Lq] = max(st.uncond_len, 1)
+            if i not in segs:
+                continue
+            j, rp = 0, st.uncond_pos
+            for part in segs[i]:
+                if isinstance(part, tuple):
+                    ty, x = part
+                    L = math.prod(x.shape[:-1])
+                    sl = slice(i * Lq + j, i * Lq + j + L)
+                    pos[sl] = i * maxlen + st.uncond_len + j + np.arange(L)
+                    kve[sl] = st.uncond_len + j + L                       # the whole block sees itself
+                    rot[sl] = rp; rp += 1
+                    tok_inst[sl] = i
+                    row_tok[ty][sl] = np.arange(i * Lq + j, i * Lq + j + L)
+                    p.lat[ty]['x'][i * Lq + j:i * Lq + j + L].copy_(x.reshape(L, -1))
+                    if ty in p.ext_add:                                   # history modalities carry their positional embedding (T:3173-3176)
+                        p.lat[ty]['add'][i * Lq + j:i * Lq + j + L].copy_(m._pos_rows(ty, [tuple(x.shape[:-1])]))
+                    j += L
+                else:
+                    n = len(part)
+                    sl = slice(i * Lq + j, i * Lq + j + n)
+                    ids[sl] = m.null_text_id
+                    pos[sl] = i * maxlen + st.uncond_len + j + np.arange(n)
+                    kve[sl] = st.uncond_len + j + 1 + np.arange(n)
+                    rot[sl] = rp + np.arange(n); rp += n
+                    j += n
+            st.uncond_len += j; st.uncond_parts = len(st.parts); st.uncond_pos = rp
+        self._load(p, ids, pos, kve, rot, tok_inst)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        for t in row_tok:
+            p.row_tok[t].copy_(up(row_tok[t])); p.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
+            p.row_inst[t].copy_(up(np.repeat(np.arange(B, dtype=np.int32), Lq)))
+            p.set_noise(t, None)
+        p.inst_time.fill_(1.)
+        self._run(p, stream, 0, p.fwd_embed_end)
 
     def _ensure_capacity(self, cache, states, extra):
         need = max(s.cache_len for s in states) + extra + 1
