@@ -6,8 +6,9 @@ runs in the HIP kernels through a *decode plan* (engine.Plan with a KV cache):
 
   * text step (T:2279-2349)   one new token per active sample: embed -> transformer against the cache -> fp32 logits
   * modality step (T:2354-2556) joint fixed-grid midpoint ODE (torchdiffeq semantics) over all samples
-    in the modality phase; every evaluation = latent_to_model -> transformer (FiLM path, t = step time) against the
-    conditional cache, again against the null-text cache for classifier-free guidance, -> model_to_latent.
+    in the modality phase; every evaluation = latent_to_model -> transformer (FiLM path, t = step time) -> model_to_latent,
+    against the conditional cache and - classifier-free guidance - the null-text cache: ONE forward over 2 B rows (the two
+    caches are halves of one buffer).  The null-text cache is appended between phases (`_uncond_append`), not rebuilt.
 
 Cache semantics reproduced exactly: the new [som] token is NOT in the conditional cache when its modality is decoded
 (the modality block takes the rotary position the [som] would have had, T:2411); the K/V committed for a decoded
