@@ -276,8 +276,9 @@ def test_attention_fwd_bwd(b, h, n, qs, ks):
         assert (sim > 0.45).any(), 'this case must reach the exact-tanh branch'
 
 
-@pytest.mark.parametrize('b,h,lq,n_kv', [(3, 2, 1, 300), (2, 4, 4, 200), (5, 1, 6, 64), (2, 8, 16, 1100)])
-def test_attention_fwd_against_kv_cache(b, h, lq, n_kv):
+@pytest.mark.parametrize('entry', ['tfx_attn_fwd', 'tfx_decode_attn'])     # the forward kernel with cache addressing / the decode entry (<= 2 rows per sample: one block per (row, head))
+@pytest.mark.parametrize('b,h,lq,n_kv', [(3, 2, 1, 300), (2, 4, 4, 200), (5, 1, 6, 64), (2, 8, 16, 1100), (64, 8, 1, 333), (7, 3, 2, 77)])
+def test_attention_fwd_against_kv_cache(b, h, lq, n_kv, entry):
     """decode-time call (engine.Plan(cache=...)): `lq` new query rows per sample against keys / values that live in a LONGER per-sample
     cache buffer (`n_kv` > n rows, token-major [b, n_kv, 2 * h * 64] = k~ | v), each query row with its own visible length `kv_end`
     (own prefix + the block being decoded; rows of finished samples see a short prefix).  Reference: masked softmax in fp32."""
@@ -298,7 +299,7 @@ def test_attention_fwd_against_kv_cache(b, h, lq, n_kv):
     a = capi.make_args('tfx_attn_args', q=q, k=cache, v=cache[:, HD:], ld_q=HD, ld_k=2 * HD, ld_v=2 * HD, gate=gates[:, 8:], ld_gate=8 + h,
                        kv_end=kv_end, q_start=torch.zeros(T, dtype=torch.int32, device=DEV), out=out, ld_out=HD, lse=lse, b=b, h=h, n=lq,
                        n_kv=n_kv, softcap=50.0)
-    capi.call('tfx_attn_fwd', a, stream())
+    capi.call(entry, a, stream())
     torch.cuda.synchronize()
     qh = q.float().reshape(b, lq, h, 64).transpose(1, 2)
     kh = cache[:, :HD].float().reshape(b, n_kv, h, 64).transpose(1, 2)
