@@ -4,7 +4,7 @@ Conv2d / ConvTranspose2d pair in place of latent_to_model / model_to_latent, axi
 for the velocity-consistency term, `generate_modality_only` for samples.  There is no network here, so the digits are synthetic (a few Gaussian
 strokes per image); everything else is the reference script with the import changed.
 
-    python examples/train_image_flow_unet.py --steps 300
+    python examples/image_flow_unet.py --steps 300
 """
 from __future__ import annotations
 

@@ -1,9 +1,9 @@
 """Interleaved text + image training and guided sampling - the configuration of the reference's `train_mnist.py`: a class-label token followed
 by (or following) a 28 x 28 image, frozen patchify encoder / decoder to 14 x 14 x 4 latents (channel-first), axial positional embedding,
 classifier-free-guidance text drop during training (`prob_uncond`), an EMA copy that does the sampling (`ema_model.sample(prompt=..., cfg_scale=3)`).
-No network here: the "digits" are ten synthetic stroke templates (examples/train_image_flow_unet.py), the label is the template index.
+No network here: the "digits" are ten synthetic stroke templates (examples/image_flow_unet.py), the label is the template index.
 
-    python examples/train_text_image.py --steps 300
+    python examples/label_image_cfg.py --steps 300
 """
 from __future__ import annotations
 
@@ -17,7 +17,7 @@ from torch.utils.data import Dataset
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from transfusion_pytorch_amd import Transfusion, print_modality_sample          # noqa: E402
-from train_image_flow_unet import Patchify, Unpatchify                          # noqa: E402
+from image_flow_unet import Patchify, Unpatchify                          # noqa: E402
 
 
 class LabelledStrokes(Dataset):

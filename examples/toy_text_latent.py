@@ -1,8 +1,8 @@
 """The reference's smallest training loop (`train_toy.py`: a one-token text prefix + a (2, 16) latent per sample, torch Adam + global-norm clip,
 a sample every so often) on the native MI355X path - the only change against the reference script is the import.
 
-    python examples/train_toy.py --steps 200                # torch.optim.Adam over model.parameters(), as in the reference
-    python examples/train_toy.py --steps 200 --fused        # transfusion_pytorch_amd.optim.FusedAdam: one clip + Adam launch over the flat buffer
+    python examples/toy_text_latent.py --steps 200                # torch.optim.Adam over model.parameters(), as in the reference
+    python examples/toy_text_latent.py --steps 200 --fused        # transfusion_pytorch_amd.optim.FusedAdam: one clip + Adam launch over the flat buffer
 """
 from __future__ import annotations
 

@@ -20,21 +20,21 @@ def falling(losses, k=10):
 
 @pytest.mark.parametrize('fused', [False, True])
 def test_train_toy_loop(fused):
-    import train_toy
+    import toy_text_latent as train_toy
     losses = train_toy.main(steps=120, fused=fused, sample_every=60, log=lambda *a: None)
     assert len(losses) == 120 and all(l == l for l in losses)
     assert falling(losses)
 
 
 def test_image_flow_with_unet_ema_teacher_and_generation():
-    import train_image_flow_unet as ex
+    import image_flow_unet as ex
     losses, images = ex.main(steps=80, log=lambda *a: None)
     assert falling(losses)
     assert images.shape == (4, 1, 28, 28) and float(images.min()) >= 0. and float(images.max()) <= 1.
 
 
 def test_text_image_interleaved_with_guided_sampling():
-    import train_text_image as ex
+    import label_image_cfg as ex
     losses, out = ex.main(steps=80, log=lambda *a: None, fallback_shape=True)
     assert falling(losses)
     # the prompt label, then - if the model opened a modality - a decoded (1, 28, 28) image (T:2581-2583 decodes unless asked not to)
