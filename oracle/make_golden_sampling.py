@@ -28,6 +28,37 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 CFG = dict(num_text_tokens=256, dim=128, depth=4, dim_latents=(32,), heads=2, dim_head=64)
 CFG_DEEP = dict(num_text_tokens=256, dim=256, depth=8, dim_latents=(32,), heads=4, dim_head=64)
 DEEP_KW = dict(max_length=64, text_temperature=0., modality_steps=16, fixed_modality_shape=(4,), cfg_scale=3.)
+# the model of SURVEY 8(d) config 5 (dim 1024 / depth 24 / dim_latent 384: 885 M parameters): a short run of the same sampler, forced modality first
+CFG_BIG = dict(num_text_tokens=256, dim=1024, depth=24, dim_latents=(384,), heads=8, dim_head=64)
+BIG_KW = dict(max_length=20, text_temperature=0., modality_steps=4, fixed_modality_shape=(4,), cfg_scale=3., force_modality_at_start=0)
+
+
+def big_case():
+    cfg = OracleConfig(**CFG_BIG)
+    sd = D.det_state_dict(cfg.state_dict_shapes(), tag='sampling_big')
+    prompts = [D.det_randint('spb/p0', (10,), 0, 256), [D.det_randint('spb/p1', (5,), 0, 256), (0, D.det_normalish('spb/p1m', (3, 384)))]]
+    noise = D.det_normalish('spb/noise', (8, 384))
+    return cfg, sd, prompts, noise
+
+
+def run_big():
+    cfg, sd, prompts, noise = big_case()
+    model = build_reference_model(cfg, sd, modality_default_shape=(4,))
+    model.eval()
+    rec = MarginRecorder().install()
+    try:
+        outs = model.sample_many([p if not isinstance(p, list) else list(p) for p in prompts], init_modality_noise=noise, **BIG_KW)
+        margins = rec.take()
+    finally:
+        rec.remove()
+    g = dict(cfg=CFG_BIG, runs={'forced': [to_plain(o) for o in outs]}, margins={'forced': margins})
+    for i, o in enumerate(outs):
+        mg = margins[i]
+        print('big', i, [('mod', tuple(p[1].shape)) if isinstance(p, tuple) else p.tolist() for p in o],
+              f'| {len(mg)} decisions, min margin {min((m for _, _, m in mg), default=float("nan")):.4f}, {sum(m < 0.05 for _, _, m in mg)} below 0.05')
+    path = os.path.join(OUT, 'sampling_big.pt')
+    torch.save(g, path)
+    print('saved', path, os.path.getsize(path), 'bytes')
 
 
 def sampling_case(deep: bool = False, clean: bool = False):
@@ -137,6 +168,8 @@ def run_case(deep: bool, clean: bool = False):
 
 def main():
     import sys
+    if 'big' in sys.argv[1:]:
+        return run_big()
     if 'clean' in sys.argv[1:]:
         return run_case(False, clean=True)
     run_case(False)

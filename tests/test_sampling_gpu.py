@@ -201,3 +201,30 @@ def test_incremental_null_text_cache_equals_full_reprefill(monkeypatch):
                 assert torch.equal(pa, pb)
     print(f'decoded modalities, incremental vs full re-prefill: worst relative distance {worst:.2e}')
     assert worst <= 2e-2
+
+
+def test_sample_many_at_the_config5_model_size_matches_reference_golden():
+    """the model of SURVEY 8(d) config 5 - dim 1024 / depth 24 / dim_latent 384, 885 M parameters (AttentionResidual over 25 hiddens, 12 U-Net skip
+    pairs in the decode plans, the split-K decode GEMMs at K = 1024 / 2048 / 2752, the joint guidance forward, the incremental null-text cache) -
+    against the unmodified reference's `sample_many` (tests/golden/sampling_big.pt, oracle/make_golden_sampling.py big): every decisive greedy step
+    identical, decoded modalities within the bf16 tolerance."""
+    from oracle.make_golden_sampling import BIG_KW, big_case
+    from transfusion_pytorch_amd import Transfusion
+    g = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'sampling_big.pt'), weights_only=False)
+    cfg, sd, prompts, noise = big_case()
+    m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents[0], modality_default_shape=(4,),
+                    transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    m.load_state_dict(sd)
+    del sd
+    m = m.cuda().eval()
+    outs = m.sample_many([p if not isinstance(p, list) else list(p) for p in prompts], init_modality_noise=noise, **BIG_KW)
+    tot_dec = tot_all = n_mod = 0
+    for i, (o, r, mg) in enumerate(zip(outs, g['runs']['forced'], g['margins']['forced'])):
+        margins = {(pi, pos): v for pi, pos, v in mg}
+        n_dec, n_tie, errs, div = walk(plain(o), r, margins)
+        all_dec = sum(v >= NEAR_TIE for v in margins.values())
+        print(f'[big] sample {i}: {n_dec}/{all_dec} decisive steps identical (+{n_tie} near-ties passed); modality rel errs {["%.2e" % e for e in errs]}; left the reference path at {div}')
+        tot_dec += n_dec; tot_all += all_dec; n_mod += len(errs)
+        for e in errs:
+            assert e <= 5e-2
+    assert n_mod >= 2 and tot_dec >= 0.5 * tot_all
