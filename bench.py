@@ -197,7 +197,8 @@ def main():
     opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
     opt.always_sync = use_pg
     if use_pg and os.environ.get('TFX_DP_OVERLAP', '1') != '0':
-        opt.overlap_grad_sync(groups=4)                       # the gradient all-reduce goes out in 4 layer groups DURING the backward
+        # the gradient all-reduce goes out in 4 layer groups DURING the backward; fp32 on the links like the reference's DDP (TFX_DP_BF16=1: bf16)
+        opt.overlap_grad_sync(groups=4, exchange_dtype=torch.bfloat16 if os.environ.get('TFX_DP_BF16') == '1' else None)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     torch.manual_seed(7 + rank)                               # per-rank noise / times / CFG streams
     # a FRESH batch for every step (train_toy.py:50-52 draws new data each iteration): generated before the timed region (the metric excludes

@@ -88,6 +88,15 @@ def _worker_overlap(rank, world, port, q):
     gm = sum(all_local) / world
     gm = gm * min(1., 0.5 / (float(gm.norm()) + 1e-6))
     ok &= bool(torch.allclose(new, ps.flat.detach() - 3e-4 * gm / (gm.abs() + 1e-8), rtol=0, atol=1e-6))
+    # the same exchange in bf16 (half the bytes on the links): every element still reduced exactly once, the sum within bf16 rounding of the fp32 one
+    ps.grad = local.clone()
+    red16 = GradReducer(m, None, groups=3, exchange_dtype=torch.bfloat16)
+    red16.begin()
+    for first in range(((5 - 1) // per) * per, -1, -per):
+        red16.group_ready(first, min(first + per, 5) - 1)
+    red16.finish()
+    ok &= bool(((ps.grad - expect).abs() <= 2 ** -7 * (sum(a.abs() for a in all_local)) + 1e-6).all())
+    ok &= not bool(torch.equal(ps.grad, expect))                              # (it really travelled in bf16)
     q.put((rank, ok))
     dist.destroy_process_group()
 

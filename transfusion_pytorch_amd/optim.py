@@ -21,12 +21,13 @@ class GradReducer:
     backward of the earlier layers runs; what is left (time conditioning, embeddings, input projections) follows the backward.
     Every element is reduced exactly once (tests/test_dp_gloo.py).  One process per GPU, RCCL over xGMI via torch.distributed."""
 
-    def __init__(self, model, process_group=None, groups: int = 4):
+    def __init__(self, model, process_group=None, groups: int = 4, exchange_dtype=None):
         self.model, self.group = model, process_group
+        self.exchange_dtype = exchange_dtype         # torch.bfloat16: the ranges travel as bf16 (half the xGMI bytes), summed in bf16, written back to the fp32 buffer
         ps, md = model.store, model.md
         self.groups = max(1, min(groups, md.depth))
         self.per = -(-md.depth // self.groups)
-        self.handles, self.done = [], []
+        self.handles, self.done, self.staged = [], [], []
         self._step = -1
         d, D = md.dim, md.depth
         off = lambda name: ps.offsets[name][0]
@@ -47,13 +48,21 @@ class GradReducer:
         g = self.model.store.grad
         for a, b in ranges:
             if b > a:
-                h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-                if async_op:
-                    self.handles.append(h)
+                if self.exchange_dtype is not None:
+                    buf = g[a:b].to(self.exchange_dtype)
+                    h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                    if async_op:
+                        self.handles.append(h); self.staged.append((a, b, buf))
+                    else:
+                        g[a:b].copy_(buf)
+                else:
+                    h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                    if async_op:
+                        self.handles.append(h)
                 self.done.append((a, b))
 
     def begin(self):
-        self.handles, self.done = [], []
+        self.handles, self.done, self.staged = [], [], []
 
     def group_ready(self, lo: int, hi: int):
         """called between two segments of the backward list: layers lo..hi are final (and, at the first cut, nothing else is)"""
@@ -74,6 +83,10 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        g = self.model.store.grad
+        for a, b, buf in self.staged:                 # reduced-precision ranges come back into the fp32 buffer
+            g[a:b].copy_(buf)
+        self.staged = []
         assert sum(b - a for a, b in self.done) == n, 'every gradient element must be reduced exactly once'
 
 
@@ -94,9 +107,10 @@ class FusedAdam:
         self.ext_params = list(model.external_parameters()) if hasattr(model, 'external_parameters') else []
         self.ext_opt = torch.optim.Adam(self.ext_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if self.ext_params else None
 
-    def overlap_grad_sync(self, groups: int = 4):
-        """exchange the gradients in `groups` layer groups DURING the backward (GradReducer) instead of one all-reduce after it"""
-        self.reducer = GradReducer(self.model, self.group, groups)
+    def overlap_grad_sync(self, groups: int = 4, exchange_dtype=None):
+        """exchange the gradients in `groups` layer groups DURING the backward (GradReducer) instead of one all-reduce after it;
+        `exchange_dtype=torch.bfloat16` halves the bytes on the links (the sum is formed in bf16; master gradients stay fp32)"""
+        self.reducer = GradReducer(self.model, self.group, groups, exchange_dtype)
         self.model._grad_reducer = self.reducer
         self.model._dp_groups = self.reducer.groups
         return self
