@@ -19,6 +19,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -237,7 +238,6 @@ class Sampler:
             if st.num_tokens > max_length:
                 st.phase = 'done'
 
-        import os, time
         tm = {'text': 0., 'text_steps': 0, 'uncond_prefill': 0., 'ode': 0., 'phases': 0} if os.environ.get('TFX_SAMPLE_TIMING') else None
         def mark():
             if tm is None:
