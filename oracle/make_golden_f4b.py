@@ -56,6 +56,11 @@ def pos_case():
     return cfg, sd, batch, times, noise, xm, nm, tm, prompt, init_noise
 
 
+SAMPLE_MAX_LEN = 70
+SAMPLE_PROMPT = lambda: D.det_randint('f4b/u/prompt', (5,), 0, 256)
+SAMPLE_NOISE = lambda: D.det_normalish('f4b/u/init', (64, 4))
+
+
 def unet_modules(dim):
     enc, dec = nn.Conv2d(4, dim, 3, 2, 1), nn.ConvTranspose2d(dim, 4, 3, 2, 1, output_padding=1)
     fill_module_(enc, 'f4b/unet/enc', 0.15); fill_module_(dec, 'f4b/unet/dec', 0.05)
@@ -169,10 +174,26 @@ def make_unet():
         logits = model(batch, times=times, return_loss=False)
     with patched('randn', [g0]):
         gen = model.generate_modality_only(batch_size=2, modality_steps=GEN_STEPS)
+    # `sample()` as train_mnist_with_unet.py / train_latent_with_text.py call it: the UN-CACHED sample_one (the stride-2 encoder changes the token
+    # count, which the cached paths cannot slice).  Greedy text, injected modality noise; cfg_scale = 1 because the reference's guidance branch
+    # ALWAYS decodes against a null-text kv cache (T:1972-1988, whatever `cache_kv` says) and then fails on this model (`decode_length` = 64 latent
+    # positions against a block of 16 tokens: "shape '[4, 4, 128]' is invalid for input of size 2944").  One thing is pinned that the
+    # reference leaves to chance: its un-cached text steps draw RANDOM times for the modalities already in the history (T:1917-1924 passes no
+    # `times`); every other call of its samplers conditions them at 1 (T:1996, T:2192), and so does this golden (and the native loop).
+    import transfusion_pytorch.transfusion as T
+    orig_fn = T.default_modality_length_to_time_fn
+    T.default_modality_length_to_time_fn = lambda num_modalities: torch.ones(num_modalities.shape[0], max(int(num_modalities.amax()), 1))
+    try:
+        out = model.sample_one(SAMPLE_PROMPT(), max_length=SAMPLE_MAX_LEN, text_temperature=0., init_modality_noise=SAMPLE_NOISE(), modality_steps=GEN_STEPS,
+                               cfg_scale=1., force_modality_at_start=0, cache_kv=False)
+    finally:
+        T.default_modality_length_to_time_fn = orig_fn
+    parts = [(p if not isinstance(p, tuple) else ('mod', p[0], p[1])) for p in out]
     torch.save(dict(ext_sd=ext_sd, loss=loss.detach(), text_loss=bd.text.detach(), flow_losses=[f.detach() for f in bd.flow], grad_norms=gn, grad_heads=gh,
-                    fm_loss=lm.detach(), fm_grad_norms=gn_m, fm_grad_heads=gh_m, fm_pred=pm, logits=logits, gen=gen),
+                    fm_loss=lm.detach(), fm_grad_norms=gn_m, fm_grad_heads=gh_m, fm_pred=pm, logits=logits, gen=gen, sample=parts),
                os.path.join(OUT, 'f4b_unet.pt'))
-    print('unet: loss', float(loss), 'fm', float(lm), 'gen', tuple(gen.shape), 'logits', tuple(logits.shape))
+    print('unet: loss', float(loss), 'fm', float(lm), 'gen', tuple(gen.shape), 'logits', tuple(logits.shape),
+          'sample', [tuple(p.shape) if torch.is_tensor(p) else tuple(p[2].shape) for p in parts])
 
 
 if __name__ == '__main__':

@@ -162,3 +162,31 @@ def test_processing_strategy_registry_returns_the_reference_batch_type():
         assert abs(float(out.get_recon_losses[0][0](pf.cuda())) - float(want)) < 1e-5
     no_meta = PROCESSING_STRATEGIES['auto'](batch, times, m, return_loss=False, return_embed=True)       # decode-time layout: no meta tokens (MP:330)
     assert no_meta.text.shape[1] < ref.text.shape[1] and not no_meta.flows
+
+
+def test_forward_text_cache_and_hiddens():
+    """`forward_text` (tensor input of forward(), T:2586-2645) hands out and takes `(kv, tokens_seen)`: a multi-token cached call over the NEW tokens
+    reproduces those rows of the full forward; hiddens = [x_0 .. x_depth, final norm output]."""
+    m, cfg, prompts, _ = native_model()
+    seq = torch.cat([prompts[0], prompts[3][0]]).cuda()[None].repeat(2, 1)               # (2, 18)
+    seq[1] = seq[1].flip(0)
+    n0 = 9
+    with torch.no_grad():
+        full, hid_full = m.forward_text(seq, return_loss=False, return_hiddens=True)
+        assert rel(full, m(seq, return_loss=False)) < 1e-5
+        assert len(hid_full) == cfg.depth + 2 and all(h.shape == (2, 18, cfg.dim) for h in hid_full)
+        logits, (kv, seen) = m.forward_text(seq[:, :n0], return_loss=False, return_kv_cache=True)
+        assert seen == n0 and kv.shape == (cfg.depth, 2, 2, cfg.heads, n0, cfg.dim_head)
+        assert rel(logits, full[:, :n0]) < 1e-2
+        # four new tokens at once, then one at a time through forward() with a tensor input (T:2967-2968 routes it here)
+        step, (kv, seen), hid = m.forward_text(seq[:, n0:n0 + 4], return_loss=False, cache=(kv, seen), return_kv_cache=True, return_hiddens=True)
+        assert step.shape == (2, 4, full.shape[-1]) and seen == n0 + 4 and kv.shape[4] == n0 + 4
+        assert rel(step, full[:, n0:n0 + 4]) < 1.5e-2
+        assert rel(hid[-1], hid_full[-1][:, n0:n0 + 4]) < 1.5e-2
+        cache = (kv, seen)
+        for i in range(n0 + 4, 18):
+            step, cache = m(seq[:, i:i + 1], return_loss=False, cache=cache, return_kv_cache=True)
+            assert rel(step[:, 0], full[:, i]) < 1.5e-2, i
+        assert cache[1] == 18
+        with pytest.raises(NotImplementedError):
+            m.forward_text(seq, return_kv_cache=True)                                      # a loss and a cache in one call: not in the native path

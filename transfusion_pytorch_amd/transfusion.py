@@ -605,10 +605,11 @@ class Transfusion(nn.Module):
         """inference forward over explicit samples (nothing added, no noising): fills and runs a non-training plan up to the
         fp32 logits.  Returns (plan, structure).  Used by the sampler's prefills (T:2194-2201, T:2389-2406)."""
         self._require_gpu()
-        if self._ext:
-            raise NotImplementedError('decoding (sample / sample_many / the kv-cache forward) with pre_post_transformer_enc_dec modality types is not '
-                                      'wired in the native path - use forward() / forward_modality() / generate_modality_only()')
         dev, stream = self.device, self._stream()
+        ext_ctx = None
+        if self._ext:                                # the user's encoders produce the token rows (encoder layout in, as forward() hands it over)
+            with torch.no_grad():
+                samples, ext_ctx = self._ext_preprocess(samples, None, return_loss=False)
         sig, user_text, latents = fast_signature(samples)
         key = (sig, 'plain', add_meta, pad_n)
         S = self._struct_cache.pop(key, None)
@@ -644,11 +645,15 @@ class Transfusion(nn.Module):
             if t in R:
                 r = R[t]
                 plan.row_tok[t][:r].copy_(S['row_tok'][t]); plan.row_inst[t][:r].copy_(S['row_inst'][t])
-                plan.lat[t]['x'][:r].copy_(torch.cat(latents[t]).to(dev, torch.float32))
+                if t in plan.ext:
+                    plan.lat[t]['tok'][:r].copy_(torch.cat(ext_ctx[t]['tok']))
+                else:
+                    plan.lat[t]['x'][:r].copy_(torch.cat(latents[t]).to(dev, torch.float32))
                 if t in plan.ext_add:                                 # prompted modalities carry their axial positional embedding (T:3173-3176)
                     P = S['P']
                     plan.lat[t]['add'][:r].copy_(self._pos_rows(t, [P.inst_shape[g] for g in range(I) if int(P.inst_type[g]) == t]))
-            plan.set_noise(t, None)
+            if t not in plan.ext:
+                plan.set_noise(t, None)
         Plan.run(plan.fwd, stream, 0, plan.fwd_logits_end)
         return plan, S
 
@@ -928,6 +933,8 @@ class Transfusion(nn.Module):
         """`model_to_latent_projs[type]` (Linear(dim, dim_latent, bias=False), T:1479) applied to rows of the final embedding - the last
         step of the reference's external decode loop (T:2013-2015) - through the native NT GEMM.  embed_rows: (..., dim) -> (..., dim_latent) fp32."""
         self._require_gpu()
+        if modality_type in self._ext:                                 # the user's decoder (add_temp_batch_dim(mod.model_to_latent), T:2013); (*axial, dim) in
+            return self.model_to_latent_projs[modality_type](embed_rows.to(self.device, torch.float32)[None])[0]
         md, dev, stream = self.md, self.device, self._stream()
         self.store.refresh_shadows(stream)
         x = embed_rows.reshape(-1, md.dim).to(dev, torch.bfloat16).contiguous()
@@ -981,16 +988,19 @@ class Transfusion(nn.Module):
                 nm = max((sum(1 for p in s if isinstance(p, tuple) or (torch.is_tensor(p) and p.is_floating_point())) for s in modalities), default=0)
                 times = self._default_times(np.array([sum(1 for p in s if isinstance(p, tuple) or (torch.is_tensor(p) and p.is_floating_point()))
                                                      for s in modalities])) if nm else torch.empty((b, 0), device=dev)
-            plan, S = self._forward_plain(modalities, times, add_meta=not return_embed, pad_n=1)
-            n, P, tm = S['n'], S['P'], S['tm']
-            out = (plan.embed.view(b, n, md.dim).float(), self._pred_flow_closures(P)) if return_embed \
-                else plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
+            # lengths are bucketed to multiples of 64 (an un-cached decode loop calls this once per token: one plan per bucket, not per length);
+            # the padding columns sit behind every real token and are cut off again below
+            plan, S = self._forward_plain(modalities, times, add_meta=not return_embed, pad_n=64)
+            n_pad, n, P, tm = S['n'], S['n_true'], S['P'], S['tm']
+            out = (plan.embed.view(b, n_pad, md.dim)[:, :n].float(), self._pred_flow_closures(P)) if return_embed \
+                else plan.logits.view(b, n_pad, md.vp)[:, :n, :md.vocab].clone()
             kv = None
             if return_kv_cache:
-                buf = torch.zeros(md.depth, b, -(-(n + 64) // 64) * 64, 2 * md.hdk, device=dev, dtype=torch.bfloat16)
-                Sampler(self)._fill_cache(buf, plan, b, n)
+                buf = torch.zeros(md.depth, b, -(-(n_pad + 64) // 64) * 64, 2 * md.hdk, device=dev, dtype=torch.bfloat16)
+                Sampler(self)._fill_cache(buf, plan, b, n_pad)
                 buf._tfx_filled = n
-                kv = (self._kv_public(buf, n), int(tm.rot_pos.max()) + 1 if tm.rot_pos.size else 0)
+                rp = tm.rot_pos.reshape(b, n_pad)[:, :n]
+                kv = (self._kv_public(buf, n), int(rp.max()) + 1 if rp.size else 0)
         else:
             assert decode_length is not None, '`decode_length` must be passed in on forward for modality sampling. think of a cleaner way on some future date'   # T:3191
             assert decoding in ('text', 'modality')                                                                                                          # T:3192
@@ -1020,6 +1030,10 @@ class Transfusion(nn.Module):
                     last = (0, last) if torch.is_tensor(last) and last.is_floating_point() else last
                     assert isinstance(last, tuple), 'decoding a modality: every sample must end in the modality being decoded'
                     ty, x = int(last[0]), last[1]
+                    if ty in self._ext:                                    # the user's encoder makes the block's token rows (encoder layout in)
+                        x = x.to(dev, torch.float32)
+                        pre = self.latent_to_model_projs[ty]
+                        x = pre(x[None])[0] if self.channel_first_latent[ty] else pre(x)
                     assert int(np.prod(x.shape[:-1])) == L, '`decode_length` must be the number of tokens of the trailing modality'
                     tys.append((ty, x))
                     tok_inst[i * L:(i + 1) * L] = i
@@ -1030,21 +1044,26 @@ class Transfusion(nn.Module):
                     plan.lat[t]['add'].zero_()
                 for i, (ty, x) in enumerate(tys):
                     row_tok[ty][i * L:(i + 1) * L] = np.arange(i * L, (i + 1) * L)
-                    plan.lat[ty]['x'][i * L:(i + 1) * L].copy_(x.reshape(L, -1).to(dev, torch.float32))
+                    plan.lat[ty]['tok' if ty in plan.ext else 'x'][i * L:(i + 1) * L].copy_(x.reshape(L, -1).to(dev, torch.float32))
                     if ty in plan.ext_add:                                # the decoded block's positional embedding (T:3179-3180 under the decode slice T:1167-1176)
                         plan.lat[ty]['add'][i * L:(i + 1) * L].copy_(self._pos_rows(ty, [tuple(x.shape[:-1])]))
                 up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
                 for t in row_tok:
                     plan.row_tok[t].copy_(up(row_tok[t])); plan.row_src[t].copy_(up(np.maximum(row_tok[t], 0)))
                     plan.row_inst[t].copy_(up(np.repeat(np.arange(b, dtype=np.int32), L)))
-                    plan.set_noise(t, None)
+                    if t not in plan.ext:
+                        plan.set_noise(t, None)
                 assert times is not None, 'decoding a modality needs `times` (the ODE step time in the last column, T:1990-1996)'
                 plan.inst_time.copy_(times.to(dev, torch.float32).reshape(b, -1)[:, -1])
             smp._load(plan, ids=ids, pos=pos, kve=kve, rot=rot, tok_inst=tok_inst)
             Plan.run(plan.fwd, stream, 0, plan.fwd_embed_end if return_embed else plan.fwd_logits_end)
             n = L
             if return_embed:
-                P = self._scan(modalities, add_sos_eos=False, add_meta=False)
+                scan_in = modalities
+                if self._ext:                                                  # the closures reshape to the PROJECTED axial shapes (MP:738-741)
+                    with torch.no_grad():
+                        scan_in, _ = self._ext_preprocess(modalities, None, return_loss=False)
+                P = self._scan(scan_in, add_sos_eos=False, add_meta=False)
                 out = (plan.embed.view(b, L, md.dim).float(), self._pred_flow_closures(P))
             else:
                 out = plan.logits.view(b, L, md.vp)[..., :md.vocab].clone()
@@ -1056,7 +1075,8 @@ class Transfusion(nn.Module):
         if return_kv_cache:
             ret = (*ret, kv)
         if return_hiddens:                                                     # hiddens = [x_0 .. x_depth, final norm output] (T:1199, T:1244, T:1253)
-            ret = (*ret, [plan.hid[i].view(b, n, md.dim).float() for i in range(md.depth + 1)] + [plan.embed.view(b, n, md.dim).float()])
+            nn_ = plan.T // b                                                     # the plan's (bucketed) row length; only the n real tokens go out
+            ret = (*ret, [plan.hid[i].view(b, nn_, md.dim)[:, :n].float() for i in range(md.depth + 1)] + [plan.embed.view(b, nn_, md.dim)[:, :n].float()])
         if return_times:
             ret = (*ret, times)
         return ret[0] if len(ret) == 1 else ret
@@ -1064,12 +1084,15 @@ class Transfusion(nn.Module):
     # ------------------------------------------------------------------ pure-text LM path (T:2586-2664)
     def forward_text(self, text, return_loss=True, return_embed=False, cache=None, return_hiddens=False, return_kv_cache=False):
         """`Transfusion.forward_text`: the hot path with zero modalities - causal mask, no conditioning, cross entropy over the
-        text-only part of the vocabulary (`text_only_logits_mask`, T:1509, T:2653).  KV-cached decoding goes through `sample_*`."""
+        text-only part of the vocabulary (`text_only_logits_mask`, T:1509, T:2653).  Inference calls also take / return the kv cache
+        `(tensor, tokens_seen)` and the hiddens (T:2612-2645): with a cache, `text` holds the NEW tokens only (rotary positions from tokens_seen)."""
         self._require_gpu()
-        if cache is not None or return_hiddens or return_kv_cache:
-            raise NotImplementedError('forward_text: kv cache / hiddens are not wired in the native path (use sample_many for decoding)')
+        if (cache is not None or return_hiddens or return_kv_cache) and return_loss:
+            raise NotImplementedError('forward_text: kv cache / hiddens are returned by the inference call only (return_loss = False)')
         dev, stream, md = self.device, self._stream(), self.md
         text = text.to(dev)
+        if cache is not None:
+            return self._forward_text_cached(text, cache, return_embed, return_kv_cache, return_hiddens)
         inp, labels = (text[:, :-1], text[:, 1:]) if return_loss else (text, None)          # T:2603-2604
         b, n = inp.shape
         key = ('text', b, n)
@@ -1091,9 +1114,17 @@ class Transfusion(nn.Module):
         plan.text_ids.copy_(inp.masked_fill(inp == -1, 0).reshape(-1))                      # T:2608
         if not return_loss:
             Plan.run(plan.fwd, stream, 0, plan.fwd_embed_end if return_embed else plan.fwd_logits_end)
-            if return_embed:
-                return plan.embed.view(b, n, md.dim).float()
-            return plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
+            out = plan.embed.view(b, n, md.dim).float() if return_embed else plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
+            ret = (out,)
+            if return_kv_cache:                                                            # (tensor, tokens_seen + seq_len), T:2631
+                from .sampling import Sampler
+                buf = torch.zeros(md.depth, b, -(-(n + 64) // 64) * 64, 2 * md.hdk, device=dev, dtype=torch.bfloat16)
+                Sampler(self)._fill_cache(buf, plan, b, n)
+                buf._tfx_filled = n
+                ret = (*ret, (self._kv_public(buf, n), n))
+            if return_hiddens:
+                ret = (*ret, [plan.hid[i].view(b, n, md.dim).float() for i in range(md.depth + 1)] + [plan.embed.view(b, n, md.dim).float()])
+            return ret[0] if len(ret) == 1 else ret
         lab = labels.reshape(-1)
         plan.labels.copy_(torch.where(lab == self.ignore_index, torch.full_like(lab, -1), lab))
         plan.set_loss_scales(1.0, {})                        # mean over the valid labels: the count lives on the device (see _bwd_scale)
@@ -1110,6 +1141,35 @@ class Transfusion(nn.Module):
                 self._anchor = torch.zeros((), device=dev, requires_grad=True)
             loss = _NativeLoss.apply(self._anchor, self, loss, _NO_ROWS)[0]
         return loss
+
+    def _forward_text_cached(self, text, cache, return_embed, return_kv_cache, return_hiddens):
+        """forward_text against a kv cache (T:2612-2631): the L new tokens of every row run as ONE causal multi-token decode step - token j at cache
+        position n_cached + j and rotary position tokens_seen + j, attending to the cache and to the new tokens up to itself"""
+        from .sampling import Sampler
+        md, dev, stream = self.md, self.device, self._stream()
+        kv_in, seen = cache
+        b, L = text.shape
+        buf, n_cached = self._kv_native(kv_in, L)
+        assert buf.shape[1] == b, 'kv cache batch does not match the number of rows'
+        if not hasattr(self, '_decode_plans') or len(self._decode_plans) > 8:
+            self._decode_plans = {}
+        smp = Sampler(self)
+        plan = smp._decode_plan(('fwd_text', L, buf.data_ptr()), b, L, buf, False)
+        ar = np.arange(L, dtype=np.int32)
+        ids = text.masked_fill(text == -1, 0).reshape(-1).to(torch.int32).cpu().numpy()      # T:2608
+        pos = (np.arange(b, dtype=np.int32)[:, None] * buf.shape[2] + n_cached + ar[None, :]).reshape(-1)
+        kve = np.tile(n_cached + 1 + ar, b)
+        rot = np.tile(int(seen) + ar, b)
+        smp._load(plan, ids=ids, pos=pos, kve=kve, rot=rot, tok_inst=np.full(b * L, -1, np.int32))
+        Plan.run(plan.fwd, stream, 0, plan.fwd_embed_end if return_embed else plan.fwd_logits_end)
+        out = plan.embed.view(b, L, md.dim).float() if return_embed else plan.logits.view(b, L, md.vp)[..., :md.vocab].clone()
+        buf._tfx_filled = n_cached + L
+        ret = (out,)
+        if return_kv_cache:
+            ret = (*ret, (self._kv_public(buf, n_cached + L), int(seen) + L))
+        if return_hiddens:
+            ret = (*ret, [plan.hid[i].view(b, L, md.dim).float() for i in range(md.depth + 1)] + [plan.embed.view(b, L, md.dim).float()])
+        return ret[0] if len(ret) == 1 else ret
 
     # ------------------------------------------------------------------ pure flow path (T:2710-2869)
     def forward_modality(self, modalities, times=None, modality_type=None, encode_modality=True, velocity_consistency_ema_model=None,
@@ -1381,17 +1441,20 @@ class Transfusion(nn.Module):
         was_training = self.training
         self.eval()                                              # @temp_eval in the reference
         try:
+            if self._ext:
+                # `pre_post_transformer_enc_dec` types: a conv / U-Net encoder may change the token count (stride 2 in the reference's examples), which
+                # only the reference's UN-CACHED `sample_one` supports (its cached paths slice `modality_length` latent tokens, T:2004 / T:2441) -
+                # so these models decode prompt by prompt through that loop, written against forward() (one full forward per token / ODE evaluation,
+                # lengths bucketed to 64).  Text and past modalities see the [som] tokens and t = 1 re-encodings exactly as there.
+                plist = prompts if isinstance(prompts, list) else [prompts]
+                outs = [self._sample_one_through_forward(pr, max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p, cache_kv=False,
+                                                         fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
+                                                         init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale)
+                        for pr in plist]
+                return outs if return_unprocessed_modalities else self.decode_modalities(outs)
             special = any(self.channel_first_latent) or any(e is not None for e in self.modality_encoder) or any(d is not None for d in self.modality_decoder)
             if special and prompts is not None:
-                # prompted modalities: frozen encoder first (prepare_prompt_sample, T:1755-1758), then the kernels' channel-last layout
-                norm = []
-                for pr in (prompts if isinstance(prompts, list) else [prompts]):
-                    parts = [pr] if (isinstance(pr, tuple) or torch.is_tensor(pr)) else (list(pr) if pr is not None else None)
-                    if parts is not None:
-                        parts = self._to_channel_last(self._encode_modalities([parts]))[0]
-                        parts = parts[0] if (isinstance(pr, tuple) or torch.is_tensor(pr)) else parts
-                    norm.append(parts)
-                prompts = norm
+                prompts = [self._normalize_prompt(pr) for pr in (prompts if isinstance(prompts, list) else [prompts])]
             out = Sampler(self).sample_many(prompts, max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
                                             fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
                                             init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale,
@@ -1403,6 +1466,22 @@ class Transfusion(nn.Module):
             return out
         finally:
             self.train(was_training)
+
+    def _normalize_prompt(self, pr):
+        """a prompt's modalities through their frozen encoder (prepare_prompt_sample, T:1755-1758) and into the decoder's channel-last layout
+        (EVERY channel-first type, also those whose encoder is a user module)"""
+        if pr is None:
+            return None
+        single = isinstance(pr, tuple) or torch.is_tensor(pr)
+        parts = self._encode_modalities([[pr] if single else list(pr)])[0]
+        out = []
+        for part in parts:
+            if torch.is_tensor(part) and part.is_floating_point():
+                part = (0, part)
+            if isinstance(part, tuple) and self.channel_first_latent[part[0]]:
+                part = (part[0], part[1].movedim(0, -1))
+            out.append(part)
+        return out[0] if single else out
 
     @torch.no_grad()
     def sample_one(self, prompt=None, max_length=2048, text_temperature=1., text_min_p=0.1, cache_kv=False, fixed_modality_shape=None,
@@ -1429,8 +1508,9 @@ class Transfusion(nn.Module):
         try:
             smp = Sampler(self)
             dev, stream = self.device, self._stream()
-            parts, forced_id, forced_shape = smp._prepare(prompt, force_modality_at_start)
-            sample = [(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in parts]
+            parts, forced_id, forced_shape = smp._prepare(self._normalize_prompt(prompt), force_modality_at_start)
+            # forward() takes the public layout: channel-first types as (dim_latent, *axial)
+            sample = [((p[0], self._from_channel_last(p[0], p[1])) if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in parts]
             curr_length = 0                                                            # counts DECODED tokens only (T:1878)
             num_past = sum(isinstance(p, tuple) for p in sample)
             cache = None
@@ -1441,8 +1521,9 @@ class Transfusion(nn.Module):
                 if decoding_text:
                     # (the reference leaves `times` to the random default here, T:1917-1924; prompted / decoded modalities are conditioned at 1
                     # everywhere else in its samplers - T:1996, T:2192 - and so here)
-                    logits, new_cache = self.forward([sample], return_loss=False, cache=cache, decode_length=1, decoding_text_or_modality='text',
-                                                     return_kv_cache=True, times=torch.ones(1, max(num_past, 1), device=dev))
+                    logits = self.forward([sample], return_loss=False, cache=cache, decode_length=1, decoding_text_or_modality='text',
+                                          return_kv_cache=cache_kv, times=torch.ones(1, max(num_past, 1), device=dev))
+                    logits, new_cache = logits if cache_kv else (logits, None)
                     tok = int(_sample_text_token(logits[0, -1:].float().contiguous(), self.md.vocab, text_temperature, text_min_p, stream)[0])
                     sample[-1] = torch.cat((sample[-1], torch.tensor([tok], device=dev)))
                     st.curr_seq = sample[-1].tolist()
@@ -1456,6 +1537,7 @@ class Transfusion(nn.Module):
                 ty, shape = st.curr_modality_id, st.modality_shape
                 L, dl = st.modality_length, self.md.dim_latents[ty]
                 y = (init_modality_noise[:L, :dl].to(dev, torch.float32) if init_modality_noise is not None else torch.randn(L, dl, device=dev)).reshape(*shape, dl)
+                y = self._from_channel_last(ty, y).contiguous()                       # T:1963-1964
                 use_cfg = cfg_scale != 1.
                 uncond_hist = [torch.full_like(p, self.null_text_id) if not isinstance(p, tuple) else p for p in sample]
                 uncond_cache = None
@@ -1466,9 +1548,13 @@ class Transfusion(nn.Module):
 
                 def flow(t, yy, hist, kv):
                     tt = torch.ones(1, num_past + 1, device=dev); tt[0, -1] = t          # past modalities are conditioned at time 1 (T:1996)
-                    (emb, fns), kv_out = self.forward([[*hist, (ty, yy)]], times=tt, return_embed=True, cache=kv, decode_length=L, return_kv_cache=True,
-                                                      decoding_text_or_modality='modality')
-                    return self.model_to_latent(ty, fns[ty][-1](emb, need_splice=kv is None)), kv_out
+                    res = self.forward([[*hist, (ty, yy)]], times=tt, return_embed=True, cache=kv, decode_length=L, return_kv_cache=cache_kv,
+                                       decoding_text_or_modality='modality')
+                    (emb, fns), kv_out = res if cache_kv else (res, None)
+                    fl = self.model_to_latent(ty, fns[ty][-1](emb, need_splice=kv is None))
+                    if ty not in self._ext:                                           # the native projection returns (*axial, dim_latent)
+                        fl = self._from_channel_last(ty, fl)
+                    return fl.contiguous(), kv_out
 
                 def velocity(t, yy):
                     nonlocal new_cache
