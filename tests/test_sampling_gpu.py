@@ -171,10 +171,11 @@ def test_small_heads_cached_decode_is_consistent_with_the_full_forward():
             assert logits[b, i, seq[b, i + 1]].item() >= logits[b, i].max().item() - 0.05, (b, i)
 
 
-def test_incremental_null_text_cache_equals_full_reprefill(monkeypatch):
+def test_schedules_and_null_text_cache_forms_agree(monkeypatch):
     """classifier-free guidance needs the KV cache of the null-text history before every modality.  The reference re-runs the whole history
-    (T:2386-2406); the native sampler appends only what each sample added since its last modality (Sampler._uncond_append) - same keys / values up
-    to the kernels' accumulation order.  A model whose [som] logit is boosted opens many modalities: both forms must produce the same samples."""
+    (T:2386-2406); the phased native loop appends only what each sample added since its last modality (Sampler._uncond_append); the continuous
+    loop (default) keeps the null-text half in lock-step inside its mixed forwards - same keys / values up to the kernels' accumulation order.
+    A model whose [som] logit is boosted opens many modalities at different times in different samples: the three must produce the same samples."""
     from transfusion_pytorch_amd import Transfusion
     torch.manual_seed(0)
     m = Transfusion(num_text_tokens=16, dim_latent=(8, 16), modality_default_shape=((4,), (3, 3)), transformer=dict(dim=128, depth=2, dim_head=16, heads=4)).cuda().eval()
@@ -183,24 +184,31 @@ def test_incremental_null_text_cache_equals_full_reprefill(monkeypatch):
         m.store.mark_dirty()
     prompts = [[torch.randint(0, 16, (5,)).cuda()], [torch.randint(0, 16, (2,)).cuda(), (1, torch.randn(3, 3, 16).cuda())], None, [torch.randint(0, 16, (9,)).cuda()]]
     kw = dict(max_length=48, text_temperature=0., init_modality_noise=torch.randn(16, 16).cuda(), modality_steps=3, cfg_scale=3., force_modality_at_start=0)
+    monkeypatch.setenv('TFX_SAMPLE_SCHEDULE', 'phased')
     monkeypatch.setenv('TFX_UNCOND_INCREMENTAL', '0')
     full = m.sample_many(prompts, **kw)
     monkeypatch.setenv('TFX_UNCOND_INCREMENTAL', '1')
     inc = m.sample_many(prompts, **kw)
+    monkeypatch.setenv('TFX_SAMPLE_SCHEDULE', 'continuous')
+    cont = m.sample_many(prompts, **kw)
+    cont_nocfg = m.sample_many(prompts, **{**kw, 'cfg_scale': 1.})
+    monkeypatch.setenv('TFX_SAMPLE_SCHEDULE', 'phased')
+    phased_nocfg = m.sample_many(prompts, **{**kw, 'cfg_scale': 1.})
     n_mod = [sum(isinstance(p, tuple) for p in s) for s in full]
     print('modalities per sample:', n_mod)
-    assert max(n_mod) >= 3, 'the test needs samples that pass through several modality phases'
-    worst = 0.
-    for a, b in zip(full, inc):
-        assert [isinstance(p, tuple) for p in a] == [isinstance(p, tuple) for p in b]
-        for pa, pb in zip(a, b):
-            if isinstance(pa, tuple):
-                assert pa[0] == pb[0] and pa[1].shape == pb[1].shape
-                worst = max(worst, float((pa[1] - pb[1]).norm() / (pa[1].norm() + 1e-20)))
-            else:
-                assert torch.equal(pa, pb)
-    print(f'decoded modalities, incremental vs full re-prefill: worst relative distance {worst:.2e}')
-    assert worst <= 2e-2
+    assert max(n_mod) >= 3 and len(set(n_mod)) > 1, 'the test needs samples that pass through several modality phases, out of step with each other'
+    for what, ref, other in (('incremental vs full re-prefill', full, inc), ('continuous vs phased', full, cont), ('continuous vs phased, no guidance', phased_nocfg, cont_nocfg)):
+        worst = 0.
+        for a, b in zip(ref, other):
+            assert [isinstance(p, tuple) for p in a] == [isinstance(p, tuple) for p in b], what
+            for pa, pb in zip(a, b):
+                if isinstance(pa, tuple):
+                    assert pa[0] == pb[0] and pa[1].shape == pb[1].shape
+                    worst = max(worst, float((pa[1] - pb[1]).norm() / (pa[1].norm() + 1e-20)))
+                else:
+                    assert torch.equal(pa, pb), what
+        print(f'decoded modalities, {what}: worst relative distance {worst:.2e}')
+        assert worst <= 2e-2
 
 
 def test_sample_many_at_the_config5_model_size_matches_reference_golden():

@@ -1,22 +1,25 @@
-"""host profile of sample_many (config 5, forced modality at start): where the wall time goes.   python tools/prof_sample.py [dim depth]"""
-import cProfile, os, pstats, sys, time
+"""one `sample_many` run of SURVEY 8(d) config 5 (forced modality at the start) for a rocprofv3 kernel trace of the decode loop.
+    (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/ps -o p -- python $R/tools/prof_sample.py [max_length])
+    python tools/prof_summary.py /tmp/ps/p_kernel_trace.csv --steps <global steps printed by TFX_SAMPLE_TIMING=1>"""
+import os
+import sys
+import time
+
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-from transfusion_pytorch_amd import Transfusion
-dim, depth = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 24)
+from bench import sample_prompts                      # noqa: E402
+from transfusion_pytorch_amd import Transfusion      # noqa: E402
+
+max_len = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
-m = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=dim, depth=depth)).to(dev).eval()
+m = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=1024, depth=24)).to(dev).eval()
 g = torch.Generator(device=dev).manual_seed(1234)
-prompts = bench.sample_prompts(16, dev, g)
+prompts = sample_prompts(16, dev, g)
 noise = torch.randn(16, 384, device=dev, generator=g)
-kw = dict(max_length=256, modality_steps=16, cfg_scale=3., text_temperature=0., init_modality_noise=noise, fixed_modality_shape=(4,))
-if os.environ.get("FORCE", "0") == "1": kw["force_modality_at_start"] = 0
-m.sample_many(prompts, **{**kw, 'max_length': 24})
+kw = dict(max_length=max_len, modality_steps=16, cfg_scale=3., text_temperature=0., init_modality_noise=noise, fixed_modality_shape=(4,), force_modality_at_start=0)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+m.sample_many(prompts, **kw)
 torch.cuda.synchronize()
-pr = cProfile.Profile(); pr.enable(); t0 = time.perf_counter()
-res = m.sample_many(prompts, **kw)
-torch.cuda.synchronize(); dt = time.perf_counter() - t0; pr.disable()
-print(f'{dt:.3f} s')
-pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+print(f'sample_many(max_length={max_len}): {time.perf_counter() - t0:.3f} s', file=sys.stderr)

@@ -1233,18 +1233,19 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int grid_sd = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   // decode steps (samples x 1 ... x modality length rows): K split across the waves - as long as the 64 x 64 tiles fit the chip in one round
   // (128 KiB of LDS = one block per CU; 344 tiles at M = 256, N = 5504 measured 19.9 us against 13.7 for the 64 x 128 kernel below)
-  if (dma && p.M <= 512 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) {
+  // (M up to 1024: the mixed forwards of the continuous decode schedule run samples x (modality length + 1) rows - 640 at SURVEY 8(d) config 5)
+  if (dma && p.M <= 1024 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) {
     static bool attr_sd = false;
     const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
     if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }
     hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI>, dim3(grid_sd), dim3(256), smem_sd, s, p);
     return (int)hipGetLastError();
   }
-  if (dma && p.M <= 512) {                              // few row blocks: latency-bound, deep DMA ring (see gemm_nt_skinny_kernel)
+  const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
+  if (dma && (p.M <= 512 || (p.M <= 1024 && grid_sk <= 512))) {   // few row blocks: latency-bound, deep DMA ring (see gemm_nt_skinny_kernel)
     static bool attr_sk = false;
     const int smem_sk = SK_ST * SK_STAGE * 2;
     if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk); attr_sk = true; }
-    const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
     hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(grid_sk), dim3(256), smem_sk, s, p);
     return (int)hipGetLastError();
   }

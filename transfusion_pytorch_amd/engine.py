@@ -295,12 +295,14 @@ class Plan:
                 self._nt(L, A=lt['add'], lda=d, B=S['eye'], ldb=d, M=r, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.hid[0], ldc=d,
                          R=self.hid[0], ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
         self._k(L, 'tfx_embed_fwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, table=S['embed'], x=self.hid[0])
+        self.fwd_cond = (len(L), len(L))      # [begin, end) of the time-conditioning launches: inst_time -> per-instance AdaLN tables
         if I > 0:
             self._k(L, 'tfx_fourier', 'tfx_fourier_args', I=I, half=d // 2, times=self.inst_time, w=ps.fourier_w, out=self.fe, ld=md.kf)
             self._nt(L, algo_k=d + 1, A=self.fe, lda=md.kf, B=S['time'], ldb=md.kf, M=I, N=4 * d, K=md.kf, epi=E['TFX_EPI_SILU'], C=self.cond, ldc=4 * d,
                      C2=self.pre, ldc2=4 * d, bias=pp('transformer.to_time_cond.1.bias'))
             self._nt(L, A=self.cond, lda=4 * d, B=S['ada'], ldb=4 * d, M=I, N=nt3, K=4 * d, epi=E['TFX_EPI_F32'], C=self.tables, ldc=nt3,
                      bias=pp('transformer.layers.0.1.to_film.bias'))
+            self.fwd_cond = (self.fwd_cond[0], len(L))
         src = skip_sources(md)
         fused_pre = {}                        # decode plans: layer -> its attention-side AdaLN-pre args when the previous layer's end launch runs them
         for i in range(D):

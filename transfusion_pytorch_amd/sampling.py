@@ -46,6 +46,10 @@ class _State:                                   # _SamplingState, T:1270-1287 (t
     modality_length: int | None = None
     num_tokens: int = 0
     forced: tuple = (None, None)
+    unfed: bool = False                         # the last token of curr_seq was sampled but has not gone through the model yet
+    ode_k: int = 0                              # continuous schedule: index of the next ODE evaluation of the modality being decoded
+    som_pending: bool = False                   # continuous schedule: the null-text cache still lacks the [som] that opened the current modality
+    commit_pending: bool = False                # continuous schedule: the null-text cache still lacks the modality just decoded (at t = 1)
 
 
 def _sample_text_token(logits, V, temperature, min_p, stream):
@@ -170,12 +174,12 @@ class Sampler:
         cache[:, :, :n, :hd].copy_(plan.qkr.view(D, B, n, 2 * hd)[..., hd:])
         cache[:, :, :n, hd:].copy_(plan.qkvg.view(D, B, n, ldq)[..., 2 * hd:3 * hd])
 
-    def _decode_plan(self, key, B, Lq, cache, with_latents):
+    def _decode_plan(self, key, B, Lq, cache, with_latents, n_inst=None):
         plans = self.m._decode_plans
         if key not in plans:
             R = {t: B * Lq for t in range(self.m.num_modalities)} if with_latents else {}
             self.m.store.refresh_shadows(self.m._stream())
-            p = Plan(self.m.store, B, Lq, B if with_latents else 0, R, training=False, cache=cache)
+            p = Plan(self.m.store, B, Lq, (n_inst or B) if with_latents else 0, R, training=False, cache=cache)
             p.q_start.zero_()
             plans[key] = p
         return plans[key]
@@ -229,7 +233,7 @@ class Sampler:
         first = _sample_text_token(plan.logits.index_select(0, last_rows), md.vocab, text_temperature, text_min_p, stream).tolist()
         for st, tok in zip(states, first):
             if st.phase == 'text':
-                st.curr_seq.append(tok); st.last_token = tok; st.num_tokens += 1
+                st.curr_seq.append(tok); st.last_token = tok; st.num_tokens += 1; st.unfed = True
                 if isinstance(st.parts[-1], list) and st.parts[-1] is not st.curr_seq:
                     st.parts[-1] = st.curr_seq
                 if tok == m.eos_id:
@@ -238,6 +242,245 @@ class Sampler:
             if st.num_tokens > max_length:
                 st.phase = 'done'
 
+        # Two schedules over the same per-sample state machine (samples only ever attend to their own cache, so the schedule cannot change
+        # what a sample decodes - the reference's own test asserts sample_many == per-prompt sample_one):
+        #   continuous (default)  every global step advances EVERY live sample - by a text token or by one ODE evaluation - in one mixed forward
+        #   phased                the reference's loop (T:2226-2360): text steps until no sample is in its text phase, then one joint ODE
+        if os.environ.get('TFX_SAMPLE_SCHEDULE', 'continuous') != 'phased':
+            self._loop_continuous(states, joint, maxlen, use_cfg, stream, max_length, text_temperature, text_min_p, fixed_modality_shape,
+                                  init_modality_noise, modality_steps, cfg_scale)
+        else:
+            self._loop_phased(states, joint, use_cfg, stream, max_length, text_temperature, text_min_p, fixed_modality_shape,
+                              init_modality_noise, modality_steps, cfg_scale)
+        m._decode_plans = {}
+        return [[(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in st.parts] for st in states]
+
+    def _pinned(self, name, shape, dtype):
+        """pinned host staging buffers, a ring of 8 per (name, shape): the per-step control arrays go up as asynchronous copies"""
+        ring = self.__dict__.setdefault('_stage2', {})
+        key = (name, tuple(shape), dtype)
+        if key not in ring:
+            ring[key] = [[torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(8)], 0]
+        bufs, k = ring[key]
+        ring[key][1] = (k + 1) % len(bufs)
+        return bufs[k]
+
+    def _loop_continuous(self, states, joint, maxlen, use_cfg, stream, max_length, text_temperature, text_min_p, fixed_modality_shape,
+                         init_modality_noise, modality_steps, cfg_scale):
+        """Continuous batching of the decode loop.  The reference's schedule (and `_loop_phased`) makes the samples that reached a [som] wait until
+        the slowest writer of the round has reached its own, then decodes all waiting modalities in one joint ODE: with B desynchronised samples the
+        text phase runs sum over rounds of max_i(text run) steps.  Here every global step is ONE forward over (1 | 2) B x Lq rows in which each live
+        sample advances by what it needs: a text sample feeds its last token (one row), a sample inside a modality runs its next ODE evaluation
+        (L rows at its own step time - the fixed-grid midpoint method as a per-sample state machine on the device), and the null-text half of
+        classifier-free guidance stays in lock-step - the null id of the same token, the same evaluation against its own cache, and, right
+        after a modality is finished, that block once more at t = 1 (what the reference's re-prefill of the null-text history computes, T:2386-2406).
+        The run takes max_i(tokens_i + evaluations_i) steps instead.  Row roles and cache positions follow `_load_modality` / `_uncond_append`."""
+        m, md, dev = self.m, self.md, self.dev
+        B = len(states)
+        H = 2 if use_cfg else 1
+        nb = H * B
+        M, dmax = m.num_modalities, max(md.dim_latents)
+        ts = torch.linspace(0, 1, modality_steps)
+        evals = []                                                          # (time, coefficient, sub-step): torchdiffeq fixed-grid midpoint
+        for k in range(modality_steps - 1):
+            t0, dt = float(ts[k]), float(ts[k + 1] - ts[k])
+            evals += [(t0, dt * 0.5, 1), (t0 + dt * 0.5, dt, 2)]
+        # The time conditioning of a decode step - Fourier features -> MLP -> every layer's AdaLN tables, a GEMM that streams ALL the conditioning
+        # weights (1.2 GB at dim 1024 / depth 24: 0.5 ms of a 4 ms step) - depends on the step time alone, and a fixed-grid solver only ever asks
+        # for 2 (S - 1) times plus t = 1 (finished blocks).  The "instances" of the mixed plan are therefore those TIMES: their tables are computed
+        # once per plan, a token's instance index says which row it reads, and the conditioning launches drop out of the per-step replay.
+        cond_times = torch.tensor([e[0] for e in evals] + [1.], dtype=torch.float32, device=dev)
+        n_t = cond_times.numel()
+        tm = {'steps': 0, 'mixed_steps': 0, 'prefill': 0., 'loop': 0., 'host_build': 0., 'host_issue': 0., 'wait': 0., 'host_post': 0.} if os.environ.get('TFX_SAMPLE_TIMING') else None
+        t_a = time.perf_counter()
+        if use_cfg:
+            # null-text twin of the prefill: every token that went through the model so far (the sampled-but-unfed last token excluded)
+            hist = []
+            for st in states:
+                parts = [list(p) if isinstance(p, list) else p for p in st.parts]
+                if st.unfed:
+                    parts[-1] = parts[-1][:-1]
+                hist.append([p for p in parts if isinstance(p, tuple) or len(p)])
+            past = max(max((s.num_past_modalities for s in states), default=0), 1)
+            uplan, US = m._forward_plain(self._as_batch(hist, null_text=True), torch.ones(B, past, device=dev), add_meta=False)
+            if joint.shape[2] < US['n']:
+                joint = self._grow(joint, US['n'])
+            self._fill_cache(joint[:, B:], uplan, B, US['n'])
+            for st in states:
+                st.uncond_len, st.uncond_pos = st.cache_len, st.tokens_seen
+        if tm is not None:
+            torch.cuda.synchronize(); tm['prefill'] = time.perf_counter() - t_a; t_a = time.perf_counter()
+
+        Lc = 0
+        Y = Ym = None
+        multi = M > 1 or md.dim_latents[0] != dmax
+        tmask = torch.zeros(M, B, 1, 1, device=dev) if multi else None      # per type: which samples are decoding a block of that type
+        async_steps = 0
+
+        def begin_modality(i, st):
+            nonlocal Lc, Y, Ym
+            L, dl = st.modality_length, md.dim_latents[st.curr_modality_id]
+            if L > Lc:
+                newY, newYm = torch.zeros(B, L, dmax, device=dev), torch.zeros(B, L, dmax, device=dev)
+                if Y is not None:
+                    newY[:, :Lc], newYm[:, :Lc] = Y, Ym
+                Y, Ym, Lc = newY, newYm, L
+            Y[i, :L, :dl] = init_modality_noise[:L, :dl].to(dev) if init_modality_noise is not None else torch.randn(L, dl, device=dev)
+            st.ode_k, st.som_pending = 0, bool(use_cfg and st.unfed)
+            if multi:
+                tmask[:, i] = 0.; tmask[st.curr_modality_id, i] = 1.
+
+        for i, st in enumerate(states):
+            if st.phase == 'modality':
+                begin_modality(i, st)
+
+        while not all(s.phase == 'done' for s in states):
+            t_0 = time.perf_counter()
+            mixed = any(s.phase == 'modality' or (s.phase == 'text' and s.commit_pending) for s in states)
+            Lq = Lc + 1 if mixed else 1
+            need = max(max(s.cache_len, s.uncond_len) for s in states) + Lq + 2
+            if need > joint.shape[2]:
+                joint = self._grow(joint, need + 192)
+            cap = joint.shape[2]
+            p = self._decode_plan(('mix' if mixed else 'txt', nb, Lq, joint.data_ptr()), nb, Lq, joint, mixed, n_inst=n_t)
+            T = nb * Lq
+            ids = np.zeros(T, np.int32); pos = np.full(T, -1, np.int32); kve = np.ones(T, np.int32); rot = np.zeros(T, np.int32)
+            tok_inst = np.full(T, -1, np.int32)
+            row_tok = np.full((M, T), -1, np.int32) if mixed else None
+            ctl = np.zeros((2, B), np.float32)                              # per sample: ODE mode (1 / 2 = first / second evaluation of a step, 3 = block at t = 1), coefficient
+            pos_rows = []                                                   # (type, first row, shape): blocks that carry their axial positional embedding
+            for i, st in enumerate(states):
+                for h in range(H):
+                    r = h * B + i
+                    base = st.uncond_len if h else st.cache_len
+                    lo, tx = r * Lq, r * Lq + Lq - 1                        # block rows start at lo, the text row is the last one
+                    kve[lo:lo + Lq] = max(base, 1)
+                    if st.phase == 'text':
+                        upos = st.uncond_pos if h else st.tokens_seen
+                        if h and st.commit_pending:                         # the block just decoded, prompt-style: t = 1, one rotary position
+                            L, ty = st.modality_length, st.curr_modality_id
+                            pos[lo:lo + L] = r * cap + base + np.arange(L); kve[lo:lo + L] = base + L; rot[lo:lo + L] = upos
+                            tok_inst[lo:lo + L] = n_t - 1; row_tok[ty, lo:lo + L] = np.arange(lo, lo + L)
+                            ctl[0, i] = 3.
+                            pos_rows.append((ty, lo, st.modality_shape))
+                            base += L; upos += 1
+                        ids[tx] = m.null_text_id if h else st.last_token
+                        pos[tx], kve[tx], rot[tx] = r * cap + base, base + 1, upos
+                    elif st.phase == 'modality':
+                        L, ty = st.modality_length, st.curr_modality_id
+                        t_eval, a, mode = evals[st.ode_k]
+                        if h and st.som_pending:                            # the [som] the real history never feeds (T:2411) is part of the null-text one
+                            ids[tx] = m.null_text_id
+                            pos[tx], kve[tx], rot[tx] = r * cap + base, base + 1, st.uncond_pos
+                            base += 1
+                        pos[lo:lo + L] = r * cap + base + np.arange(L); kve[lo:lo + L] = base + L; rot[lo:lo + L] = st.tokens_seen
+                        tok_inst[lo:lo + L] = st.ode_k; row_tok[ty, lo:lo + L] = np.arange(lo, lo + L)
+                        ctl[0, i], ctl[1, i] = mode, a
+                        if getattr(self, 'pos_emb_in_decode', False):
+                            pos_rows.append((ty, lo, st.modality_shape))
+            t_1 = time.perf_counter()
+            self._load(p, ids, pos, kve, rot, tok_inst)
+            if mixed:
+                if not getattr(p, '_cont_ready', False):
+                    for t in range(M):
+                        p.row_inst[t].zero_()
+                        p.set_noise(t, None)
+                    p.inst_time.copy_(cond_times)
+                    Plan.run(p.fwd, stream, *p.fwd_cond)                      # the AdaLN tables of every time the solver will ask for, once
+                    p._cont_ready = True
+                hrt = self._pinned('row_tok', (2, M, T), torch.int32)
+                hrt[0].copy_(torch.from_numpy(row_tok)); hrt[1].copy_(torch.from_numpy(np.maximum(row_tok, 0)))
+                hct = self._pinned('ctl', (2, B), torch.float32)
+                hct.copy_(torch.from_numpy(ctl))
+                dct = hct.to(dev, non_blocking=True)
+                for t in range(M):
+                    p.row_tok[t].copy_(hrt[0, t], non_blocking=True); p.row_src[t].copy_(hrt[1, t], non_blocking=True)
+                if md.model_output_clean:                                   # the clean-prediction conversion reads a row's time through its instance
+                    for t in range(M):
+                        p.row_inst[t].copy_(p.tok_inst.clamp(min=0))
+                mode = dct[0].view(B, 1, 1)
+                X = torch.where(mode == 2., Ym, Y)
+                for t in range(M):
+                    dl = md.dim_latents[t]
+                    xv = p.lat[t]['x'].view(nb, Lq, dl)
+                    for h in range(H):
+                        xv[h * B:(h + 1) * B, :Lc] = X[:, :, :dl]
+                for t in p.ext_add:
+                    add = p.lat[t]['add']
+                    add.zero_()
+                    for ty, lo, shape in pos_rows:
+                        if ty == t:
+                            add[lo:lo + math.prod(shape)].copy_(m._pos_rows(t, [shape]))
+            if mixed:
+                self._run(p, stream, 0, p.fwd_cond[0])
+                self._run(p, stream, p.fwd_cond[1], p.fwd_pred_end)
+            else:
+                self._run(p, stream, 0, p.fwd_logits_end)
+            if mixed:
+                F = None
+                for t in range(M):
+                    dl = md.dim_latents[t]
+                    pv = p.lat[t]['pred'].view(nb, Lq, dl)[:, :Lc]
+                    g = pv[B:] + cfg_scale * (pv[:B] - pv[B:]) if use_cfg else pv[:B]
+                    if not multi:
+                        F = g
+                    else:
+                        if F is None:
+                            F = torch.zeros(B, Lc, dmax, device=dev)
+                        F[:, :, :dl] += torch.where(tmask[t] > 0., g, torch.zeros_like(g))
+                upd = Y + dct[1].view(B, 1, 1) * F
+                Ym = torch.where(mode == 1., upd, Ym)
+                Y = torch.where(mode == 2., upd, Y)
+            t_2 = time.perf_counter()
+            toks = None
+            if any(s.phase == 'text' for s in states):
+                lg = p.logits.view(nb, Lq, md.vp)[:B, Lq - 1]
+                toks = _sample_text_token(lg, md.vocab, text_temperature, text_min_p, stream).tolist()      # host sync
+                async_steps = 0
+            else:
+                async_steps += 1
+                if async_steps >= 4:                                        # the staging rings are 8 deep: never run further ahead of the device
+                    torch.cuda.current_stream(dev).synchronize(); async_steps = 0
+            t_3 = time.perf_counter()
+            for i, st in enumerate(states):
+                if st.phase == 'text':
+                    tok = toks[i]
+                    if use_cfg:
+                        if st.commit_pending:
+                            st.uncond_len += st.modality_length; st.uncond_pos += 1; st.commit_pending = False
+                        st.uncond_len += 1; st.uncond_pos += 1
+                    st.cache_len += 1
+                    st.curr_seq.append(tok); st.last_token = tok; st.tokens_seen += 1; st.num_tokens += 1; st.unfed = True
+                    if tok == m.eos_id or st.num_tokens > max_length:
+                        st.phase = 'done'; continue
+                    if self._maybe_transition(st, fixed_modality_shape):
+                        begin_modality(i, st)
+                elif st.phase == 'modality':
+                    if st.som_pending:
+                        st.uncond_len += 1; st.uncond_pos += 1; st.som_pending = False
+                    st.ode_k += 1
+                    if st.ode_k < len(evals):
+                        continue
+                    L, ty = st.modality_length, st.curr_modality_id          # commit, T:2531-2556
+                    dl = md.dim_latents[ty]
+                    st.cache_len += L
+                    st.parts.append((ty, Y[i, :L, :dl].reshape(*st.modality_shape, dl).clone()))
+                    st.curr_seq = [m.eom_ids[ty]]; st.parts.append(st.curr_seq); st.last_token = m.eom_ids[ty]; st.unfed = True
+                    st.tokens_seen += 1; st.num_tokens += L; st.num_past_modalities += 1
+                    st.phase = 'done' if st.num_tokens > max_length else 'text'
+                    st.commit_pending = bool(use_cfg and st.phase == 'text')
+            if tm is not None:
+                tm['steps'] += 1; tm['mixed_steps'] += int(mixed)
+                tm['host_build'] += t_1 - t_0; tm['host_issue'] += t_2 - t_1; tm['wait'] += t_3 - t_2; tm['host_post'] += time.perf_counter() - t_3
+        if tm is not None:
+            torch.cuda.synchronize(); tm['loop'] = time.perf_counter() - t_a
+            print('[TFX_SAMPLE_TIMING]', {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()})
+
+    def _loop_phased(self, states, joint, use_cfg, stream, max_length, text_temperature, text_min_p, fixed_modality_shape,
+                     init_modality_noise, modality_steps, cfg_scale):
+        m, md, dev = self.m, self.md, self.dev
+        B = len(states)
+        cache = joint[:, :B]
         tm = {'text': 0., 'text_steps': 0, 'uncond_prefill': 0., 'ode': 0., 'phases': 0} if os.environ.get('TFX_SAMPLE_TIMING') else None
         def mark():
             if tm is None:
@@ -331,10 +574,8 @@ class Sampler:
                 st.curr_seq = [m.eom_ids[ty]]; st.parts.append(st.curr_seq); st.last_token = m.eom_ids[ty]
                 st.tokens_seen += 1; st.num_tokens += L; st.num_past_modalities += 1
                 st.phase = 'done' if st.num_tokens > max_length else 'text'
-        m._decode_plans = {}
         if tm is not None:
             print('[TFX_SAMPLE_TIMING]', {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()})
-        return [[(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in st.parts] for st in states]
 
     # ------------------------------------------------------------------ helpers
     # ------------------------------------------------------------------ pure-text generation (T:2666-2707)
