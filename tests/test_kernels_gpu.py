@@ -42,7 +42,8 @@ def gemm_nt(**kw):
 # ---------------------------------------------------------------------------------------------- GEMM NT
 # (33000, 1032, 128) and (65536, 512, 192): >= 512 tiles of 256x256 -> the ping-pong kernel (ragged M and N tiles in the first)
 @pytest.mark.parametrize('M,N,K', [(300, 200, 128), (128, 128, 64), (1000, 1544, 512), (4096, 512, 1408), (77, 390, 192), (33000, 1032, 128), (65536, 512, 192),
-                                   (64, 1544, 512), (1, 512, 64), (37, 2816, 1408), (512, 520, 1024), (256, 128, 768)])   # M <= 512: the skinny deep-ring kernel
+                                   (64, 1544, 512), (1, 512, 64), (37, 2816, 1408), (512, 520, 1024), (256, 128, 768),    # M <= 512: the skinny deep-ring kernel
+                                   (640, 5504, 1024), (2000, 388, 512), (640, 1024, 2752), (640, 1544, 1024), (3000, 1024, 256)])   # <= 256 tiles of 128 x 128: the 4-slot mid kernel; 640 rows: split-K decode kernel up to 1024 rows
 def test_gemm_nt_bf16_bias(M, N, K):
     torch.manual_seed(0)
     A, B = rnd(M, K), rnd(N, K, scale=K ** -0.5)
@@ -67,7 +68,7 @@ def test_gemm_nt_asymmetric_identity():
     assert torch.equal(C, B.float().T)
 
 
-@pytest.mark.parametrize('M', [333, 66000])            # 66000 rows x 512 columns: 516 tiles of 256x256 -> ping-pong kernel (split-A, RESID)
+@pytest.mark.parametrize('M', [333, 1500, 66000])      # 66000 rows x 512 columns: 516 tiles of 256x256 -> ping-pong kernel (split-A, RESID); 1500: the mid kernel
 def test_gemm_nt_split_a_rowmaps_resid(M):
     torch.manual_seed(1)
     N, K1, K2 = (256 if M < 1000 else 512), 128, 192
@@ -117,10 +118,10 @@ def geglu_perm(dip):
     return is_gate, feat
 
 
-@pytest.mark.parametrize('M', [300, 130, 70000])       # 70000 rows: the ping-pong 256x256 kernel and its staged epilogues; 130: the split-K decode kernel (K >= 256)
+@pytest.mark.parametrize('M', [300, 130, 640, 70000])  # 70000 rows: the ping-pong 256x256 kernel and its staged epilogues; 130: the split-K decode kernel (K >= 256); 640: the mid kernel
 def test_gemm_nt_geglu_fwd_bwd(M):
     torch.manual_seed(3)
-    d, dip = (512 if M == 130 else 128), 192 if M < 1000 else 1024
+    d, dip = (512 if M in (130, 640) else 128), (192 if M < 600 else 2752 if M == 640 else 1024)
     u = rnd(M, d)
     Wa, Wg = rnd(dip, d, scale=d ** -0.5), rnd(dip, d, scale=d ** -0.5)
     ba, bg = torch.randn(dip, device=DEV), torch.randn(dip, device=DEV)
@@ -137,7 +138,7 @@ def test_gemm_nt_geglu_fwd_bwd(M):
     check('geglu pre-activation (interleaved)', ag, ag_ref, 6e-3)
     check('geglu hidden', hm, a * F.gelu(g), 8e-3)
     # backward epilogue: dh = dy @ W2t^T (here: plain GEMM against random B), d[a|g] from saved ag
-    K2 = 320 if M == 130 else 128
+    K2 = 320 if M in (130, 640) else 128
     dy, W2t = rnd(M, K2), rnd(dip, K2, scale=K2 ** -0.5)
     dag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF)
     gemm_nt(A=dy, lda=K2, B=W2t, ldb=K2, M=M, N=dip, K=K2, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip,

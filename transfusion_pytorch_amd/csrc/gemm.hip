@@ -719,6 +719,95 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Mid-size NT: at most ONE 128 x 128 tile per CU (mixed decode steps at samples x (modality length + 1) rows, prefills, latent projections,
+// conditioning MLPs).  The 2-stage kernel above is then alone on its CU and every K-tile waits out a full memory round trip (1.4 us per tile
+// measured at M = 640, N = 5504, K = 1024 - 15 % of the MFMA rate).  Same tile, fragments, accumulation order and epilogue, but a 4-slot ring of
+// 32 KiB stages (three K-tiles of LDS-DMA in flight, counted vmcnt: 8 instructions per wave and tile), one block per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int MD_ST = 4;
+constexpr int MD_STAGE = (BM + BN) * BK;                // elements per ring slot: A [128][64] then B [128][64]
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_mid_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* ring = (bf16*)smem_raw;
+
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+  const int nk = p.K / BK;
+
+  const bf16 *ga[4], *ga2[4], *gb[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int row = w * 32 + j * 8 + (l >> 3);
+    const int c = (l & 7) ^ ((row >> 1) & 7);
+    int rm = min(m0 + row, p.M - 1);
+    if (p.a_rowmap) rm = p.a_rowmap[rm];
+    const int rn = min(n0 + row, p.N - 1);
+    ga[j] = p.A + (size_t)rm * p.lda + c * 8;
+    ga2[j] = p.A2 ? p.A2 + (size_t)rm * p.lda2 + c * 8 : nullptr;
+    gb[j] = p.B + (size_t)rn * p.ldb + c * 8;
+  }
+  auto issue = [&](int kt) {                               // 8 DMA instructions per wave and K-tile
+    const int k0 = kt * BK;
+    bf16* slot = ring + (kt % MD_ST) * MD_STAGE;
+    const bool second = p.A2 && k0 >= p.K1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) glds16_asm(second ? ga2[j] + (k0 - p.K1) : ga[j] + k0, slot + (w * 32 + j * 8) * BK);
+#pragma unroll
+    for (int j = 0; j < 4; j++) glds16_asm(gb[j] + k0, slot + BM * BK + (w * 32 + j * 8) * BK);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  for (int kt = 0; kt < min(MD_ST - 1, nk); kt++) issue(kt);
+  const int arow0 = wm * 64 + (l & 31), brow0 = wn * 64 + (l & 31);
+  auto ldfrag = [&](const bf16* base, int r, int ks) { return *(const bf16x8*)(base + r * BK + (((ks * 2 + hi) ^ ((r >> 1) & 7)) << 3)); };
+  for (int kt = 0; kt < nk; kt++) {
+    const int ahead = min(MD_ST - 2, nk - 1 - kt);           // K-tiles after kt that may still be in flight (in-order counter)
+    switch (ahead) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();                            // tile kt has landed for everyone, and everyone finished reading slot (kt - 1) % MD_ST
+    if (kt + MD_ST - 1 < nk) issue(kt + MD_ST - 1);          // refill the slot read in the previous iteration
+    const bf16* as = ring + (kt % MD_ST) * MD_STAGE;
+    const bf16* bs = as + BM * BK;
+    bf16x8 af[2][2], bfr[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { af[0][i] = ldfrag(as, arow0 + i * 32, 0); bfr[0][i] = ldfrag(bs, brow0 + i * 32, 0); }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const int c = ks & 1;
+      if (ks + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) { af[c ^ 1][i] = ldfrag(as, arow0 + i * 32, ks + 1); bfr[c ^ 1][i] = ldfrag(bs, brow0 + i * 32, ks + 1); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[c][j], af[c][i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  __builtin_amdgcn_s_barrier();                                  // the ring becomes staging space: 16 KiB per wave
+  nt_epilogue<EPI, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, ring + w * 8192);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny NT (decode steps, time-conditioning MLPs: M <= 512 rows).  With a handful of 64-row blocks the 2-stage kernel
 // above is pure latency: every K-tile waits one full memory round trip (12.9 us for M = 64, K = 512).  Here a block owns a
 // 64 x 128 tile and keeps SK_ST - 1 K-tiles of LDS-DMA in flight (a 6-slot ring of 24 KiB stages = the whole K = 512 panel
@@ -1242,7 +1331,7 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
     return (int)hipGetLastError();
   }
   const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
-  if (dma && (p.M <= 512 || (p.M <= 1024 && grid_sk <= 512))) {   // few row blocks: latency-bound, deep DMA ring (see gemm_nt_skinny_kernel)
+  if (dma && (p.M <= 512 || (p.M <= 1024 && grid_sk <= 256))) {   // few row blocks: latency-bound, deep DMA ring (see gemm_nt_skinny_kernel)
     static bool attr_sk = false;
     const int smem_sk = SK_ST * SK_STAGE * 2;
     if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk); attr_sk = true; }
@@ -1258,6 +1347,15 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
     static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
     if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 18000; }
     hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p, stagger);
+    return (int)hipGetLastError();
+  }
+  static int mid = -1;                // TFX_NT_MID=0: the 2-stage kernel also when a CU gets at most one tile (A/B)
+  if (mid < 0) { const char* e = getenv("TFX_NT_MID"); mid = e ? atoi(e) : 1; }
+  if (dma && mid && grid <= 256 && p.K >= 4 * BK) {
+    static bool attr_md = false;
+    const int smem_md = MD_ST * MD_STAGE * 2;
+    if (!attr_md) { (void)hipFuncSetAttribute((const void*)gemm_nt_mid_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_md); attr_md = true; }
+    hipLaunchKernelGGL(gemm_nt_mid_kernel<EPI>, dim3(grid), dim3(256), smem_md, s, p);
     return (int)hipGetLastError();
   }
   if (dma) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
