@@ -265,6 +265,16 @@ int tfx_sample_tokens(const float* logits, int32_t ld, int32_t B, int32_t V, flo
 /* ODE state update of the fixed-grid midpoint solver (torchdiffeq semantics; T:2468-2525) fused with classifier-free
  * guidance (T:2516-2521): f = f_uncond ? f_uncond + cfg_scale * (f_cond - f_uncond) : f_cond;  out = y + a * f   (fp32, n elements) */
 int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, float cfg_scale, float a, float* out, int64_t n, void* stream);
+/* The same solver as a per-sample state machine (continuous decode schedule: in one forward every sample is at its OWN evaluation).
+ * y, ym: fp32 [B][Lc][dmax] - the state at the start of a solver step and its midpoint; ctl: fp32 [2][B] = per sample (mode, coefficient a):
+ *   mode 1  first evaluation of a step:  input y,  result ym = y + a f        mode 3  a finished block re-encoded at t = 1: input y, no update
+ *   mode 2  second evaluation:           input ym, result y  = y + a f        mode 0  the sample is not inside a modality
+ * tfx_ode_stage writes the evaluation inputs into the plan's latent rows: x[(h B + i) Lq + j][c] = input_i[j][c] (h < H halves, j < Lc, c < dl; x: [H B Lq][dl]).
+ * tfx_ode_update applies the results: f = pred[i Lq + j] (H == 1) or, with guidance (H == 2, T:2516-2521), pu + cfg_scale (pc - pu) with
+ * pc = pred[i Lq + j], pu = pred[(B + i) Lq + j]; samples with sel[i] == 0 are skipped (sel NULL = all: one call per modality type). */
+int tfx_ode_stage(const float* y, const float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, float* x, int32_t H, int32_t Lq, int32_t dl, void* stream);
+int tfx_ode_update(float* y, float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, const float* pred, int32_t H, int32_t Lq, int32_t dl,
+                   float cfg_scale, const float* sel, void* stream);
 
 /* ---- parameter plumbing ---------------------------------------------------------------------- */
 /* dst[r][c] (bf16, ld_dst, Rd rows, Cd cols) = src[rowmap ? rowmap[r] : r][c] or 0 when out of range / map < 0 */

@@ -165,6 +165,15 @@ class Plan:
         self.text_ids, self.cache_pos, self.kv_end, self.rot_pos, self.tok_inst, self.q_start, self.labels = (self.idx[r, :T] if r != 1 else self.idx[r] for r in range(7))
         self.inst_time = z(I1, dtype=torch.float32)
         self.row_tok = {t: z(r, dtype=torch.int32) for t, r in R.items()}
+        self.rowbuf = None
+        if cache is not None and R and len(set(R.values())) == 1:
+            # decode plans: the per-step row maps of all types (row_tok, then row_src) and a small fp32 control area live in ONE buffer, so a step
+            # uploads them with one copy
+            r = next(iter(R.values()))
+            self.row_stride = rs = (r + 3) // 4 * 4                       # 16-byte aligned rows
+            self.rowbuf = z(2 * len(R) * rs + 2 * b, dtype=torch.int32)
+            self.row_tok = {t: self.rowbuf[k * rs:k * rs + r] for k, t in enumerate(R)}
+            self.ctl = self.rowbuf[2 * len(R) * rs:].view(torch.float32)
         self.row_inst = {t: z(r, dtype=torch.int32) for t, r in R.items()}
         # ---- forward activations
         self.hid = e(D + 1, T, d)
@@ -372,6 +381,9 @@ class Plan:
             # decode plans: flow prediction only (model_to_latent on the modality rows), no losses.  `row_src` = row_tok with
             # the dropped rows (-1) clamped to 0, so the gather never reads out of bounds (those rows are ignored by the caller)
             self.row_src = {t: torch.zeros(r, device=self.ps.device, dtype=torch.int32) for t, r in self.R.items()}
+            if self.rowbuf is not None:
+                r, M, rs = next(iter(self.R.values())), len(self.R), self.row_stride
+                self.row_src = {t: self.rowbuf[(M + k) * rs:(M + k) * rs + r] for k, t in enumerate(self.R)}
             for t, r in self.R.items():
                 if t in self.ext:
                     continue

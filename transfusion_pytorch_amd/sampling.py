@@ -313,9 +313,19 @@ class Sampler:
 
         Lc = 0
         Y = Ym = None
-        multi = M > 1 or md.dim_latents[0] != dmax
-        tmask = torch.zeros(M, B, 1, 1, device=dev) if multi else None      # per type: which samples are decoding a block of that type
+        multi = M > 1
+        sel = torch.zeros(M, B, device=dev) if multi else None              # per type: which samples are decoding a block of that type
+        lib = capi.lib()
+        sp = ctypes.c_void_p(stream)
         async_steps = 0
+        # host mirror of the per-sample state, one column per sample (the step's index arrays are built from it with array operations):
+        PH, CL, UL, TS, UP, LT, LL, TY, OK, SP, CP = range(11)              # phase (0 done / 1 text / 2 modality), cache_len, uncond_len, tokens_seen, uncond_pos,
+        A = np.zeros((11, B), np.int64)                                     # last_token, modality length, type, ode_k, som_pending, commit_pending
+        code = {'done': 0, 'text': 1, 'modality': 2}
+
+        def mirror(i, st):
+            A[:, i] = (code[st.phase], st.cache_len, st.uncond_len, st.tokens_seen, st.uncond_pos, st.last_token if st.last_token is not None else 0,
+                       st.modality_length or 0, st.curr_modality_id or 0, st.ode_k, st.som_pending, st.commit_pending)
 
         def begin_modality(i, st):
             nonlocal Lc, Y, Ym
@@ -328,58 +338,54 @@ class Sampler:
             Y[i, :L, :dl] = init_modality_noise[:L, :dl].to(dev) if init_modality_noise is not None else torch.randn(L, dl, device=dev)
             st.ode_k, st.som_pending = 0, bool(use_cfg and st.unfed)
             if multi:
-                tmask[:, i] = 0.; tmask[st.curr_modality_id, i] = 1.
+                sel[:, i] = 0.; sel[st.curr_modality_id, i] = 1.
 
         for i, st in enumerate(states):
             if st.phase == 'modality':
                 begin_modality(i, st)
+            mirror(i, st)
+        ar_b = np.arange(B, dtype=np.int64)
+        modes = np.array([e[2] for e in evals], np.float32); coefs = np.array([e[1] for e in evals], np.float32)
 
-        while not all(s.phase == 'done' for s in states):
+        while A[PH].any():
             t_0 = time.perf_counter()
-            mixed = any(s.phase == 'modality' or (s.phase == 'text' and s.commit_pending) for s in states)
+            is_t, is_m = A[PH] == 1, A[PH] == 2
+            com = is_t & (A[CP] > 0)
+            mixed = bool(is_m.any() or com.any())
             Lq = Lc + 1 if mixed else 1
-            need = max(max(s.cache_len, s.uncond_len) for s in states) + Lq + 2
+            need = int(max(A[CL].max(), A[UL].max())) + Lq + 2
             if need > joint.shape[2]:
                 joint = self._grow(joint, need + 192)
             cap = joint.shape[2]
             p = self._decode_plan(('mix' if mixed else 'txt', nb, Lq, joint.data_ptr()), nb, Lq, joint, mixed, n_inst=n_t)
             T = nb * Lq
-            ids = np.zeros(T, np.int32); pos = np.full(T, -1, np.int32); kve = np.ones(T, np.int32); rot = np.zeros(T, np.int32)
-            tok_inst = np.full(T, -1, np.int32)
-            row_tok = np.full((M, T), -1, np.int32) if mixed else None
-            ctl = np.zeros((2, B), np.float32)                              # per sample: ODE mode (1 / 2 = first / second evaluation of a step, 3 = block at t = 1), coefficient
-            pos_rows = []                                                   # (type, first row, shape): blocks that carry their axial positional embedding
-            for i, st in enumerate(states):
-                for h in range(H):
-                    r = h * B + i
-                    base = st.uncond_len if h else st.cache_len
-                    lo, tx = r * Lq, r * Lq + Lq - 1                        # block rows start at lo, the text row is the last one
-                    kve[lo:lo + Lq] = max(base, 1)
-                    if st.phase == 'text':
-                        upos = st.uncond_pos if h else st.tokens_seen
-                        if h and st.commit_pending:                         # the block just decoded, prompt-style: t = 1, one rotary position
-                            L, ty = st.modality_length, st.curr_modality_id
-                            pos[lo:lo + L] = r * cap + base + np.arange(L); kve[lo:lo + L] = base + L; rot[lo:lo + L] = upos
-                            tok_inst[lo:lo + L] = n_t - 1; row_tok[ty, lo:lo + L] = np.arange(lo, lo + L)
-                            ctl[0, i] = 3.
-                            pos_rows.append((ty, lo, st.modality_shape))
-                            base += L; upos += 1
-                        ids[tx] = m.null_text_id if h else st.last_token
-                        pos[tx], kve[tx], rot[tx] = r * cap + base, base + 1, upos
-                    elif st.phase == 'modality':
-                        L, ty = st.modality_length, st.curr_modality_id
-                        t_eval, a, mode = evals[st.ode_k]
-                        if h and st.som_pending:                            # the [som] the real history never feeds (T:2411) is part of the null-text one
-                            ids[tx] = m.null_text_id
-                            pos[tx], kve[tx], rot[tx] = r * cap + base, base + 1, st.uncond_pos
-                            base += 1
-                        pos[lo:lo + L] = r * cap + base + np.arange(L); kve[lo:lo + L] = base + L; rot[lo:lo + L] = st.tokens_seen
-                        tok_inst[lo:lo + L] = st.ode_k; row_tok[ty, lo:lo + L] = np.arange(lo, lo + L)
-                        ctl[0, i], ctl[1, i] = mode, a
-                        if getattr(self, 'pos_emb_in_decode', False):
-                            pos_rows.append((ty, lo, st.modality_shape))
+            ids = np.zeros((H, B, Lq), np.int32); pos = np.full((H, B, Lq), -1, np.int64); kve = np.ones((H, B, Lq), np.int64)
+            rot = np.zeros((H, B, Lq), np.int64); tok_inst = np.full((H, B, Lq), -1, np.int64)
+            blk_any = np.zeros((H, B, Lq), bool)
+            jj = np.arange(Lq, dtype=np.int64)[None, :]
+            in_blk = jj < A[LL][:, None]                                    # columns a block of this sample's modality length would take
+            for h in range(H):
+                r = (h * B + ar_b)[:, None]
+                base = (A[UL] if h else A[CL])
+                kve[h] = np.maximum(base, 1)[:, None]
+                txt_first = is_m & (A[SP] > 0) if h else np.zeros(B, bool)  # null-text half: the [som] the real history never feeds (T:2411), ahead of the block
+                blk_first = com if h else np.zeros(B, bool)                 # null-text half: the block just decoded, prompt-style (t = 1), ahead of the next token
+                has_blk = (is_m | blk_first)[:, None] & in_blk
+                boff = (base + txt_first)[:, None]
+                pos[h] = np.where(has_blk, r * cap + boff + jj, -1)
+                kve[h] = np.where(has_blk, boff + A[LL][:, None], kve[h])
+                rot[h] = np.where(has_blk, np.where(is_m, A[TS], A[UP])[:, None], 0)          # an ODE block sits at tokens_seen in BOTH halves; a finished one at its history position
+                tok_inst[h] = np.where(has_blk, np.where(is_m, A[OK], n_t - 1)[:, None], -1)   # instance = index of the conditioning time
+                blk_any[h] = has_blk
+                has_txt = is_t | txt_first
+                tbase = base + np.where(blk_first, A[LL], 0)
+                trot = np.where(is_t, (A[UP] + blk_first) if h else A[TS], A[UP])
+                ids[h, :, -1] = np.where(has_txt, m.null_text_id if h else A[LT], 0)
+                pos[h, :, -1] = np.where(has_txt, r[:, 0] * cap + tbase, pos[h, :, -1])
+                kve[h, :, -1] = np.where(has_txt, tbase + 1, kve[h, :, -1])
+                rot[h, :, -1] = np.where(has_txt, trot, rot[h, :, -1])
             t_1 = time.perf_counter()
-            self._load(p, ids, pos, kve, rot, tok_inst)
+            self._load(p, ids.reshape(-1), pos.reshape(-1), kve.reshape(-1), rot.reshape(-1), tok_inst.reshape(-1))
             if mixed:
                 if not getattr(p, '_cont_ready', False):
                     for t in range(M):
@@ -388,52 +394,48 @@ class Sampler:
                     p.inst_time.copy_(cond_times)
                     Plan.run(p.fwd, stream, *p.fwd_cond)                      # the AdaLN tables of every time the solver will ask for, once
                     p._cont_ready = True
-                hrt = self._pinned('row_tok', (2, M, T), torch.int32)
-                hrt[0].copy_(torch.from_numpy(row_tok)); hrt[1].copy_(torch.from_numpy(np.maximum(row_tok, 0)))
-                hct = self._pinned('ctl', (2, B), torch.float32)
-                hct.copy_(torch.from_numpy(ctl))
-                dct = hct.to(dev, non_blocking=True)
+                # row maps of all types + the solver control block: one staging buffer, one copy
+                hb = self._pinned('rowbuf', (p.rowbuf.numel(),), torch.int32)
+                hv = hb.numpy()
+                rs = p.row_stride
+                rowidx = np.arange(T, dtype=np.int32)
+                flat_blk = blk_any.reshape(-1)
                 for t in range(M):
-                    p.row_tok[t].copy_(hrt[0, t], non_blocking=True); p.row_src[t].copy_(hrt[1, t], non_blocking=True)
+                    mine = flat_blk if M == 1 else (blk_any & (A[TY] == t)[None, :, None]).reshape(-1)
+                    hv[t * rs:t * rs + T] = np.where(mine, rowidx, -1)
+                    hv[(M + t) * rs:(M + t) * rs + T] = np.where(mine, rowidx, 0)
+                ctl = hv[2 * M * rs:].view(np.float32)
+                kk = np.minimum(A[OK], len(evals) - 1)
+                ctl[:B] = np.where(is_m, modes[kk], np.where(com, 3., 0.))
+                ctl[B:2 * B] = np.where(is_m, coefs[kk], 0.)
+                p.rowbuf.copy_(hb, non_blocking=True)
                 if md.model_output_clean:                                   # the clean-prediction conversion reads a row's time through its instance
                     for t in range(M):
                         p.row_inst[t].copy_(p.tok_inst.clamp(min=0))
-                mode = dct[0].view(B, 1, 1)
-                X = torch.where(mode == 2., Ym, Y)
                 for t in range(M):
                     dl = md.dim_latents[t]
-                    xv = p.lat[t]['x'].view(nb, Lq, dl)
-                    for h in range(H):
-                        xv[h * B:(h + 1) * B, :Lc] = X[:, :, :dl]
-                for t in p.ext_add:
+                    capi.check(lib.tfx_ode_stage(Y.data_ptr(), Ym.data_ptr(), p.ctl.data_ptr(), B, Lc, dmax, p.lat[t]['x'].data_ptr(), H, Lq, dl, sp), 'tfx_ode_stage')
+                for t in p.ext_add:                                         # blocks that carry their axial positional embedding (history-style always, T:3173-3176)
                     add = p.lat[t]['add']
                     add.zero_()
-                    for ty, lo, shape in pos_rows:
-                        if ty == t:
-                            add[lo:lo + math.prod(shape)].copy_(m._pos_rows(t, [shape]))
-            if mixed:
+                    for i in np.flatnonzero((is_m & bool(getattr(self, 'pos_emb_in_decode', False))) | com):
+                        if states[i].curr_modality_id != t:
+                            continue
+                        rows = m._pos_rows(t, [states[i].modality_shape])
+                        for h in range(H) if is_m[i] else [1]:
+                            lo = (h * B + i) * Lq
+                            add[lo:lo + rows.shape[0]].copy_(rows)
                 self._run(p, stream, 0, p.fwd_cond[0])
                 self._run(p, stream, p.fwd_cond[1], p.fwd_pred_end)
-            else:
-                self._run(p, stream, 0, p.fwd_logits_end)
-            if mixed:
-                F = None
                 for t in range(M):
                     dl = md.dim_latents[t]
-                    pv = p.lat[t]['pred'].view(nb, Lq, dl)[:, :Lc]
-                    g = pv[B:] + cfg_scale * (pv[:B] - pv[B:]) if use_cfg else pv[:B]
-                    if not multi:
-                        F = g
-                    else:
-                        if F is None:
-                            F = torch.zeros(B, Lc, dmax, device=dev)
-                        F[:, :, :dl] += torch.where(tmask[t] > 0., g, torch.zeros_like(g))
-                upd = Y + dct[1].view(B, 1, 1) * F
-                Ym = torch.where(mode == 1., upd, Ym)
-                Y = torch.where(mode == 2., upd, Y)
+                    capi.check(lib.tfx_ode_update(Y.data_ptr(), Ym.data_ptr(), p.ctl.data_ptr(), B, Lc, dmax, p.lat[t]['pred'].data_ptr(), H, Lq, dl,
+                                                  float(cfg_scale), sel[t].data_ptr() if multi else None, sp), 'tfx_ode_update')
+            else:
+                self._run(p, stream, 0, p.fwd_logits_end)
             t_2 = time.perf_counter()
             toks = None
-            if any(s.phase == 'text' for s in states):
+            if is_t.any():
                 lg = p.logits.view(nb, Lq, md.vp)[:B, Lq - 1]
                 toks = _sample_text_token(lg, md.vocab, text_temperature, text_min_p, stream).tolist()      # host sync
                 async_steps = 0
@@ -442,7 +444,8 @@ class Sampler:
                 if async_steps >= 4:                                        # the staging rings are 8 deep: never run further ahead of the device
                     torch.cuda.current_stream(dev).synchronize(); async_steps = 0
             t_3 = time.perf_counter()
-            for i, st in enumerate(states):
+            for i in np.flatnonzero(A[PH]):
+                st = states[i]
                 if st.phase == 'text':
                     tok = toks[i]
                     if use_cfg:
@@ -452,23 +455,23 @@ class Sampler:
                     st.cache_len += 1
                     st.curr_seq.append(tok); st.last_token = tok; st.tokens_seen += 1; st.num_tokens += 1; st.unfed = True
                     if tok == m.eos_id or st.num_tokens > max_length:
-                        st.phase = 'done'; continue
-                    if self._maybe_transition(st, fixed_modality_shape):
+                        st.phase = 'done'
+                    elif self._maybe_transition(st, fixed_modality_shape):
                         begin_modality(i, st)
-                elif st.phase == 'modality':
+                else:
                     if st.som_pending:
                         st.uncond_len += 1; st.uncond_pos += 1; st.som_pending = False
                     st.ode_k += 1
-                    if st.ode_k < len(evals):
-                        continue
-                    L, ty = st.modality_length, st.curr_modality_id          # commit, T:2531-2556
-                    dl = md.dim_latents[ty]
-                    st.cache_len += L
-                    st.parts.append((ty, Y[i, :L, :dl].reshape(*st.modality_shape, dl).clone()))
-                    st.curr_seq = [m.eom_ids[ty]]; st.parts.append(st.curr_seq); st.last_token = m.eom_ids[ty]; st.unfed = True
-                    st.tokens_seen += 1; st.num_tokens += L; st.num_past_modalities += 1
-                    st.phase = 'done' if st.num_tokens > max_length else 'text'
-                    st.commit_pending = bool(use_cfg and st.phase == 'text')
+                    if st.ode_k == len(evals):                                # commit, T:2531-2556
+                        L, ty = st.modality_length, st.curr_modality_id
+                        dl = md.dim_latents[ty]
+                        st.cache_len += L
+                        st.parts.append((ty, Y[i, :L, :dl].reshape(*st.modality_shape, dl).clone()))
+                        st.curr_seq = [m.eom_ids[ty]]; st.parts.append(st.curr_seq); st.last_token = m.eom_ids[ty]; st.unfed = True
+                        st.tokens_seen += 1; st.num_tokens += L; st.num_past_modalities += 1
+                        st.phase = 'done' if st.num_tokens > max_length else 'text'
+                        st.commit_pending = bool(use_cfg and st.phase == 'text')
+                mirror(i, st)
             if tm is not None:
                 tm['steps'] += 1; tm['mixed_steps'] += int(mixed)
                 tm['host_build'] += t_1 - t_0; tm['host_issue'] += t_2 - t_1; tm['wait'] += t_3 - t_2; tm['host_post'] += time.perf_counter() - t_3
