@@ -139,12 +139,16 @@ class LaunchList(list):
 
 
 class Plan:
-    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None, dp_groups: int = 0):
+    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None, dp_groups: int = 0, tile_attn: bool = False):
         """cache: None, or a KV cache tensor [depth, b, maxlen, 2*heads*64] (k~ | v per token).  With a cache the plan is a
         DECODE step: each layer appends this step's k~ / v rows at `cache_pos` (flat row b*maxlen + position, -1 = skip) and
         attention reads keys / values from the cache (per-token visible length in `kv_end`)."""
         md = ps.md
         self.cache = cache
+        # decode plans: `tile_attn` keeps the tiled forward kernel also for one or two new rows per sample (tfx_decode_attn would pick its
+        # matrix-core-free kernel there) - the continuous decode schedule runs a sample's text token in plans of different row counts, and a token
+        # must come out of the same arithmetic whichever plan carried it (sample_many == per-prompt sample_one, reference tests :785-808)
+        self.tile_attn = tile_attn
         assert cache is None or not training
         self.dp_groups = dp_groups          # > 0: the backward list is cut into that many layer groups for the overlapped gradient all-reduce (optim.GradReducer)
         self.bwd_cuts = []                  # [(list index, first layer of the group, last layer of the group)], in backward order
@@ -339,7 +343,7 @@ class Plan:
                     gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
                     cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck)
             self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
-            self._k(L, 'tfx_attn_fwd' if self.cache is None else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
+            self._k(L, 'tfx_attn_fwd' if (self.cache is None or self.tile_attn) else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
             self._nt(L, algo_k=md.hd, A=self.og[li], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[li], ldc=d)
             a_post = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[li], out=self.xb[li], tok_inst=self.tok_inst,
                                     table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))

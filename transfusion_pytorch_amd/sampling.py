@@ -174,12 +174,12 @@ class Sampler:
         cache[:, :, :n, :hd].copy_(plan.qkr.view(D, B, n, 2 * hd)[..., hd:])
         cache[:, :, :n, hd:].copy_(plan.qkvg.view(D, B, n, ldq)[..., 2 * hd:3 * hd])
 
-    def _decode_plan(self, key, B, Lq, cache, with_latents, n_inst=None):
+    def _decode_plan(self, key, B, Lq, cache, with_latents, n_inst=None, tile_attn=False):
         plans = self.m._decode_plans
         if key not in plans:
             R = {t: B * Lq for t in range(self.m.num_modalities)} if with_latents else {}
             self.m.store.refresh_shadows(self.m._stream())
-            p = Plan(self.m.store, B, Lq, (n_inst or B) if with_latents else 0, R, training=False, cache=cache)
+            p = Plan(self.m.store, B, Lq, (n_inst or B) if with_latents else 0, R, training=False, cache=cache, tile_attn=tile_attn)
             p.q_start.zero_()
             plans[key] = p
         return plans[key]
@@ -357,7 +357,7 @@ class Sampler:
             if need > joint.shape[2]:
                 joint = self._grow(joint, need + 192)
             cap = joint.shape[2]
-            p = self._decode_plan(('mix' if mixed else 'txt', nb, Lq, joint.data_ptr()), nb, Lq, joint, mixed, n_inst=n_t)
+            p = self._decode_plan(('mix' if mixed else 'txt', nb, Lq, joint.data_ptr()), nb, Lq, joint, mixed, n_inst=n_t, tile_attn=True)
             T = nb * Lq
             ids = np.zeros((H, B, Lq), np.int32); pos = np.full((H, B, Lq), -1, np.int64); kve = np.ones((H, B, Lq), np.int64)
             rot = np.zeros((H, B, Lq), np.int64); tok_inst = np.full((H, B, Lq), -1, np.int64)
