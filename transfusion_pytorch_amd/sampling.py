@@ -10,6 +10,9 @@ runs in the HIP kernels through a *decode plan* (engine.Plan with a KV cache):
     against the conditional cache and - classifier-free guidance - the null-text cache: ONE forward over 2 B rows (the two
     caches are halves of one buffer).  The null-text cache is appended between phases (`_uncond_append`), not rebuilt.
 
+Schedule: continuous batching by default (`_loop_continuous`: every global step advances every live sample by a token or by one ODE evaluation
+in one mixed forward); `TFX_SAMPLE_SCHEDULE=phased` keeps the reference's text-rounds / joint-ODE loop (`_loop_phased`).
+
 Cache semantics reproduced exactly: the new [som] token is NOT in the conditional cache when its modality is decoded
 (the modality block takes the rotary position the [som] would have had, T:2411); the K/V committed for a decoded
 modality are those of the LAST conditional ODE evaluation (T:2531-2533); past modalities are conditioned at t = 1.
