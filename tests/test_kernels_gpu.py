@@ -277,8 +277,8 @@ def test_attention_fwd_bwd(b, h, n, qs, ks):
         assert (sim > 0.45).any(), 'this case must reach the exact-tanh branch'
 
 
-@pytest.mark.parametrize('entry', ['tfx_attn_fwd', 'tfx_decode_attn'])     # the forward kernel with cache addressing / the decode entry (<= 2 rows per sample: one block per (row, head))
-@pytest.mark.parametrize('b,h,lq,n_kv', [(3, 2, 1, 300), (2, 4, 4, 200), (5, 1, 6, 64), (2, 8, 16, 1100), (64, 8, 1, 333), (7, 3, 2, 77)])
+@pytest.mark.parametrize('entry', ['tfx_attn_fwd', 'tfx_decode_attn'])     # the forward kernel with cache addressing / the decode entry (<= 2 rows per sample: one block per (sample, head), no matrix cores)
+@pytest.mark.parametrize('b,h,lq,n_kv', [(3, 2, 1, 300), (2, 4, 4, 200), (5, 1, 6, 64), (2, 8, 16, 1100), (64, 8, 1, 333), (7, 3, 2, 77), (128, 8, 5, 330), (3, 2, 8, 100), (2, 2, 3, 9), (2, 2, 7, 40)])
 def test_attention_fwd_against_kv_cache(b, h, lq, n_kv, entry):
     """decode-time call (engine.Plan(cache=...)): `lq` new query rows per sample against keys / values that live in a LONGER per-sample
     cache buffer (`n_kv` > n rows, token-major [b, n_kv, 2 * h * 64] = k~ | v), each query row with its own visible length `kv_end`
@@ -292,6 +292,8 @@ def test_attention_fwd_against_kv_cache(b, h, lq, n_kv, entry):
     gates = rnd(T, 8 + h)
     g = torch.Generator().manual_seed(3)
     kv_end = torch.stack([torch.randint(1, n_kv + 1, (1,), generator=g).expand(lq) for _ in range(b)]).clone()
+    if b > 2:                                                     # rows of one sample with DIFFERENT visible lengths (a text row next to a block, mixed decode steps)
+        kv_end[1] = torch.randint(1, n_kv + 1, (lq,), generator=g)
     kv_end[0] = n_kv                                              # a full cache
     kv_end[-1] = 1                                                # a single visible key
     kv_end = kv_end.to(torch.int32).to(DEV)

@@ -126,6 +126,22 @@ TFX_DEV int wave_min_i(int v) {                  // wave-uniform result, returne
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
   return __builtin_amdgcn_readfirstlane(v);
 }
+// Number of keys a 128-row query tile has to walk.  Training layouts: kv_end is non-decreasing in the query index (prefix-extension mask), the
+// last row of the tile has the largest.  Decode steps against a KV cache: a sample's new rows need not be ordered by visible length (a text row
+// next to a modality block in the mixed steps of the continuous schedule) - take the true maximum over the tile's rows.
+TFX_DEV int tile_kv_limit(const tfx_attn_args& p, size_t tok0, int q0, int n, int kve, bool row_valid) {
+  int lim = p.kv_end[tok0 + min(q0 + 127, n - 1)];
+  if (p.n_kv > 0) {                                              // block-uniform
+    __shared__ int kvl[4];
+    int m = row_valid ? kve : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) kvl[threadIdx.x >> 6] = m;
+    __syncthreads();
+    lim = max(max(kvl[0], kvl[1]), max(kvl[2], kvl[3]));
+  }
+  return __builtin_amdgcn_readfirstlane(lim);
+}
 TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
   bf16x8 o;
 #pragma unroll
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256, TFX_ATTN_FWD_WAVES) void attn_fwd_kernel(tfx_a
   const int qrow = q0 + w * 32 + (l & 31);
   const int qc = min(qrow, n - 1);
   const int kve = p.kv_end[tok0 + qc];
-  const int kv_limit = p.kv_end[tok0 + min(q0 + 127, n - 1)];     // kv_end is non-decreasing in the query index
+  const int kv_limit = tile_kv_limit(p, tok0, q0, n, kve, qrow < n);
   const int nt = (kv_limit + 63) / 64;
 
   bf16x8 qf[4];
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) 
   const int qrow = q0 + w * 32 + (l & 31);
   const int qc = min(qrow, n - 1);
   const int kve = p.kv_end[tok0 + qc];
-  const int kv_limit = p.kv_end[tok0 + min(q0 + 127, n - 1)];     // kv_end is non-decreasing in the query index
+  const int kv_limit = tile_kv_limit(p, tok0, q0, n, kve, qrow < n);
   const int nt = (kv_limit + 63) / 64;
   bf16x8 qf[4];
 #pragma unroll

@@ -106,67 +106,93 @@ __global__ void scale_copy_k(const bf16* src, bf16* dst, long long n, float sc) 
 }
 
 
-// Decode attention (reference score pipeline T:998-1027 against the KV cache T:1005-1016): one BLOCK per (new query row, head), its four waves
-// walk the visible keys 32 at a time.  Lane = (key group g = lane / 8, dim slice sl = lane % 8): per trip a wave takes 8 keys, every lane 8 of the
-// 64 dims of its key (16-byte loads: a key row is 8 lanes x 16 B, contiguous), the partial dots meet with three DPP steps, then soft-cap (exact
-// tanh - a handful of scores per lane), exp2 against the FIXED reference 0 (|cap * log2e * tanh| <= 72: no running maximum needed, as in the
-// training kernel), and the value row joins the per-lane accumulator.  The 32 key groups are summed through LDS; out = o / l * sigmoid(gate).
-__global__ __launch_bounds__(256) void decode_attn_k(tfx_attn_args p) {
-  __shared__ float red[32][8][9];                          // [wave * 8 + key group][dim slice][8 dims + l]
+// Decode attention (reference score pipeline T:998-1027 against the KV cache T:1005-1016): one BLOCK per (sample, head) for up to R = 8 NEW query
+// rows of the sample (instantiated for R = 1, 2: text steps), its four waves walk the visible keys 32 at
+// a time.  Lane = (key group g = lane / 8, dim slice sl = lane % 8): per trip a wave takes 8 keys, every lane 8 of the 64 dims of its key (16-byte
+// loads: a key row is 8 lanes x 16 B, contiguous) - loaded ONCE for all rows - and per row the partial dots meet with three DPP steps, then soft-cap
+// (exact tanh - a handful of scores per lane), exp2 against the FIXED reference 0 (|cap * log2e * tanh| <= 72: no running maximum needed, as in
+// the training kernel), and the value row joins the row's per-lane accumulator.  The 32 key groups are summed through LDS; out = o / l *
+// sigmoid(gate).  A row's arithmetic does not depend on R or on the other rows of its block (keys past its own visible length add exact zeros in
+// the same order), so a token comes out the same whichever plan carried it.
+template <int R>
+__global__ __launch_bounds__(256) void decode_attn_rows_k(tfx_attn_args p) {
+  extern __shared__ float red_raw[];                       // [R][wave * 8 + key group][dim slice][8 dims + l]
+  float (*red)[32][8][9] = (float (*)[32][8][9])red_raw;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = lane >> 3, sl = lane & 7;
-  const int t = blockIdx.x / p.h, h = blockIdx.x % p.h, b = t / p.n;
-  const int kve = min(p.kv_end[t], p.n_kv);
-  float q8[8];
-  {
-    const bf16x8 qv = *(const bf16x8*)(p.q + (size_t)t * p.ld_q + h * 64 + sl * 8);
+  const int b = blockIdx.x / p.h, h = blockIdx.x % p.h;
+  const int t0 = b * p.n;
+  int kve[R], kmax = 1;
+  float q8[R][8], o8[R][8], l[R];
 #pragma unroll
-    for (int e = 0; e < 8; e++) q8[e] = bf2f(qv[e]);
+  for (int r = 0; r < R; r++) {
+    kve[r] = r < p.n ? min(p.kv_end[t0 + r], p.n_kv) : 0;
+    kmax = max(kmax, kve[r]);
+    bf16x8 qv;
+    if (r < p.n) qv = *(const bf16x8*)(p.q + (size_t)(t0 + r) * p.ld_q + h * 64 + sl * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { q8[r][e] = r < p.n ? bf2f(qv[e]) : 0.f; o8[r][e] = 0.f; }
+    l[r] = 0.f;
   }
   const bf16* kb = p.k + (size_t)b * p.n_kv * p.ld_k + h * 64 + sl * 8;
   const bf16* vb = p.v + (size_t)b * p.n_kv * p.ld_v + h * 64 + sl * 8;
   const float icap = 1.f / p.softcap, cap2 = p.softcap * 1.4426950408889634f;
-  float l = 0.f, o8[8];
-#pragma unroll
-  for (int e = 0; e < 8; e++) o8[e] = 0.f;
-#pragma unroll 4
-  for (int j0 = wv * 8; j0 < kve; j0 += 32) {
+#pragma unroll 2
+  for (int j0 = wv * 8; j0 < kmax; j0 += 32) {
     const int j = j0 + g;
-    const int jc = min(j, kve - 1);
+    const int jc = min(j, kmax - 1);
     const bf16x8 kv = *(const bf16x8*)(kb + (size_t)jc * p.ld_k);
     const bf16x8 vv = *(const bf16x8*)(vb + (size_t)jc * p.ld_v);
-    float dot = 0.f;
+    float kf[8], vf[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) dot = __builtin_fmaf(q8[e], bf2f(kv[e]), dot);
-    dot = group8_sum(dot);
-    const float x = dot * icap;
-    const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (2.f * 1.4426950408889634f)));   // tanh(x)
-    const float pj = j < kve ? __builtin_amdgcn_exp2f(cap2 * th) : 0.f;
-    l += pj;
+    for (int e = 0; e < 8; e++) { kf[e] = bf2f(kv[e]); vf[e] = bf2f(vv[e]); }
 #pragma unroll
-    for (int e = 0; e < 8; e++) o8[e] = __builtin_fmaf(pj, bf2f(vv[e]), o8[e]);
+    for (int r = 0; r < R; r++) {
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) dot = __builtin_fmaf(q8[r][e], kf[e], dot);
+      dot = group8_sum(dot);
+      const float x = dot * icap;
+      const float th = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (2.f * 1.4426950408889634f)));   // tanh(x)
+      const float pj = j < kve[r] ? __builtin_amdgcn_exp2f(cap2 * th) : 0.f;
+      l[r] += pj;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o8[r][e] = __builtin_fmaf(pj, vf[e], o8[r][e]);
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; e++) red[wv * 8 + g][sl][e] = o8[e];
-  red[wv * 8 + g][sl][8] = l;
+  for (int r = 0; r < R; r++) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[r][wv * 8 + g][sl][e] = o8[r][e];
+    red[r][wv * 8 + g][sl][8] = l[r];
+  }
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x < 8 * R && (int)(threadIdx.x >> 3) < p.n) {
+    const int r = threadIdx.x >> 3, s2 = threadIdx.x & 7, t = t0 + r;
     float o[8], lt = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; e++) o[e] = 0.f;
     for (int gg = 0; gg < 32; gg++) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) o[e] += red[gg][sl][e];
-      lt += red[gg][sl][8];
+      for (int e = 0; e < 8; e++) o[e] += red[r][gg][s2][e];
+      lt += red[r][gg][s2][8];
     }
     const float gate = bf2f(p.gate[(size_t)t * p.ld_gate + h]);
     const float sc = __builtin_amdgcn_rcpf(1.f + __expf(-gate)) / lt;
     bf16x8 ov;
 #pragma unroll
     for (int e = 0; e < 8; e++) ov[e] = f2bf(o[e] * sc);
-    *(bf16x8*)(p.out + (size_t)t * p.ld_out + h * 64 + sl * 8) = ov;
-    if (p.lse && sl == 0) p.lse[((size_t)b * p.h + h) * p.n + (t - b * p.n)] = __logf(lt);
+    *(bf16x8*)(p.out + (size_t)t * p.ld_out + h * 64 + s2 * 8) = ov;
+    if (p.lse && s2 == 0) p.lse[((size_t)b * p.h + h) * p.n + r] = __logf(lt);
   }
+}
+
+template <int R> static int launch_decode_rows(const tfx_attn_args& a, hipStream_t s) {
+  static bool attr = false;
+  const int smem = R * 32 * 8 * 9 * 4;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)decode_attn_rows_k<R>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  hipLaunchKernelGGL(decode_attn_rows_k<R>, dim3((unsigned)(a.b * a.h)), dim3(256), smem, s, a);
+  return (int)hipGetLastError();
 }
 }  // namespace tfx
 using namespace tfx;
@@ -216,17 +242,15 @@ int tfx_cast_block_bf16(const float* src, int32_t ld_src, tfx_bf16* dst, int32_t
   return (int)hipGetLastError();
 }
 /* the K13 name of SURVEY 8(b): attention of a short block of NEW query rows per sample against keys / values that live in a KV cache
- * (`n_kv` > 0 rows per sample, per-row visible length in `kv_end`).  A text step (one or two new rows per sample) runs in decode_attn_k - one
- * block per (query row, head), no matrix cores (measured at 64 samples x 8 heads, 200 keys: the 220-launch text step 2.42 -> 2.33 ms); from four
- * rows per sample on (modality blocks, prefix appends) the forward kernel with its cache addressing is the faster one (512 rows: 3.47 vs 3.52 ms) */
+ * (`n_kv` > 0 rows per sample, per-row visible length in `kv_end`; the rows of a sample need not be ordered by visible length). */
 int tfx_decode_attn(const tfx_attn_args* a, void* s) {
   if (!a || a->n_kv <= 0) return -10;
-  if (a->n <= 2) {
-    const long long blocks = (long long)a->b * a->n * a->h;
-    if (blocks == 0) return 0;
-    hipLaunchKernelGGL(tfx::decode_attn_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, *a);
-    return (int)hipGetLastError();
-  }
+  if ((long long)a->b * a->h == 0 || a->n <= 0) return 0;
+  // one or two rows per sample (text steps): the multi-row kernel; from there on the tiled forward kernel with its cache addressing is the faster
+  // one - both read the layer's whole KV cache and are HBM-bound (86 MB per launch at 128 cache rows x 330 keys: 21.6 us for five rows per sample
+  // here against 18.9 us there, rocprofv3 inside the continuous decode loop)
+  if (a->n == 1) return tfx::launch_decode_rows<1>(*a, (hipStream_t)s);
+  if (a->n == 2) return tfx::launch_decode_rows<2>(*a, (hipStream_t)s);
   return tfx::attn_fwd(*a, (hipStream_t)s);
 }
 }

@@ -360,6 +360,7 @@ class Sampler:
             if need > joint.shape[2]:
                 joint = self._grow(joint, need + 192)
             cap = joint.shape[2]
+            # one attention kernel - the tiled forward kernel - for every plan of the run: a token's arithmetic must not depend on which plan carried it
             p = self._decode_plan(('mix' if mixed else 'txt', nb, Lq, joint.data_ptr()), nb, Lq, joint, mixed, n_inst=n_t, tile_attn=True)
             T = nb * Lq
             ids = np.zeros((H, B, Lq), np.int32); pos = np.full((H, B, Lq), -1, np.int64); kve = np.ones((H, B, Lq), np.int64)
