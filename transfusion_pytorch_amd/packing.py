@@ -41,33 +41,48 @@ class PackedBatch:
     total_tokens: int = 0
 
 
+def _ranges(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """concatenation of arange(starts[i], starts[i] + lens[i]) without a Python loop"""
+    lens = np.asarray(lens, dtype=np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    first = np.cumsum(lens) - lens                      # index of every range's first element in the output
+    return np.repeat(np.asarray(starts, dtype=np.int64) - first, lens) + np.arange(total, dtype=np.int64)
+
+
 def scan_batch(modalities, *, num_modalities, dim_latents, sos_id, eos_id, meta_id, som_ids, eom_ids,
                add_sos_eos: bool, add_meta: bool = True) -> PackedBatch:
+    """one pass over the parts (never over the tokens): every part contributes a run (ids array | fill value, length, droppable flag) to its
+    sample's row, and the per-token arrays are assembled from the runs with array operations"""
     b = len(modalities)
-    rows, positions = [], []
-    user_text, dest = [], []
-    droppable = []
+    positions = []
+    user_text, dest_b, dest_o, dest_l = [], [], [], []
     inst_b, inst_m, inst_type, inst_off, inst_len, inst_shape = [], [], [], [], [], []
     latents = {t: [] for t in range(num_modalities)}
-    row_inst = {t: [] for t in range(num_modalities)}
-    row_pos_local = {t: [] for t in range(num_modalities)}   # (sample, offset) pairs, resolved after n_full is known
+    run_b, run_o, run_l, run_fill, run_drop = [], [], [], [], []      # constant runs: (sample, offset, length, id value, droppable)
+    lit_b, lit_o, lit_ids = [], [], []                                # literal runs: the [meta] shape string [som] tokens (never droppable)
+    meta_cache = {}
+    lens = np.zeros(b, dtype=np.int64)
+    is_tensor = torch.is_tensor
     for bi, sample in enumerate(modalities):
-        ids = []          # python ints for specials, None for user text (filled on device), -1 for latent slots
-        drop = []
+        cur = 0
         m = 0
         pos = []
         if add_sos_eos:
-            ids.append(sos_id); drop.append(True)
+            run_b.append(bi); run_o.append(0); run_l.append(1); run_fill.append(sos_id); run_drop.append(True)
+            cur = 1
         for part in sample:
-            if torch.is_tensor(part) and part.is_floating_point():        # bare float tensor = modality type 0 (T:3060)
+            if is_tensor(part) and part.is_floating_point():              # bare float tensor = modality type 0 (T:3060)
                 part = (0, part)
             if not isinstance(part, tuple):
                 assert is_int_tensor(part), 'text must be an int / long tensor'
-                L = part.numel()
                 assert part.ndim <= 1
-                user_text.append(part.reshape(-1))
-                dest.append((bi, len(ids), L))
-                ids.extend([None] * L); drop.extend([True] * L)
+                L = part.numel()
+                user_text.append(part if part.ndim == 1 else part.reshape(-1))
+                dest_b.append(bi); dest_o.append(cur); dest_l.append(L)
+                run_b.append(bi); run_o.append(cur); run_l.append(L); run_fill.append(-1); run_drop.append(True)
+                cur += L
                 continue
             ty, x = part[0], part[1]
             assert 0 <= ty < num_modalities, f'received a modality index that is out of range. only {num_modalities} modalities specified'
@@ -75,43 +90,51 @@ def scan_batch(modalities, *, num_modalities, dim_latents, sos_id, eos_id, meta_
             axial = tuple(x.shape[:-1])
             L = math.prod(axial)
             if add_meta:
-                shape_str = ','.join(map(str, axial))
-                ids.append(meta_id); ids.extend(ord(c) + meta_id + 1 for c in shape_str); ids.append(som_ids[ty])
-                drop.extend([False] * (len(shape_str) + 2))
-            off = len(ids)
-            ids.extend([-1] * L); drop.extend([False] * L)
+                key = (axial, ty)
+                lit = meta_cache.get(key)
+                if lit is None:
+                    shape_str = ','.join(map(str, axial))
+                    lit = meta_cache[key] = np.array([meta_id, *(ord(c) + meta_id + 1 for c in shape_str), som_ids[ty]], dtype=np.int32)
+                lit_b.append(bi); lit_o.append(cur); lit_ids.append(lit)
+                cur += len(lit)
+            off = cur
+            cur += L                                                      # latent slots: id -1, not droppable = the arrays' initial values
             if add_meta:
-                ids.append(eom_ids[ty]); drop.append(False)
-            g = len(inst_b)
+                run_b.append(bi); run_o.append(cur); run_l.append(1); run_fill.append(eom_ids[ty]); run_drop.append(False)
+                cur += 1
             inst_b.append(bi); inst_m.append(m); inst_type.append(ty); inst_off.append(off); inst_len.append(L); inst_shape.append(axial)
             pos.append((ty, off, L))
-            latents[ty].append(x.reshape(L, -1))
-            row_inst[ty].append(np.full(L, g, dtype=np.int32))
-            row_pos_local[ty].append((bi, off, L))
+            latents[ty].append(x if x.ndim == 2 else x.reshape(L, -1))
             m += 1
         if add_sos_eos:
-            ids.append(eos_id); drop.append(True)
-        rows.append(ids); droppable.append(drop); positions.append(pos)
-    lens = np.array([len(r) for r in rows], dtype=np.int64)
+            run_b.append(bi); run_o.append(cur); run_l.append(1); run_fill.append(eos_id); run_drop.append(True)
+            cur += 1
+        lens[bi] = cur
+        positions.append(pos)
     n_full = int(lens.max()) if b else 0
-    text_host = np.full((b, n_full), -1, dtype=np.int32)
-    cfg_drop = np.zeros((b, n_full), dtype=bool)
-    for bi, (ids, drop) in enumerate(zip(rows, droppable)):
-        arr = np.array([(-1 if v is None else v) for v in ids], dtype=np.int32)
-        text_host[bi, :len(ids)] = arr
-        cfg_drop[bi, :len(ids)] = drop
-    text_dest = np.concatenate([np.arange(L, dtype=np.int64) + (bi * n_full + o) for bi, o, L in dest]) if dest else np.zeros(0, np.int64)
-    row_pos = {}
+    text_host = np.full(b * n_full, -1, dtype=np.int32)
+    cfg_drop = np.zeros(b * n_full, dtype=bool)
+    if run_b:
+        rb, ro, rl = np.asarray(run_b, np.int64), np.asarray(run_o, np.int64), np.asarray(run_l, np.int64)
+        idx = _ranges(rb * n_full + ro, rl)
+        text_host[idx] = np.repeat(np.asarray(run_fill, np.int32), rl)
+        cfg_drop[idx] = np.repeat(np.asarray(run_drop, bool), rl)
+    if lit_b:
+        ll = np.fromiter((len(a) for a in lit_ids), dtype=np.int64, count=len(lit_ids))
+        text_host[_ranges(np.asarray(lit_b, np.int64) * n_full + np.asarray(lit_o, np.int64), ll)] = np.concatenate(lit_ids)
+    text_dest = _ranges(np.asarray(dest_b, np.int64) * n_full + np.asarray(dest_o, np.int64), dest_l) if dest_b else np.zeros(0, np.int64)
+    ib, it, io, il = np.array(inst_b, np.int64), np.array(inst_type, np.int32), np.array(inst_off, np.int32), np.array(inst_len, np.int32)
+    row_inst, row_pos = {}, {}
     for t in range(num_modalities):
-        if row_pos_local[t]:
-            row_pos[t] = np.concatenate([np.arange(L, dtype=np.int64) + (bi * n_full + o) for bi, o, L in row_pos_local[t]]).astype(np.int32)
-            row_inst[t] = np.concatenate(row_inst[t])
+        sel = np.flatnonzero(it == t)
+        if sel.size:
+            row_pos[t] = _ranges(ib[sel] * n_full + io[sel], il[sel]).astype(np.int32)
+            row_inst[t] = np.repeat(sel.astype(np.int32), il[sel])
         else:
-            row_inst.pop(t); latents.pop(t)
+            latents.pop(t)
     return PackedBatch(
-        b=b, n_full=n_full, text_host=text_host, user_text=user_text, text_dest=text_dest, cfg_droppable=cfg_drop,
-        positions=positions, inst_b=np.array(inst_b, np.int64), inst_m=np.array(inst_m, np.int64),
-        inst_type=np.array(inst_type, np.int32), inst_off=np.array(inst_off, np.int32), inst_len=np.array(inst_len, np.int32),
+        b=b, n_full=n_full, text_host=text_host.reshape(b, n_full), user_text=user_text, text_dest=text_dest, cfg_droppable=cfg_drop.reshape(b, n_full),
+        positions=positions, inst_b=ib, inst_m=np.array(inst_m, np.int64), inst_type=it, inst_off=io, inst_len=il,
         inst_shape=inst_shape, latents=latents, row_inst=row_inst, row_pos=row_pos, lens=lens, total_tokens=int(lens.sum()))
 
 
@@ -128,24 +151,25 @@ class TokenMaps:
 
 def token_maps(P: PackedBatch, n: int, num_modalities: int, rot_offset: int = 0) -> TokenMaps:
     b = P.b
-    tok_inst = np.full((b, n), -1, dtype=np.int32)
+    tok_inst = np.full(b * n, -1, dtype=np.int32)
     ar = np.arange(n, dtype=np.int32)
-    kv_end = np.tile(ar + 1, (b, 1))
-    q_start = np.tile(ar, (b, 1))
-    extra = np.zeros((b, n), dtype=np.int32)
+    kv_end = np.tile(ar + 1, b)
+    q_start = np.tile(ar, b)
+    extra = np.zeros(b * n, dtype=np.int32)
     counts = np.zeros(num_modalities, dtype=np.int64)
-    for g in range(len(P.inst_b)):
-        bi, off, L, ty = P.inst_b[g], int(P.inst_off[g]), int(P.inst_len[g]), P.inst_type[g]
-        lo, hi = min(off, n), min(off + L, n)
-        if lo >= hi:
-            continue
-        tok_inst[bi, lo:hi] = g
-        kv_end[bi, lo:hi] = np.maximum(kv_end[bi, lo:hi], hi)
-        q_start[bi, lo:hi] = lo
-        extra[bi, lo + 1:hi] = 1
-        counts[ty] += hi - lo
-    rot = ar[None, :] - np.cumsum(extra, axis=1, dtype=np.int32) + rot_offset
-    return TokenMaps(n=n, tok_inst=tok_inst, kv_end=kv_end.astype(np.int32), q_start=q_start.astype(np.int32),
+    if len(P.inst_b):
+        lo = np.minimum(P.inst_off.astype(np.int64), n)
+        hi = np.minimum(P.inst_off.astype(np.int64) + P.inst_len, n)
+        ln = hi - lo                                                   # tokens of the instance inside the view (0 = cut off)
+        idx = _ranges(P.inst_b * n + lo, ln)
+        tok_inst[idx] = np.repeat(np.arange(len(ln), dtype=np.int32), ln)
+        kv_end[idx] = np.repeat(hi, ln)                                # the whole block sees itself (>= the causal i + 1 inside it)
+        q_start[idx] = np.repeat(lo, ln)
+        extra[idx] = 1
+        extra[(P.inst_b * n + lo)[ln > 0]] = 0                         # a block takes ONE rotary position: every token after its first stays put
+        counts += np.bincount(P.inst_type, weights=ln, minlength=num_modalities).astype(np.int64)[:num_modalities]
+    rot = ar[None, :] - np.cumsum(extra.reshape(b, n), axis=1, dtype=np.int32) + rot_offset
+    return TokenMaps(n=n, tok_inst=tok_inst.reshape(b, n), kv_end=kv_end.reshape(b, n).astype(np.int32), q_start=q_start.reshape(b, n).astype(np.int32),
                      rot_pos=rot.astype(np.int32), is_type=counts)
 
 
@@ -175,15 +199,13 @@ def token_segments(tok_inst: np.ndarray, max_text_run: int = 8):
     """runs of consecutive tokens (within a sample row) sharing one tok_inst value; text runs are chopped to
     <= max_text_run tokens so the waves that own them stay balanced.  Returns flat (start, length) arrays."""
     b, n = tok_inst.shape
-    starts, lens = [], []
-    for bi in range(b):
-        row = tok_inst[bi]
-        cut = np.flatnonzero(np.diff(row)) + 1
-        bounds = np.concatenate(([0], cut, [n]))
-        for lo, hi in zip(bounds[:-1], bounds[1:]):
-            if row[lo] >= 0:
-                starts.append(bi * n + lo); lens.append(hi - lo)
-            else:
-                for s in range(lo, hi, max_text_run):
-                    starts.append(bi * n + s); lens.append(min(max_text_run, hi - s))
-    return np.asarray(starts, dtype=np.int32), np.asarray(lens, dtype=np.int32)
+    if b * n == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32)
+    col = np.broadcast_to(np.arange(n, dtype=np.int64), (b, n))
+    start = np.ones((b, n), dtype=bool)
+    start[:, 1:] = tok_inst[:, 1:] != tok_inst[:, :-1]                  # a new run begins where the value changes (and at column 0)
+    run_start = np.maximum.accumulate(np.where(start, col, 0), axis=1)  # column where the token's run began
+    start |= (tok_inst < 0) & ((col - run_start) % max_text_run == 0)    # text runs: a new segment every max_text_run tokens
+    starts = np.flatnonzero(start.reshape(-1))
+    ends = np.append(starts[1:], b * n)
+    return starts.astype(np.int32), (ends - starts).astype(np.int32)
