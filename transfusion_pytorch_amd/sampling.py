@@ -10,8 +10,9 @@ runs in the HIP kernels through a *decode plan* (engine.Plan with a KV cache):
     against the conditional cache and - classifier-free guidance - the null-text cache: ONE forward over 2 B rows (the two
     caches are halves of one buffer).  The null-text cache is appended between phases (`_uncond_append`), not rebuilt.
 
-Schedule: continuous batching by default (`_loop_continuous`: every global step advances every live sample by a token or by one ODE evaluation
-in one mixed forward); `TFX_SAMPLE_SCHEDULE=phased` keeps the reference's text-rounds / joint-ODE loop (`_loop_phased`).
+Schedule: continuous batching (`_loop_continuous`: every global step advances every live sample by a token or by one ODE evaluation in one
+mixed forward) while a mixed step stays launch-bound (<= 4096 rows), else the reference's text-rounds / joint-ODE loop (`_loop_phased`);
+`TFX_SAMPLE_SCHEDULE=continuous | phased` forces one.
 
 Cache semantics reproduced exactly: the new [som] token is NOT in the conditional cache when its modality is decoded
 (the modality block takes the rotary position the [som] would have had, T:2411); the K/V committed for a decoded
@@ -249,7 +250,15 @@ class Sampler:
         # what a sample decodes - the reference's own test asserts sample_many == per-prompt sample_one):
         #   continuous (default)  every global step advances EVERY live sample - by a text token or by one ODE evaluation - in one mixed forward
         #   phased                the reference's loop (T:2226-2360): text steps until no sample is in its text phase, then one joint ODE
-        if os.environ.get('TFX_SAMPLE_SCHEDULE', 'continuous') != 'phased':
+        # A mixed step carries (modality length + 1) rows for EVERY sample, a text step of the phased loop one: continuous batching pays while a
+        # forward is launch-bound (its time does not depend on the row count) - up to a few thousand rows.  Long blocks (images) in a large batch
+        # keep the phased schedule: there a mixed step would cost as much as a joint ODE evaluation of the whole batch.
+        schedule = os.environ.get('TFX_SAMPLE_SCHEDULE', 'auto')
+        if schedule == 'auto':
+            est = [math.prod(sh) for sh in m.modality_default_shape if sh is not None] + ([math.prod(fixed_modality_shape)] if fixed_modality_shape else [])
+            rows = (2 if use_cfg else 1) * B * (max(est, default=4) + 1)
+            schedule = 'continuous' if rows <= 4096 else 'phased'
+        if schedule != 'phased':
             self._loop_continuous(states, joint, maxlen, use_cfg, stream, max_length, text_temperature, text_min_p, fixed_modality_shape,
                                   init_modality_noise, modality_steps, cfg_scale)
         else:
