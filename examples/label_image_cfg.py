@@ -41,12 +41,15 @@ class LabelledStrokes(Dataset):
         return pair if self.image_after_text else pair[::-1]
 
 
-def main(steps=300, batch_size=16, sample=True, log=print, fallback_shape=False):
-    """fallback_shape: an under-trained model may spell a malformed shape string; True falls back to `modality_default_shape` (T:1636-1640)"""
+def main(steps=300, batch_size=16, sample=True, log=print, fallback_shape=False, unet=False):
+    """fallback_shape: an under-trained model may spell a malformed shape string; True falls back to `modality_default_shape` (T:1636-1640).
+    unet: the configuration of the reference's `train_mnist_with_unet.py` - a stride-2 conv / transposed-conv pair around the transformer (49 tokens
+    per 14 x 14 latent image); `sample()` then decodes through the un-cached loop, guidance included."""
     torch.manual_seed(0)
+    extra = dict(pre_post_transformer_enc_dec=(torch.nn.Conv2d(4, 64, 3, 2, 1), torch.nn.ConvTranspose2d(64, 4, 3, 2, 1, output_padding=1))) if unet else {}
     model = Transfusion(num_text_tokens=10, dim_latent=4, modality_default_shape=(14, 14), modality_encoder=Patchify(), modality_decoder=Unpatchify(),
                         add_pos_emb=True, modality_num_dim=2, prob_uncond=0.1, channel_first_latent=True, fallback_to_default_shape_if_invalid=fallback_shape,
-                        transformer=dict(dim=64, depth=4, dim_head=32, heads=8)).cuda()
+                        transformer=dict(dim=64, depth=4, dim_head=32, heads=8), **extra).cuda()
     ema_model = model.create_ema()
     loader = model.create_dataloader(LabelledStrokes(), batch_size=batch_size, shuffle=True)
     opt = torch.optim.Adam(model.parameters(), lr=3e-4)
@@ -77,5 +80,6 @@ def main(steps=300, batch_size=16, sample=True, log=print, fallback_shape=False)
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--unet', action='store_true')
     a = ap.parse_args()
-    main(steps=a.steps)
+    main(steps=a.steps, unet=a.unet)

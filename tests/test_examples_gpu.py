@@ -33,9 +33,10 @@ def test_image_flow_with_unet_ema_teacher_and_generation():
     assert images.shape == (4, 1, 28, 28) and float(images.min()) >= 0. and float(images.max()) <= 1.
 
 
-def test_text_image_interleaved_with_guided_sampling():
+@pytest.mark.parametrize('unet', [False, True])       # True: train_mnist_with_unet.py (conv pair around the transformer; sample() through the un-cached loop)
+def test_text_image_interleaved_with_guided_sampling(unet):
     import label_image_cfg as ex
-    losses, out = ex.main(steps=80, log=lambda *a: None, fallback_shape=True)
+    losses, out = ex.main(steps=80, log=lambda *a: None, fallback_shape=True, unet=unet)
     assert falling(losses)
     # the prompt label, then - if the model opened a modality - a decoded (1, 28, 28) image (T:2581-2583 decodes unless asked not to)
     assert torch.is_tensor(out[0]) and out[0].dtype == torch.long
