@@ -317,7 +317,11 @@ class Plan:
                      bias=pp('transformer.layers.0.1.to_film.bias'))
             self.fwd_cond = (self.fwd_cond[0], len(L))
         src = skip_sources(md)
-        fused_pre = {}                        # decode plans: layer -> its attention-side AdaLN-pre args when the previous layer's end launch runs them
+        fused_pre = {}                        # layer -> its attention-side AdaLN-pre args when the previous layer's end launch runs them
+        # token-wise launches that follow each other on the same rows run as ONE launch (bit-identical to the separate kernels, tests/test_kernels_gpu.py):
+        # wrapper output + next wrapper input, and the end of a layer (feed-forward output side, AttentionResidual, the next layer's input side).
+        # Decode plans always (launch-bound); training / prefill plans unless TFX_FWD_FUSED=0 (A/B): one HBM round trip of the row instead of two / three
+        fuse = self.cache is not None or os.environ.get('TFX_FWD_FUSED', '1') != '0'
         for i in range(D):
             p = f'transformer.layers.{i}'
             li, lkv = self._li(i), self._lkv(i)
@@ -331,7 +335,7 @@ class Plan:
             ta, _ = self._tab(i, 0); tf, _ = self._tab(i, 1)
             a_pre_attn = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x_a, u=self.ua[li], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
                                         gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, li), rstd=_p(self.stats, 1, li))
-            if i in fused_pre:                # decode plans: already done by the previous layer's end launch (tfx_layer_end_fwd)
+            if i in fused_pre:                # already done by the previous layer's end launch (tfx_layer_end_fwd)
                 assert fused_pre[i].x == a_pre_attn.x and fused_pre[i].u == a_pre_attn.u
             else:
                 L.append(('tfx_adaln_pre_fwd', a_pre_attn))
@@ -349,7 +353,7 @@ class Plan:
                                     table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
             a_pre = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[li], u=self.uf[li], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                                    gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, li), rstd=_p(self.stats, 3, li))
-            if self.cache is not None:        # decode plans: both sides in one launch
+            if fuse:                          # both sides in one launch
                 self._keep = getattr(self, '_keep', []) + [a_post, a_pre]
                 self._raw(L, capi.lib().tfx_adaln_post_pre_fwd, ctypes.addressof(a_post), ctypes.addressof(a_pre))
             else:
@@ -363,8 +367,8 @@ class Plan:
                                      table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
             a_ar = capi.make_args('tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
                                   gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1])
-            if self.cache is not None:
-                # decode plans: the end of the layer is ONE launch - feed-forward output side, AttentionResidual, and (when the next layer reads
+            if fuse:
+                # the end of the layer is ONE launch - feed-forward output side, AttentionResidual, and (when the next layer reads
                 # the result directly, i.e. has no U-Net skip projection in front) the next layer's attention-side AdaLN-pre
                 nxt = None
                 if i + 1 < D and not md.has_skip(i + 1):
