@@ -209,3 +209,44 @@ def test_axial_positional_embedding_and_external_encoder_wiring():
     assert [c - m.meta_id - 1 for c in row[i + 1:i + 4]] == [ord('4'), ord(','), ord('4')]
     clone = m._clone_architecture()
     assert clone.latent_to_model_projs[0][0] is not m.latent_to_model_projs[0][0]
+
+
+def test_packer_matches_oracle_on_random_ragged_batches():
+    """the native packer assembles its per-token arrays from per-part runs with array operations: ragged random batches (two modality types of
+    1 - 3 axial dims, bare float tensors = type 0, empty / adjacent text parts, samples without modalities) against the oracle's per-token
+    packer (pinned to the reference, tests/test_oracle_golden.py) - ids, positions, mask bounds, rotary positions; segments cover every token once"""
+    from oracle.transfusion_oracle import OracleConfig
+    cfg = OracleConfig(num_text_tokens=200, dim=64, depth=1, dim_latents=(8, 16), heads=1, dim_head=64)
+    g = torch.Generator().manual_seed(7)
+    ri = lambda lo, hi: int(torch.randint(lo, hi, (1,), generator=g))
+    shapes = [[(4,), (2, 3), (1,), (11,)], [(3, 3), (2, 2, 2), (5,), (1, 1)]]
+    for trial in range(25):
+        batch = []
+        for _ in range(ri(1, 6)):
+            s = []
+            for _ in range(ri(0, 8)):
+                kind = ri(0, 3)
+                if kind == 0:
+                    s.append(torch.randint(0, 200, (ri(0, 40),), generator=g))
+                else:
+                    ty = ri(0, 2)
+                    x = torch.randn(*shapes[ty][ri(0, 4)], cfg.dim_latents[ty], generator=g)
+                    s.append(x if (ty == 0 and kind == 2) else (ty, x))
+            batch.append(s or [torch.randint(0, 200, (3,), generator=g)])
+        O = pack_batch(cfg, batch)
+        P = scan_batch(batch, num_modalities=2, dim_latents=cfg.dim_latents, sos_id=cfg.sos_id, eos_id=cfg.eos_id, meta_id=cfg.meta_id,
+                       som_ids=cfg.som_ids, eom_ids=cfg.eom_ids, add_sos_eos=True)
+        assert P.positions == O.positions and P.total_tokens == O.total_tokens and P.n_full == O.text.shape[1], trial
+        text = P.text_host.copy().reshape(-1)
+        if P.user_text:
+            text[P.text_dest] = torch.cat([t.reshape(-1) for t in P.user_text]).numpy()
+        assert np.array_equal(text.reshape(O.text.shape), O.text.numpy()), trial
+        n = P.n_full - 1
+        tm = token_maps(P, n, 2)
+        assert np.array_equal(tm.kv_end, kv_end_from_positions(O.positions, P.b, n).numpy()), trial
+        assert np.array_equal(tm.rot_pos, rotary_positions(O.positions, P.b, n).numpy()), trial
+        ss, sl = token_segments(tm.tok_inst)
+        assert sl.sum() == P.b * n and (sl > 0).all() and np.array_equal(ss, np.concatenate(([0], np.cumsum(sl)[:-1])))
+        flat = tm.tok_inst.reshape(-1)
+        for s0, l0 in zip(ss, sl):
+            assert (flat[s0:s0 + l0] == flat[s0]).all() and (flat[s0] >= 0 or l0 <= 8) and s0 // n == (s0 + l0 - 1) // n
