@@ -618,19 +618,22 @@ class Plan:
                 sk = self.xres[src[i]]
                 self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
                 self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
-            if I > 0:
-                # AdaLN conditioning weights of THIS layer (both wrappers: 6d table columns, 63 % of all parameters): their table gradients
-                # are final once the layer's backward is, so the weight / bias gradients are formed here, layer by layer, instead of in one
-                # GEMM at the very end - the gradient buffer then completes back to front and its all-reduce can start during the backward
-                off = i * 2 * 3 * d
+            per = -(-D // self.dp_groups) if self.dp_groups > 0 else D
+            if I > 0 and i % per == 0:
+                # AdaLN conditioning weights (6d table columns per layer, 63 % of all parameters) of the layer GROUP that ends here: their table
+                # gradients are final once the group's backward is.  With the overlapped gradient exchange (dp_groups > 0) the weight / bias
+                # gradients are formed group by group, so that the gradient buffer completes back to front and a group's all-reduce can start
+                # during the backward; one GEMM per group (>= 768 tiles: no split, every block reduces all I instances).  Without an exchange
+                # (dp_groups == 0: one GPU, or one all-reduce after the backward) the "group" is the whole stack: ONE GEMM after layer 0
+                hi = min(i + per, D)
+                off, cols = i * 2 * 3 * d, (hi - i) * 2 * 3 * d
                 w_item = lambda it: L.append(Side(it) if side else it)
-                w_item((lib.tfx_cast_block_bf16, (self.dtables.data_ptr() + 4 * off, nt3, self.dtab_bf.data_ptr() + 2 * off, nt3, I, 6 * d)))
-                self._tn(L, I, 6 * d, 4 * d, side=side, A=self.dtab_bf.data_ptr() + 2 * off, lda=nt3, a_cols=6 * d, B=self.cond, ldb=4 * d, b_cols=4 * d,
+                w_item((lib.tfx_cast_block_bf16, (self.dtables.data_ptr() + 4 * off, nt3, self.dtab_bf.data_ptr() + 2 * off, nt3, I, cols)))
+                self._tn(L, I, cols, 4 * d, side=side, A=self.dtab_bf.data_ptr() + 2 * off, lda=nt3, a_cols=cols, B=self.cond, ldb=4 * d, b_cols=4 * d,
                          C=gp(f'{p}.1.to_film.weight'), ldc=4 * d)
-                w_item((lib.tfx_colsum_f32, (self.dtables.data_ptr() + 4 * off, nt3, I, 6 * d, gp(f'{p}.1.to_film.bias'))))
+                w_item((lib.tfx_colsum_f32, (self.dtables.data_ptr() + 4 * off, nt3, I, cols, gp(f'{p}.1.to_film.bias'))))
             sync('tfx_join_record', i)
             if self.dp_groups > 0:
-                per = -(-D // self.dp_groups)
                 if i % per == 0:                                     # lowest layer of a group: every gradient of layers >= i is final
                     sync('tfx_join_wait', i)
                     self.bwd_cuts.append((len(L), i, min(i + per, D) - 1))
