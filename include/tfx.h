@@ -126,6 +126,7 @@ typedef struct {
   /* optional segment mode (backward): runs of consecutive tokens sharing one tok_inst value; one wave owns a
    * segment, so an instance's FiLM gradients are reduced in registers and STORED (no atomics).  NULL or n_seg == 0 = per-token atomics */
   const int32_t* seg_start; const int32_t* seg_len; int32_t n_seg;
+  const tfx_bf16* dx_add;                     /* backward, optional [T,d]: one more addend of dx (the gradient a U-Net skip hands to this layer's input) */
 } tfx_adaln_pre_args;
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* stream);
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* stream);
@@ -179,6 +180,9 @@ typedef struct {
   tfx_bf16* dhiddens; int64_t stride_dh;      /* accumulate (or store if `first`) */
   int32_t first;
   float* dgamma; float* dpq;                  /* atomic accumulate */
+  /* forward, optional (training plans): the depth softmax of every token is kept for the pull-form backward (tfx_attnres_pull_bwd):
+   * save[(t * L + l) * 4 + {0, 1, 2}] = softmax weight a_l, 1 / |h_l|, score s_l = <h_l, w> / |h_l| */
+  float* save;
 } tfx_attnres_args;
 int tfx_attnres_fwd(const tfx_attnres_args* a, void* stream);
 int tfx_attnres_bwd(const tfx_attnres_args* a, void* stream);
@@ -186,6 +190,41 @@ int tfx_attnres_bwd(const tfx_attnres_args* a, void* stream);
  * over hiddens 0 .. L - 1 (writes ar->out), and - when `pre` is non-NULL - the input side of the NEXT layer's attention wrapper on that output.
  * Same roundings as the three separate launches (every written row is re-read as bf16).  post->out must be hidden L - 1 of `ar`, pre->x == ar->out. */
 int tfx_layer_end_fwd(const tfx_adaln_post_args* post, const tfx_attnres_args* ar, const tfx_adaln_pre_args* pre, void* stream);
+
+/* AttentionResidual backward in PULL form (T:807-829; the training plans' form).  Hidden l feeds the AttentionResidual of every layer
+ * j >= l - 1, so its gradient is   dh_l = sum_j [ a_jl g_j + k1_jl w_j - k2_jl h_l ],   k1 = ds inv_l, k2 = k1 s_jl inv_l,
+ * ds_jl = a_jl (<g_j, h_l> - <g_j, out_j>)   (sum_l a_jl <g_j, h_l> = <g_j, out_j>: the forward output is the softmax mix of the hiddens).
+ * The push form (tfx_attnres_bwd, one launch per layer) reads every earlier hidden and read-modify-writes every earlier gradient once per
+ * layer: (3L + 2) passes of [T, d] per layer.  The pull form computes dh_l ONCE, when the backward reaches layer l - 1: it reads h_l and the
+ * n_src output gradients g_j (all final by then), plus three saved scalars per (j, token) - (n_src + 2) passes, about 0.6x the bytes at
+ * depth 8 and 0.5x at depth 24.  d w_j = sum_t sum_l k1_jl h_l accumulates in registers (n_src <= 8 at d <= 512) or in LDS, per launch, into
+ * src[j].dw; tfx_attnres_finish turns it into d gamma / d pseudo_queries.
+ * With `post` the feed-forward wrapper's output side (tfx_adaln_post_bwd on g = the dh_l just written) runs in the same launch. */
+typedef struct {
+  const tfx_bf16* g;                          /* [T,d] gradient wrt the output of this layer's AttentionResidual (final) */
+  const float* save;                          /* [T, L, 4] its saved forward state (tfx_attnres_args.save) */
+  float* dsum;                                /* [T] <g, out>: written by the launch that lists this layer first with `out_own`, read by later ones */
+  float* w; float* dw;                        /* [d] fp32: (1 + gamma) * pseudo_queries (tfx_attnres_prep); its gradient accumulator (atomics) */
+  const float* gamma; const float* pq;        /* norm_keys.gamma, pseudo_queries [d] */
+  float* dgamma; float* dpq;                  /* their gradients (tfx_attnres_finish, accumulate) */
+  int32_t L; int32_t reserved;                /* hiddens this layer mixes */
+} tfx_attnres_src;
+typedef struct {
+  int32_t T, d, l, n_src;                     /* hidden index l; 1 <= n_src <= 32 layers read it */
+  const tfx_bf16* h;                          /* [T,d] hidden l */
+  const tfx_attnres_src* src;                 /* DEVICE array [n_src], lowest layer first */
+  const tfx_bf16* out_own;                    /* optional [T,d]: the forward output of src[0]'s AttentionResidual - its dsum is formed here */
+  const tfx_bf16* add;                        /* optional [T,d] addend (gradient that reaches the hidden directly) */
+  tfx_bf16* dh;                               /* [T,d] result (stored) */
+  const int32_t* seg_start; const int32_t* seg_len; int32_t n_seg;   /* token segments (tfx_adaln_pre_args); n_seg == 0: one token per wave */
+} tfx_attnres_pull_args;
+int tfx_attnres_prep(const tfx_attnres_src* src_dev, int32_t n, int32_t d, void* stream);     /* w = (1 + gamma) pq ; dw = 0, for n layers */
+int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_args* post, void* stream);
+int tfx_attnres_finish(const tfx_attnres_src* src_dev, int32_t n, int32_t d, void* stream);   /* dgamma += dw pq ; dpq += dw (1 + gamma) */
+/* backward of two adjacent wrapper sides in one launch: tfx_adaln_pre_bwd(pre) (dx += LN backward, in place) followed by
+ * tfx_adaln_post_bwd(post) with post->g == pre->dx: the residual-gradient row is written once and not read back.  Segment mode only
+ * (pre->n_seg > 0, same segments); bit-identical to the two launches. */
+int tfx_adaln_pre_post_bwd(const tfx_adaln_pre_args* pre, const tfx_adaln_post_args* post, void* stream);
 
 typedef struct {
   int32_t T, d;
@@ -347,6 +386,7 @@ enum { TFX_OP_GEMM_NT = 0, TFX_OP_GEMM_TN = 1, TFX_OP_ATTN_FWD = 2, TFX_OP_ATTN_
        /* positional entry points (args = tfx_raw_args) */
        TFX_OP_OUTPUT_TO_FLOW = 32, TFX_OP_GATHER_F32 = 33, TFX_OP_ONEHOT_BF16 = 34, TFX_OP_SCATTER_ROWS_BF16 = 35, TFX_OP_F32_TO_BF16 = 36,
        TFX_OP_SILU_BWD = 37, TFX_OP_COLSUM_BF16 = 38, TFX_OP_COLSUM_F32 = 39, TFX_OP_ADD_BF16 = 40, TFX_OP_SCALE_BF16_DEV = 41, TFX_OP_CAST_BLOCK_BF16 = 42, TFX_OP_SCALE_BF16_COPY = 43, TFX_OP_ADALN_POST_PRE_FWD = 44, TFX_OP_LAYER_END_FWD = 45,
+       TFX_OP_ATTNRES_PREP = 46, TFX_OP_ATTNRES_PULL_BWD = 47, TFX_OP_ATTNRES_FINISH = 52, TFX_OP_ADALN_PRE_POST_BWD = 53,
        /* stream control (args = any non-NULL pointer; `stream` = event slot 0..63):
           FORK: the library's side stream waits for everything enqueued so far on the caller's stream;
           JOIN_RECORD: mark "everything enqueued so far on the side stream";  JOIN_WAIT: the caller's stream waits for that mark;

@@ -589,6 +589,144 @@ def test_adaln_bwd_segment_mode(T, d):
         check(f'segment-mode {nm}', a_, b_, 2e-3 if 'dx' in nm or 'dy' in nm else 1e-5)
 
 
+def _segmented_tokens(T, I, seed=0):
+    """two sample rows with contiguous instances of random lengths; returns tok_inst (device), segment arrays (device), T"""
+    import numpy as np
+    from transfusion_pytorch_amd.packing import token_segments
+    tok = np.full((2, T // 2), -1, dtype=np.int32)
+    g = 0
+    for bi in range(2):
+        pos = 2
+        while pos < T // 2 - 12 and g < I:
+            L = int(np.random.RandomState(seed + g).randint(1, 12))
+            tok[bi, pos:pos + L] = g; g += 1
+            pos += L + int(np.random.RandomState(seed + 100 + g).randint(0, 20))
+    seg_start, seg_len = token_segments(tok)
+    return torch.from_numpy(tok.reshape(-1)).to(DEV), torch.from_numpy(seg_start).to(DEV), torch.from_numpy(seg_len).to(DEV), tok.size
+
+
+@pytest.mark.parametrize('T,d', [(1000, 512), (300, 1024), (200, 64)])
+def test_adaln_pre_post_bwd_fused_equals_two_launches(T, d):
+    """tfx_adaln_pre_post_bwd == tfx_adaln_pre_bwd followed by tfx_adaln_post_bwd (segment mode): rows and stored table gradients bit for bit,
+    atomically accumulated vectors to summation order; `dx_add` of the input-side kernel in both modes."""
+    torch.manual_seed(0)
+    I = 23
+    tok_inst, ss, sl, T = _segmented_tokens(T, I)
+    ld = 6 * d + 8
+    table = torch.randn(I, ld, device=DEV) * 0.5
+    x = rnd(T, d, scale=2.0); gt = torch.randn(d, device=DEV) * 0.3; du = rnd(T, d); y = rnd(T, d); ls = torch.randn(d, device=DEV) * 0.3
+    u = torch.zeros(T, d, device=DEV, dtype=BF); mean = torch.zeros(T, device=DEV); rstd = torch.zeros(T, device=DEV)
+    dx0 = rnd(T, d)
+    seg = dict(seg_start=ss, seg_len=sl, n_seg=int(ss.numel()))
+    outs = []
+    for fused in (False, True):
+        dx = dx0.clone(); dtable = torch.zeros_like(table); dgt = torch.zeros(d, device=DEV)
+        dy = torch.zeros(T, d, device=DEV, dtype=BF); dls = torch.zeros(d, device=DEV)
+        a = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x, u=u, tok_inst=tok_inst, table=table, ld_table=ld, gamma_text=gt,
+                           mean=mean, rstd=rstd, du=du, dx=dx, dtable=dtable, dgamma_text=dgt, **seg)
+        b = capi.make_args('tfx_adaln_post_args', T=T, d=d, y=y, tok_inst=tok_inst, table=table.data_ptr() + 4 * 3 * d, ld_table=ld,
+                           layerscale=ls, g=dx, dy=dy, dtable=dtable.data_ptr() + 4 * 3 * d, dlayerscale=dls, **seg)
+        capi.call('tfx_adaln_pre_fwd', a, stream())
+        if fused:
+            import ctypes
+            capi.check(capi.lib().tfx_adaln_pre_post_bwd(ctypes.byref(a), ctypes.byref(b), stream()), 'tfx_adaln_pre_post_bwd')
+        else:
+            capi.call('tfx_adaln_pre_bwd', a, stream()); capi.call('tfx_adaln_post_bwd', b, stream())
+        outs.append((dx.clone(), dy.clone(), dtable.clone(), dgt.clone(), dls.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]), 'dx differs'
+    assert torch.equal(outs[0][1], outs[1][1]), 'dy differs'
+    assert torch.equal(outs[0][2], outs[1][2]), 'dtable differs'
+    check('fused dgamma_text', outs[1][3], outs[0][3], 1e-5); check('fused dlayerscale', outs[1][4], outs[0][4], 1e-5)
+    # dx_add: one more addend of dx, segment mode and per-token mode
+    add = rnd(T, d)
+    for kw in (seg, {}):
+        res = []
+        for use_add in (False, True):
+            dx = dx0.clone()
+            dtable = torch.zeros_like(table); dgt = torch.zeros(d, device=DEV)
+            a = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=x, u=u, tok_inst=tok_inst, table=table, ld_table=ld, gamma_text=gt,
+                               mean=mean, rstd=rstd, du=du, dx=dx, dtable=dtable, dgamma_text=dgt, dx_add=add if use_add else None, **kw)
+            capi.call('tfx_adaln_pre_bwd', a, stream())
+            res.append(dx.float())
+        check('adaln_pre_bwd dx_add', res[1], res[0] + add.float(), 6e-3)
+
+
+@pytest.mark.parametrize('T,d,D,segs,post', [(600, 512, 8, True, True), (300, 512, 8, False, True), (300, 1024, 6, True, True), (200, 512, 12, True, False),
+                                             (200, 256, 3, True, True), (150, 768, 9, False, False)])
+def test_attnres_pull_backward_stack(T, d, D, segs, post):
+    """A stack of D AttentionResiduals (layer j mixes hiddens 0 .. j+1, T:807-829) differentiated in PULL form (tfx_attnres_pull_bwd: the gradient
+    of hidden l gathered once from every layer that mixed it) against torch autograd of the same stack; the forward kernels supply the saved
+    softmax state.  Covers the register (n_src <= 8, d <= 512) and the LDS accumulation forms, segments / one token per wave, and the fused
+    output side of the feed-forward wrapper against a separate tfx_adaln_post_bwd on the same row."""
+    import ctypes
+    torch.manual_seed(1)
+    I = 19
+    tok_inst, ss, sl, T = _segmented_tokens(T, I, seed=3)
+    seg = dict(seg_start=ss, seg_len=sl, n_seg=int(ss.numel())) if segs else {}
+    H = rnd(D + 1, T, d, scale=2.0)
+    gm = torch.randn(D, d, device=DEV) * 0.3; pq = torch.randn(D, d, device=DEV) * 0.5
+    G = rnd(D, T, d)                                              # gradient wrt the output of layer j's AttentionResidual
+    extra = rnd(T, d)                                             # direct gradient of hidden 0
+    outs = torch.zeros(D, T, d, device=DEV, dtype=BF)
+    saves = [torch.zeros(T, j + 2, 4, device=DEV) for j in range(D)]
+    for j in range(D):
+        a = capi.make_args('tfx_attnres_args', T=T, d=d, L=j + 2, hiddens=H, stride_h=T * d, gamma=gm[j], pq=pq[j], out=outs[j], save=saves[j])
+        capi.call('tfx_attnres_fwd', a, stream())
+    # reference
+    Hr = H.float().requires_grad_(True); gr = gm.clone().requires_grad_(True); pr = pq.clone().requires_grad_(True)
+    loss = (Hr[0] * extra.float()).sum()
+    for j in range(D):
+        hs = Hr[:j + 2]
+        keys = F.normalize(hs, dim=-1) * d ** 0.5 * (gr[j] + 1)
+        sim = torch.einsum('ltd,d->tl', keys, pr[j]) * d ** -0.5
+        o = torch.einsum('tl,ltd->td', sim.softmax(-1), hs)
+        if j == D - 1:
+            check('attnres fwd (with save)', outs[j], o, 6e-3)
+            aw = sim.softmax(-1)
+            check('saved softmax weights', saves[j][:, :, 0], aw, 1e-4)
+        loss = loss + (o * G[j].float()).sum()
+    loss.backward()
+    # native
+    dsum = torch.zeros(D, T, device=DEV); wtab = torch.zeros(2, D, d, device=DEV)
+    dgm = torch.zeros(D, d, device=DEV); dpq = torch.zeros(D, d, device=DEV)
+    SRC = capi.STRUCTS['tfx_attnres_src']
+    recs = (SRC * D)()
+    for j in range(D):
+        for k, v in dict(g=G[j], save=saves[j], dsum=dsum[j], w=wtab[0, j], dw=wtab[1, j], gamma=gm[j], pq=pq[j], dgamma=dgm[j], dpq=dpq[j]).items():
+            setattr(recs[j], k, v.data_ptr())
+        recs[j].L = j + 2
+    tab = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(recs), ctypes.sizeof(recs))), dtype=torch.uint8).to(DEV)
+    lib = capi.lib()
+    capi.check(lib.tfx_attnres_prep(tab.data_ptr(), D, d, stream()), 'prep')
+    dH = torch.full((D + 1, T, d), float('nan'), device=DEV, dtype=BF)
+    ld = 3 * d + 8
+    table = torch.randn(I, ld, device=DEV) * 0.5; ls = torch.randn(d, device=DEV) * 0.3; y = rnd(T, d)
+    for l in range(D, -1, -1):
+        j0 = max(l - 1, 0)
+        a = capi.make_args('tfx_attnres_pull_args', T=T, d=d, l=l, n_src=D - j0, h=H[l], src=tab.data_ptr() + j0 * ctypes.sizeof(SRC),
+                           out_own=outs[l - 1] if l >= 1 else None, add=extra if l == 0 else None, dh=dH[l], **seg)
+        if post and l == D:
+            dy = torch.zeros(T, d, device=DEV, dtype=BF); dt = torch.zeros_like(table); dls = torch.zeros(d, device=DEV); db = torch.zeros(d, device=DEV)
+            b = capi.make_args('tfx_adaln_post_args', T=T, d=d, y=y, tok_inst=tok_inst, table=table, ld_table=ld, layerscale=ls, g=dH[l], dy=dy,
+                               dtable=dt, dlayerscale=dls, dbias=db, **seg)
+            capi.check(lib.tfx_attnres_pull_bwd(ctypes.byref(a), ctypes.byref(b), stream()), 'pull+post')
+            dy2 = torch.zeros(T, d, device=DEV, dtype=BF); dt2 = torch.zeros_like(table); dls2 = torch.zeros(d, device=DEV); db2 = torch.zeros(d, device=DEV)
+            b2 = capi.make_args('tfx_adaln_post_args', T=T, d=d, y=y, tok_inst=tok_inst, table=table, ld_table=ld, layerscale=ls, g=dH[l], dy=dy2,
+                                dtable=dt2, dlayerscale=dls2, dbias=db2, **seg)
+            capi.call('tfx_adaln_post_bwd', b2, stream())
+            assert torch.equal(dy, dy2), 'fused output side: dy differs'
+            check('fused output side dtable', dt, dt2, 1e-5); check('fused dlayerscale', dls, dls2, 1e-5); check('fused dbias', db, db2, 1e-5)
+        else:
+            capi.check(lib.tfx_attnres_pull_bwd(ctypes.byref(a), None, stream()), 'pull')
+    capi.check(lib.tfx_attnres_finish(tab.data_ptr(), D, d, stream()), 'finish')
+    torch.cuda.synchronize()
+    for l in range(D + 1):
+        check(f'pull dH[{l}] (D={D}, d={d})', dH[l], Hr.grad[l], 2e-2)
+    check('pull dgamma', dgm, gr.grad, 2e-2); check('pull dpq', dpq, pr.grad, 2e-2)
+    for j in (0, D - 1):
+        check(f'pull dgamma layer {j}', dgm[j], gr.grad[j], 3e-2); check(f'pull dpq layer {j}', dpq[j], pr.grad[j], 3e-2)
+
+
 # ---------------------------------------------------------------------------------------------- decode-side kernels
 @pytest.mark.parametrize('B,V,ld', [(1, 390, 392), (7, 392, 392), (64, 390, 448), (5, 70, 72)])
 def test_sample_tokens_greedy_and_min_p(B, V, ld):

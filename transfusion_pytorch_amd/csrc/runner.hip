@@ -61,6 +61,14 @@ inline int run_one(const tfx_launch& l, void* s) {
       return tfx_adaln_post_pre_fwd((const tfx_adaln_post_args*)r->p0, (const tfx_adaln_pre_args*)r->p1, s);
     case TFX_OP_LAYER_END_FWD:
       return tfx_layer_end_fwd((const tfx_adaln_post_args*)r->p0, (const tfx_attnres_args*)r->p1, (const tfx_adaln_pre_args*)r->p2, s);
+    case TFX_OP_ATTNRES_PREP:
+      return tfx_attnres_prep((const tfx_attnres_src*)r->p0, (int32_t)r->i0, (int32_t)r->i1, s);
+    case TFX_OP_ATTNRES_FINISH:
+      return tfx_attnres_finish((const tfx_attnres_src*)r->p0, (int32_t)r->i0, (int32_t)r->i1, s);
+    case TFX_OP_ATTNRES_PULL_BWD:
+      return tfx_attnres_pull_bwd((const tfx_attnres_pull_args*)r->p0, (const tfx_adaln_post_args*)r->p1, s);
+    case TFX_OP_ADALN_PRE_POST_BWD:
+      return tfx_adaln_pre_post_bwd((const tfx_adaln_pre_args*)r->p0, (const tfx_adaln_post_args*)r->p1, s);
     case TFX_OP_CAST_BLOCK_BF16:
       return tfx_cast_block_bf16((const float*)r->p0, (int32_t)r->i0, (tfx_bf16*)r->p1, (int32_t)r->i1, (int32_t)r->i2, (int32_t)r->i3, s);
     case TFX_OP_SCALE_BF16_COPY:

@@ -177,6 +177,13 @@ template <int NC> __global__ __launch_bounds__(256) void adaln_pre_bwd_k(tfx_ada
     }
     c1 = wave_sum(c1) / d; c2 = wave_sum(c2) / d;
     Row<NC> dx; load_row(dx, p.dx + (size_t)t * d, d, lane);
+    if (p.dx_add) {
+      Row<NC> da; load_row(da, p.dx_add + (size_t)t * d, d, lane);
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) dx.v[i][e] += da.v[i][e];
+    }
 #pragma unroll
     for (int i = 0; i < NC; i++)
 #pragma unroll
@@ -321,7 +328,7 @@ template <int NC> __global__ __launch_bounds__(512) void adaln_pre_bwd_seg_k(tfx
     constexpr int U = NC == 1 ? 4 : (NC == 2 ? 2 : 1);
     const int tend = t0 + len;
     for (int tb = t0; tb < tend; tb += U) {
-      RowRaw<NC> xs[U], dus[U], dxs[U];                     // raw bf16: 12 prefetched rows cost 48 VGPRs, not 96
+      RowRaw<NC> xs[U], dus[U], dxs[U], das[U];             // raw bf16: 12 prefetched rows cost 48 VGPRs, not 96
       float means[U], rstds[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -329,6 +336,7 @@ template <int NC> __global__ __launch_bounds__(512) void adaln_pre_bwd_seg_k(tfx
         load_raw(xs[u], p.x + (size_t)t * d, d, lane);
         load_raw(dus[u], p.du + (size_t)t * d, d, lane);
         load_raw(dxs[u], p.dx + (size_t)t * d, d, lane);
+        if (p.dx_add) load_raw(das[u], p.dx_add + (size_t)t * d, d, lane);
         means[u] = p.mean[t]; rstds[u] = p.rstd[t];
       }
 #pragma unroll
@@ -337,6 +345,13 @@ template <int NC> __global__ __launch_bounds__(512) void adaln_pre_bwd_seg_k(tfx
         if (t >= tend) break;
         Row<NC> x, du, dx;
         widen(x, xs[u]); widen(du, dus[u]); widen(dx, dxs[u]);
+        if (p.dx_add) {
+          Row<NC> da; widen(da, das[u]);
+#pragma unroll
+          for (int i = 0; i < NC; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) dx.v[i][e] += da.v[i][e];
+        }
         const float mean = means[u], rstd = rstds[u];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -512,7 +527,7 @@ template <int NC> __global__ __launch_bounds__(256) void rmsnorm_bwd_k(tfx_rmsno
 // ------------------------------------------------------------------------------------------------
 // one step of the depth softmax (online form): fold hidden h into (o, m, den).  Shared by attnres_fwd_k and layer_end_fwd_k so that both
 // evaluate the very same expressions (the decode fusion must reproduce the separate kernels bit for bit)
-template <int NC> TFX_DEV void attnres_mix(const Row<NC>& h, const Row<NC>& w, Row<NC>& o, float& m, float& den) {
+template <int NC> TFX_DEV void attnres_mix(const Row<NC>& h, const Row<NC>& w, Row<NC>& o, float& m, float& den, float& s_out, float& inv_out) {
   // every multiply-add is spelled as an explicit fma: the compiler's own contraction choices depend on the surrounding code
   float nsq = 0.f, dt = 0.f;
 #pragma unroll
@@ -520,7 +535,9 @@ template <int NC> TFX_DEV void attnres_mix(const Row<NC>& h, const Row<NC>& w, R
 #pragma unroll
     for (int e = 0; e < 8; e++) { nsq = __builtin_fmaf(h.v[i][e], h.v[i][e], nsq); dt = __builtin_fmaf(h.v[i][e], w.v[i][e], dt); }
   nsq = wave_sum(nsq); dt = wave_sum(dt);
-  const float s = dt / fmaxf(sqrtf(nsq), 1e-12f);
+  const float nrm = fmaxf(sqrtf(nsq), 1e-12f);
+  const float s = dt / nrm;
+  s_out = s; inv_out = 1.f / nrm;
   const float mn = fmaxf(m, s);
   const float al = __expf(m - mn), ex = __expf(s - mn);
   den = __builtin_fmaf(den, al, ex); m = mn;
@@ -528,6 +545,17 @@ template <int NC> TFX_DEV void attnres_mix(const Row<NC>& h, const Row<NC>& w, R
   for (int i = 0; i < NC; i++)
 #pragma unroll
     for (int e = 0; e < 8; e++) { const float t = ex * h.v[i][e]; o.v[i][e] = __builtin_fmaf(o.v[i][e], al, t); }
+}
+
+template <int NC> TFX_DEV void attnres_mix(const Row<NC>& h, const Row<NC>& w, Row<NC>& o, float& m, float& den) {
+  float s, inv; attnres_mix<NC>(h, w, o, m, den, s, inv);
+}
+// the depth softmax of one token, kept for the pull-form backward: lane l holds (s_l, 1 / |h_l|) of hidden l
+TFX_DEV void attnres_save(float* save, int t, int L, int lane, float s_l, float inv_l, float m, float den) {
+  if (lane < L) {
+    f32x4 v = {__expf(s_l - m) / den, inv_l, s_l, 0.f};
+    *(f32x4*)(save + ((size_t)t * L + lane) * 4) = v;
+  }
 }
 
 template <int NC> __global__ __launch_bounds__(256) void attnres_fwd_k(tfx_attnres_args p) {
@@ -542,6 +570,7 @@ template <int NC> __global__ __launch_bounds__(256) void attnres_fwd_k(tfx_attnr
 #pragma unroll
     for (int e = 0; e < 8; e++) { w.v[i][e] = (1.f + w.v[i][e]) * pq.v[i][e]; o.v[i][e] = 0.f; }
   float m = -INFINITY, den = 0.f;
+  float s_l = 0.f, inv_l = 0.f;
   constexpr int PF = NC == 1 ? 4 : 2;          // rows requested before the first of them is reduced (see attnres_bwd_k)
   for (int l0 = 0; l0 < p.L; l0 += PF) {
     RowRaw<NC> hr[PF];
@@ -550,9 +579,14 @@ template <int NC> __global__ __launch_bounds__(256) void attnres_fwd_k(tfx_attnr
       if (l0 + j < p.L) load_raw(hr[j], p.hiddens + (size_t)(l0 + j) * p.stride_h + (size_t)t * d, d, lane);
 #pragma unroll
     for (int j = 0; j < PF; j++) {
-      if (l0 + j < p.L) { Row<NC> h; widen(h, hr[j]); attnres_mix<NC>(h, w, o, m, den); }
+      if (l0 + j < p.L) {
+        Row<NC> h; widen(h, hr[j]);
+        float sc, iv; attnres_mix<NC>(h, w, o, m, den, sc, iv);
+        if (lane == l0 + j) { s_l = sc; inv_l = iv; }
+      }
     }
   }
+  if (p.save) attnres_save(p.save, t, p.L, lane, s_l, inv_l, m, den);
   const float inv = 1.f / den;
 #pragma unroll
   for (int i = 0; i < NC; i++)
@@ -593,6 +627,7 @@ template <int NC> __global__ __launch_bounds__(256) void layer_end_fwd_k(tfx_ada
       for (int e = 0; e < 8; e++) { w.v[i][e] = (1.f + w.v[i][e]) * pq.v[i][e]; o.v[i][e] = 0.f; }
   }
   float m = -INFINITY, den = 0.f;
+  float s_l = 0.f, inv_l = 0.f;
   // the L - 1 stored hiddens are requested four at a time (raw bf16) before the first of the group is reduced: with up to 25 hiddens and a
   // handful of tokens per CU the loop is a chain of memory round trips otherwise (measured 17.5 us per launch at depth 24)
   for (int l0 = 0; l0 + 1 < a.L; l0 += 4) {
@@ -602,9 +637,17 @@ template <int NC> __global__ __launch_bounds__(256) void layer_end_fwd_k(tfx_ada
       if (l0 + j + 1 < a.L) load_raw(hr[j], a.hiddens + (size_t)(l0 + j) * a.stride_h + (size_t)t * d, d, lane);
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (l0 + j + 1 < a.L) { Row<NC> h; widen(h, hr[j]); attnres_mix<NC>(h, w, o, m, den); }
+      if (l0 + j + 1 < a.L) {
+        Row<NC> h; widen(h, hr[j]);
+        float sc, iv; attnres_mix<NC>(h, w, o, m, den, sc, iv);
+        if (lane == l0 + j) { s_l = sc; inv_l = iv; }
+      }
   }
-  attnres_mix<NC>(hn, w, o, m, den);
+  {
+    float sc, iv; attnres_mix<NC>(hn, w, o, m, den, sc, iv);
+    if (lane == a.L - 1) { s_l = sc; inv_l = iv; }
+  }
+  if (a.save) attnres_save(a.save, t, a.L, lane, s_l, inv_l, m, den);
   const float inv = 1.f / den;
   float sm = 0.f;
 #pragma unroll
@@ -729,6 +772,308 @@ template <int NC> __global__ __launch_bounds__(256) void attnres_bwd_k(tfx_attnr
 #pragma unroll
     for (int e = 0; e < 8; e++) tmp.v[i][e] = pw.v[i][e] * (1.f + gm.v[i][e]);
   flush_col_partials<NC>(tmp, p.dpq, d, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of two adjacent wrapper sides in one launch (include/tfx.h tfx_adaln_pre_post_bwd): adaln_pre_bwd_seg_k followed by
+// adaln_post_bwd_seg_k on the residual-gradient row it just produced (rounded to bf16 exactly as the second launch would read it back).
+// ------------------------------------------------------------------------------------------------
+template <int NC> __global__ __launch_bounds__(512) void adaln_pre_post_bwd_seg_k(tfx_adaln_pre_args p, tfx_adaln_post_args q) {
+  __shared__ float smem[SEG_WAVES * NC * 512];
+  const int lane = threadIdx.x & 63;
+  const int d = p.d;
+  Row<NC> pg, pl;                                           // text partials: d layernorm_gamma (pre), d layerscale (post)
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) { pg.v[i][e] = 0.f; pl.v[i][e] = 0.f; }
+  for (int s = blockIdx.x * SEG_WAVES + (threadIdx.x >> 6); s < p.n_seg; s += gridDim.x * SEG_WAVES) {
+    const int t0 = p.seg_start[s], len = p.seg_len[s];
+    const int inst = p.tok_inst[t0];
+    Row<NC> g, ag, ab, sc, az;
+    if (inst < 0) { load_vec(g, p.gamma_text, d, lane); load_vec(sc, q.layerscale, d, lane); }
+    else { load_vec(g, p.table + (size_t)inst * p.ld_table, d, lane); load_vec(sc, q.table + (size_t)inst * q.ld_table + 2 * d, d, lane); }
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        ag.v[i][e] = 0.f; ab.v[i][e] = 0.f; az.v[i][e] = 0.f;
+        sc.v[i][e] = inst < 0 ? 1.f + sc.v[i][e] : sigmoidf_(sc.v[i][e]);
+      }
+    constexpr int U = NC == 1 ? 4 : (NC == 2 ? 2 : 1);
+    const int tend = t0 + len;
+    for (int tb = t0; tb < tend; tb += U) {
+      RowRaw<NC> xs[U], dus[U], dxs[U], ys[U];
+      float means[U], rstds[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = min(tb + u, tend - 1);
+        load_raw(xs[u], p.x + (size_t)t * d, d, lane);
+        load_raw(dus[u], p.du + (size_t)t * d, d, lane);
+        load_raw(dxs[u], p.dx + (size_t)t * d, d, lane);
+        load_raw(ys[u], q.y + (size_t)t * d, d, lane);
+        means[u] = p.mean[t]; rstds[u] = p.rstd[t];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tb + u;
+        if (t >= tend) break;
+        Row<NC> x, du, dx;
+        widen(x, xs[u]); widen(du, dus[u]); widen(dx, dxs[u]);
+        const float mean = means[u], rstd = rstds[u];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          int c = lane + 64 * i;
+          if (c * 8 >= d) continue;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float xh = (x.v[i][e] - mean) * rstd;
+            ag.v[i][e] += du.v[i][e] * xh; ab.v[i][e] += du.v[i][e];
+            float dxh = du.v[i][e] * (1.f + g.v[i][e]);
+            c1 += dxh; c2 += dxh * xh;
+            x.v[i][e] = xh; du.v[i][e] = dxh;
+          }
+        }
+        c1 = wave_sum(c1) / d; c2 = wave_sum(c2) / d;
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) dx.v[i][e] = bf2f(f2bf(dx.v[i][e] + rstd * (du.v[i][e] - c1 - x.v[i][e] * c2)));
+        store_row(dx, p.dx + (size_t)t * d, d, lane);
+        // output side of the wrapper below: g = the row just written
+        Row<NC> yy; widen(yy, ys[u]);
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) { az.v[i][e] += dx.v[i][e] * yy.v[i][e]; dx.v[i][e] *= sc.v[i][e]; }
+        store_row(dx, q.dy + (size_t)t * d, d, lane);
+      }
+    }
+    if (inst < 0) {
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { pg.v[i][e] += ag.v[i][e]; pl.v[i][e] += az.v[i][e]; }
+    } else {
+      float* dt = p.dtable + (size_t)inst * p.ld_table;
+      float* dz = q.dtable + (size_t)inst * q.ld_table + 2 * d;
+#pragma unroll
+      for (int i = 0; i < NC; i++) {
+        int c = lane + 64 * i;
+        if (c * 8 >= d) continue;
+        f32x4 a0, a1, b0, b1, z0, z1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          a0[e] = ag.v[i][e]; a1[e] = ag.v[i][4 + e]; b0[e] = ab.v[i][e]; b1[e] = ab.v[i][4 + e];
+          z0[e] = az.v[i][e] * sc.v[i][e] * (1.f - sc.v[i][e]);
+          z1[e] = az.v[i][4 + e] * sc.v[i][4 + e] * (1.f - sc.v[i][4 + e]);
+        }
+        *(f32x4*)(dt + c * 8) = a0; *(f32x4*)(dt + c * 8 + 4) = a1;
+        *(f32x4*)(dt + d + c * 8) = b0; *(f32x4*)(dt + d + c * 8 + 4) = b1;
+        *(f32x4*)(dz + c * 8) = z0; *(f32x4*)(dz + c * 8 + 4) = z1;
+      }
+    }
+  }
+  flush_col_partials<NC>(pg, p.dgamma_text, d, smem);
+  flush_col_partials<NC>(pl, q.dlayerscale, d, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// AttentionResidual backward, pull form (include/tfx.h tfx_attnres_pull_bwd): the gradient of hidden l from every layer that mixed it,
+// optionally followed by the output side of the feed-forward wrapper that produced the hidden.
+//   NJ > 0: at most NJ sources, their d w partials live in registers and all NJ gradient rows of a token are requested at once;
+//   NJ == 0: any number of sources (<= 32), processed JC rows at a time, d w partials accumulate in LDS (ds_add_f32).
+// Dynamic LDS: [n_src][d] fp32 = the w rows (NJ > 0) or the d w accumulators (NJ == 0).
+// ------------------------------------------------------------------------------------------------
+constexpr int PULL_MAX_SRC = 32;
+template <int NC> TFX_DEV float row_dot(const Row<NC>& a, const Row<NC>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) s += a.v[i][e] * b.v[i][e];
+  return wave_sum(s);
+}
+TFX_DEV float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_bwd_k(tfx_attnres_pull_args p, tfx_adaln_post_args q, int has_post) {
+  extern __shared__ float dyn[];                            // [n_src][d]
+  __shared__ float smem[SEG_WAVES * NC * 512];
+  __shared__ tfx_attnres_src srcs[PULL_MAX_SRC];
+  constexpr bool REG = NJ > 0;
+  constexpr int JC = REG ? NJ : 4;
+  const int lane = threadIdx.x & 63;
+  const int d = p.d, ns = p.n_src;
+  for (int i = threadIdx.x; i < ns * (int)(sizeof(tfx_attnres_src) / 8); i += blockDim.x)
+    ((unsigned long long*)srcs)[i] = ((const unsigned long long*)p.src)[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < ns * d; i += blockDim.x) {
+    const int j = i / d, c = i - j * d;
+    dyn[i] = REG ? srcs[j].w[c] : 0.f;
+  }
+  __syncthreads();
+  Row<NC> pl, pb;
+  Row<NC> pw[REG ? NJ : 1];
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      pl.v[i][e] = 0.f; pb.v[i][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < (REG ? NJ : 1); j++) pw[j].v[i][e] = 0.f;
+    }
+  const bool tok_mode = p.n_seg <= 0;                        // no segments: one token per wave, per-token atomics for the table gradients
+  const int n_items = tok_mode ? p.T : p.n_seg;
+  for (int s = blockIdx.x * SEG_WAVES + (threadIdx.x >> 6); s < n_items; s += gridDim.x * SEG_WAVES) {
+    const int t0 = tok_mode ? s : p.seg_start[s], len = tok_mode ? 1 : p.seg_len[s];
+    const int inst = has_post ? q.tok_inst[t0] : -1;
+    Row<NC> sc, az;
+    if (has_post) {
+      if (inst < 0) load_vec(sc, q.layerscale, d, lane);
+      else load_vec(sc, q.table + (size_t)inst * q.ld_table + 2 * d, d, lane);
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { sc.v[i][e] = inst < 0 ? 1.f + sc.v[i][e] : sigmoidf_(sc.v[i][e]); az.v[i][e] = 0.f; }
+    }
+    const int tend = t0 + len;
+    for (int t = t0; t < tend; t++) {
+      // every row this token needs is requested before the first use (raw bf16: 4 * NC registers per row)
+      RowRaw<NC> hr, xo, ad, yr, gr[JC];
+      load_raw(hr, p.h + (size_t)t * d, d, lane);
+#pragma unroll
+      for (int jj = 0; jj < JC; jj++)
+        if (jj < ns) load_raw(gr[jj], srcs[jj].g + (size_t)t * d, d, lane);
+      if (p.out_own) load_raw(xo, p.out_own + (size_t)t * d, d, lane);
+      if (p.add) load_raw(ad, p.add + (size_t)t * d, d, lane);
+      if (has_post) load_raw(yr, q.y + (size_t)t * d, d, lane);
+      // lane k: the saved softmax state of source k at (t, l), and its <g, out>
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+      float dsl = 0.f;
+      if (lane < ns) {
+        sv = *(const f32x4*)(srcs[lane].save + ((size_t)t * srcs[lane].L + p.l) * 4);
+        if (lane > 0 || !p.out_own) dsl = srcs[lane].dsum[t];
+      }
+      Row<NC> h, G;
+      widen(h, hr);
+      if (p.add) widen(G, ad);
+      else {
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) G.v[i][e] = 0.f;
+      }
+      for (int j0 = 0; j0 < ns; j0 += JC) {
+        if (j0 > 0) {
+#pragma unroll
+          for (int jj = 0; jj < JC; jj++)
+            if (j0 + jj < ns) load_raw(gr[jj], srcs[j0 + jj].g + (size_t)t * d, d, lane);
+        }
+#pragma unroll
+        for (int jj = 0; jj < JC; jj++) {
+          const int j = j0 + jj;
+          if (j >= ns) break;
+          Row<NC> gj; widen(gj, gr[jj]);
+          const float da = row_dot<NC>(gj, h);
+          float dsum;
+          if (j == 0 && p.out_own) {
+            Row<NC> o; widen(o, xo);
+            dsum = row_dot<NC>(gj, o);
+            if (lane == 0) srcs[0].dsum[t] = dsum;
+          } else dsum = lane_bcast(dsl, j);
+          const float a = lane_bcast(sv[0], j), inv = lane_bcast(sv[1], j), sj = lane_bcast(sv[2], j);
+          const float ds = a * (da - dsum);
+          const float k1 = ds * inv, k2 = k1 * sj * inv;
+          const float* wj = REG ? (dyn + (size_t)j * d) : srcs[j].w;
+#pragma unroll
+          for (int i = 0; i < NC; i++) {
+            const int c = lane + 64 * i;
+            if (c * 8 >= d) continue;
+            const f32x4 w0 = *(const f32x4*)(wj + c * 8), w1 = *(const f32x4*)(wj + c * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const float we = e < 4 ? w0[e & 3] : w1[e & 3];
+              G.v[i][e] += a * gj.v[i][e] + k1 * we - k2 * h.v[i][e];
+              const float ph = k1 * h.v[i][e];
+              if constexpr (REG) pw[jj].v[i][e] += ph;
+              else atomicAdd(dyn + (size_t)j * d + c * 8 + e, ph);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) G.v[i][e] = bf2f(f2bf(G.v[i][e]));     // what the next kernel reads back
+      store_row(G, p.dh + (size_t)t * d, d, lane);
+      if (has_post) {
+        Row<NC> yy; widen(yy, yr);
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          const int c = lane + 64 * i;
+          if (c * 8 >= d) continue;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float gy = G.v[i][e] * yy.v[i][e];
+            if (tok_mode && inst >= 0) atomicAdd(q.dtable + (size_t)inst * q.ld_table + 2 * d + c * 8 + e, gy * sc.v[i][e] * (1.f - sc.v[i][e]));
+            else az.v[i][e] += gy;
+            G.v[i][e] *= sc.v[i][e]; pb.v[i][e] += G.v[i][e];
+          }
+        }
+        store_row(G, q.dy + (size_t)t * d, d, lane);
+      }
+    }
+    if (has_post) {
+      if (inst < 0) {
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) pl.v[i][e] += az.v[i][e];
+      } else if (!tok_mode) {
+        float* dt = q.dtable + (size_t)inst * q.ld_table + 2 * d;
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          int c = lane + 64 * i;
+          if (c * 8 >= d) continue;
+          f32x4 a0, a1;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            a0[e] = az.v[i][e] * sc.v[i][e] * (1.f - sc.v[i][e]);
+            a1[e] = az.v[i][4 + e] * sc.v[i][4 + e] * (1.f - sc.v[i][4 + e]);
+          }
+          *(f32x4*)(dt + c * 8) = a0; *(f32x4*)(dt + c * 8 + 4) = a1;
+        }
+      }
+    }
+  }
+  if (has_post) {
+    flush_col_partials<NC>(pl, q.dlayerscale, d, smem);
+    if (q.dbias) flush_col_partials<NC>(pb, q.dbias, d, smem);
+  }
+  if constexpr (REG) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+      if (j < ns) flush_col_partials<NC>(pw[j], srcs[j].dw, d, smem);
+  } else {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ns * d; i += blockDim.x) {
+      const int j = i / d, c = i - j * d;
+      const float v = dyn[i];
+      if (v != 0.f) atomicAdd(srcs[j].dw + c, v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attnres_prep_k(const tfx_attnres_src* src, int d) {
+  const tfx_attnres_src sj = src[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < d) { sj.w[c] = (1.f + sj.gamma[c]) * sj.pq[c]; sj.dw[c] = 0.f; }
+}
+__global__ __launch_bounds__(256) void attnres_finish_k(const tfx_attnres_src* src, int d) {
+  const tfx_attnres_src sj = src[blockIdx.y];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < d) { const float dw = sj.dw[c]; sj.dgamma[c] += dw * sj.pq[c]; sj.dpq[c] += dw * (1.f + sj.gamma[c]); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1279,6 +1624,40 @@ int tfx_attnres_fwd(const tfx_attnres_args* a, void* s) { if (a->L > 64) return 
 int tfx_attnres_bwd(const tfx_attnres_args* a, void* s) {
   if (a->L > 64) return -2;
   DISPATCH_NC(a->d, hipLaunchKernelGGL(attnres_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); RET();
+}
+int tfx_adaln_pre_post_bwd(const tfx_adaln_pre_args* a, const tfx_adaln_post_args* b, void* s) {
+  if (!a || !b || a->T != b->T || a->d != b->d || a->tok_inst != b->tok_inst || (const void*)a->dx != (const void*)b->g) return -2;
+  if (!a->seg_start || a->n_seg <= 0) {             // no segments: the two per-token launches
+    int rc = tfx_adaln_pre_bwd(a, s);
+    return rc ? rc : tfx_adaln_post_bwd(b, s);
+  }
+  if (a->dx_add || b->dbias) return -3;
+  DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(512), 0, ST(s), *a, *b)); RET();
+}
+int tfx_attnres_prep(const tfx_attnres_src* src, int32_t n, int32_t d, void* s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(attnres_prep_k, dim3((d + 255) / 256, n), dim3(256), 0, ST(s), src, d); RET();
+}
+int tfx_attnres_finish(const tfx_attnres_src* src, int32_t n, int32_t d, void* s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(attnres_finish_k, dim3((d + 255) / 256, n), dim3(256), 0, ST(s), src, d); RET();
+}
+int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_args* b, void* s) {
+  if (!a || a->n_src < 1 || a->n_src > PULL_MAX_SRC) return -2;
+  if (b && (b->T != a->T || b->d != a->d || (const void*)b->g != (const void*)a->dh)) return -3;
+  tfx_adaln_post_args none = {};
+  const int items = a->n_seg > 0 ? a->n_seg : a->T;
+  int grid = (items + 7) / 8; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+  const size_t dyn = (size_t)a->n_src * a->d * sizeof(float);
+  if (dyn > 100 * 1024) return -4;
+  if (a->d <= 512 && a->n_src <= 8) {
+    hipLaunchKernelGGL((attnres_pull_bwd_k<1, 8>), dim3(grid), dim3(512), dyn, ST(s), *a, b ? *b : none, b ? 1 : 0);
+  } else {
+    // d w accumulates in LDS: fewer, fatter blocks keep the closing atomics per launch down
+    if (grid > 512) grid = 512;
+    DISPATCH_NC(a->d, hipLaunchKernelGGL((attnres_pull_bwd_k<NC, 0>), dim3(grid), dim3(512), dyn, ST(s), *a, b ? *b : none, b ? 1 : 0));
+  }
+  RET();
 }
 int tfx_embed_fwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_embed_bwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_bwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }

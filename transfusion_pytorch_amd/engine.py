@@ -224,10 +224,15 @@ class Plan:
         self.loaded_structure = None
         self._seg_args = []
         self.seg_start = z(max(T, 1), dtype=torch.int32); self.seg_len = z(max(T, 1), dtype=torch.int32)
+        # AttentionResidual backward in pull form (tfx_attnres_pull_bwd): every layer's depth softmax is kept per token by the forward;
+        # TFX_ATTNRES_PULL=0 keeps the push form (tfx_attnres_bwd: one read-modify-write sweep over all earlier hiddens per layer; A/B)
+        self.pull = training and D <= 32 and os.environ.get('TFX_ATTNRES_PULL', '1') != '0'
+        if self.pull:
+            self.arsave = [e(T, i + 2, 4, dtype=torch.float32) for i in range(D)]
         self._build_forward()
         if training:
             self.dH = e(D + 1, T, d)
-            self.gx = e(T, d); self.du = e(T, d)
+            self.gx = {i: e(T, d) for i in range(D) if md.has_skip(i)}; self.du = e(T, d)
             # weight-gradient GEMMs run on a side stream one layer behind the data-gradient chain (TFX_SIDE_STREAM=0: one stream):
             # the buffers they read are kept per wrapper and double-buffered by layer parity
             # measured (A/B on one box): dim 512 -2 % step time, dim 768 +2 %, dim 1024 +4 % - with wider models the GEMMs dominate and two
@@ -366,7 +371,8 @@ class Plan:
             a_postf = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=self.xb[li], y=self.yf[li], out=self.hid[i + 1], tok_inst=self.tok_inst,
                                      table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
             a_ar = capi.make_args('tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
-                                  gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1])
+                                  gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1],
+                                  save=self.arsave[i] if self.pull else None)
             if fuse:
                 # the end of the layer is ONE launch - feed-forward output side, AttentionResidual, and (when the next layer reads
                 # the result directly, i.e. has no U-Net skip projection in front) the next layer's attention-side AdaLN-pre
@@ -559,6 +565,33 @@ class Plan:
         def sync(op, slot):
             if side:
                 L.append((op, slot))
+        pull = self.pull
+        if pull:
+            # pull-form AttentionResidual backward: one source record per layer (device array, lowest layer first) - the FINAL gradient of the
+            # layer's AttentionResidual output (the backward's last write to that buffer), its saved softmax state, its w = (1 + gamma) pq
+            self.dsum = torch.empty(D, T, device=ps.device, dtype=torch.float32)
+            self.wtab = torch.empty(2, D, d, device=ps.device, dtype=torch.float32)          # w rows | d w accumulators
+            self.nbytes += self.dsum.numel() * 4 + self.wtab.numel() * 4 + sum(t.numel() * 4 for t in self.arsave)
+            SRC = capi.STRUCTS['tfx_attnres_src']
+            recs = (SRC * D)()
+            for j in range(D):
+                pj = f'transformer.layers.{j}.3'
+                gj = self.gfin if j == D - 1 else (self.gx[j + 1] if md.has_skip(j + 1) else self.dH[j + 2])
+                for k, v in dict(g=gj, save=self.arsave[j], dsum=self.dsum[j], w=self.wtab[0, j], dw=self.wtab[1, j], gamma=pp(f'{pj}.norm_keys.gamma'),
+                                 pq=pp(f'{pj}.pseudo_queries'), dgamma=gp(f'{pj}.norm_keys.gamma'), dpq=gp(f'{pj}.pseudo_queries'), L=j + 2).items():
+                    setattr(recs[j], k, v.data_ptr() if hasattr(v, 'data_ptr') else v)
+            raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(recs), ctypes.sizeof(recs))), dtype=torch.uint8)
+            self._src_tab = raw.to(ps.device)
+            self._src_size = ctypes.sizeof(SRC)
+            self._raw(L, lib.tfx_attnres_prep, self._src_tab.data_ptr(), D, d)
+        def pull_args(l, out_own, add, dh):
+            """gradient of hidden l from the layers j >= max(l - 1, 0) that mixed it"""
+            j0 = max(l - 1, 0)
+            a = capi.make_args('tfx_attnres_pull_args', T=T, d=d, l=l, n_src=D - j0, h=self.hid[l], src=self._src_tab.data_ptr() + j0 * self._src_size,
+                               out_own=out_own, add=add, dh=dh, seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+            self._seg_args.append(a)
+            self._keep = getattr(self, '_keep', []) + [a]
+            return a
         for i in range(D - 1, -1, -1):
             p = f'transformer.layers.{i}'
             x_in = self.xres[i]
@@ -568,16 +601,24 @@ class Plan:
             dy_f, dy_a, dag, dqkvg = self.dy_f[par], self.dy_a[par], self.dag_p[par], self.dqkvg_p[par]
             if i + 2 <= D - 1:
                 sync('tfx_join_wait', i + 2)       # this layer reuses the buffers of layer i+2: its weight gradients must have read them
-            g2 = self.dskip[i + 1] if (i + 1) in pushed else None
-            self._k(L, 'tfx_attnres_bwd', 'tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
-                    gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), g=g, g2=capi.ptr(g2), dhiddens=self.dH, stride_dh=T * d,
-                    first=1 if i == D - 1 else 0, dgamma=gp(f'{p}.3.norm_keys.gamma'), dpq=gp(f'{p}.3.pseudo_queries'))
             G = self.dH[i + 1]
-            # ---- feedforward wrapper
-            self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.yf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
-                    layerscale=pp(f'{p}.2.layerscale'), g=G, dy=dy_f, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'),
-                    seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0, dbias=gp(f'{p}.2.fn.net.3.bias'))   # ff2 bias gradient = column sums of dy
-            self._seg_args.append(L[-1][1])
+            a_postf = capi.make_args('tfx_adaln_post_args', T=T, d=d, y=self.yf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
+                                     layerscale=pp(f'{p}.2.layerscale'), g=G, dy=dy_f, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'),
+                                     seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0, dbias=gp(f'{p}.2.fn.net.3.bias'))   # ff2 bias gradient = column sums of dy
+            self._seg_args.append(a_postf)
+            if pull:
+                # dH[i+1] = gradient of hidden i + 1 from the AttentionResiduals of layers i .. D-1 (all final), formed ONCE; the feed-forward
+                # wrapper's output side rides in the same launch
+                a_pull = pull_args(i + 1, self.xres[i + 1], None, G)
+                self._keep.append(a_postf)
+                self._raw(L, lib.tfx_attnres_pull_bwd, ctypes.addressof(a_pull), ctypes.addressof(a_postf))
+            else:
+                g2 = self.dskip[i + 1] if (i + 1) in pushed else None
+                self._k(L, 'tfx_attnres_bwd', 'tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
+                        gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), g=g, g2=capi.ptr(g2), dhiddens=self.dH, stride_dh=T * d,
+                        first=1 if i == D - 1 else 0, dgamma=gp(f'{p}.3.norm_keys.gamma'), dpq=gp(f'{p}.3.pseudo_queries'))
+                # ---- feedforward wrapper
+                L.append(('tfx_adaln_post_bwd', a_postf))
             self._nt(L, algo_n=di, A=dy_f, lda=d, B=S[f'ff2_t{i}'], ldb=d, M=T, N=dip, K=d, epi=E['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip,
                      aux=self.ag[i], ldaux=2 * dip)
             # the weight gradients of this wrapper go to the side stream (dy_f and d[a|g] are final); net.0 carries its bias gradient
@@ -587,15 +628,21 @@ class Plan:
             self._tn(L, T, 2 * dip, d, side=side, algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
                      C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias'))
             self._nt(L, algo_k=2 * di, A=dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
-            self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
-                    gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
-                    dtable=dtf, dgamma_text=gp(f'{p}.2.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
-            self._seg_args.append(L[-1][1])
+            a_pref = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
+                                    gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
+                                    dtable=dtf, dgamma_text=gp(f'{p}.2.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
             # ---- attention wrapper
-            self._k(L, 'tfx_adaln_post_bwd', 'tfx_adaln_post_args', T=T, d=d, y=self.ya[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
-                    layerscale=pp(f'{p}.1.layerscale'), g=G, dy=dy_a, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'),
-                    seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
-            self._seg_args.append(L[-1][1])
+            a_posta = capi.make_args('tfx_adaln_post_args', T=T, d=d, y=self.ya[i], tok_inst=self.tok_inst, table=ta, ld_table=nt3,
+                                     layerscale=pp(f'{p}.1.layerscale'), g=G, dy=dy_a, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'),
+                                     seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+            self._seg_args += [a_pref, a_posta]
+            if os.environ.get('TFX_BWD_FUSED', '1') != '0':
+                # input side of the feed-forward wrapper + output side of the attention wrapper: the residual-gradient row is written once, not read back
+                self._keep = getattr(self, '_keep', []) + [a_pref, a_posta]
+                self._raw(L, lib.tfx_adaln_pre_post_bwd, ctypes.addressof(a_pref), ctypes.addressof(a_posta))
+            else:
+                L.append(('tfx_adaln_pre_bwd', a_pref))
+                L.append(('tfx_adaln_post_bwd', a_posta))
             self._nt(L, algo_n=md.hd, A=dy_a, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
             self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
@@ -604,9 +651,11 @@ class Plan:
                     dqk=self.dqk, ld_dqk=2 * hd, dqkv=dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
             self._rope_args.append(L[-1][1])
             self._nt(L, algo_k=md.nq, A=dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
+            # (pull form: the gradient a U-Net skip hands to this layer's input joins here, so that G ends up as the TOTAL gradient of xres[i])
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, tok_inst=self.tok_inst, table=ta, ld_table=nt3,
                     gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i), du=self.du, dx=G,
-                    dtable=dta, dgamma_text=gp(f'{p}.1.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+                    dtable=dta, dgamma_text=gp(f'{p}.1.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0,
+                    dx_add=self.dskip[i] if (pull and i in pushed) else None)
             self._seg_args.append(L[-1][1])
             # weight gradients of the attention wrapper (dy_a, d[q|k|v|gates] and G = dH[i+1] are final) on the side stream
             sync('tfx_fork', 2 * i + 1)
@@ -639,16 +688,21 @@ class Plan:
                     self.bwd_cuts.append((len(L), i, min(i + per, D) - 1))
             if md.has_skip(i):
                 st = S[f'skip_t{i}']
-                self._nt(L, A=G, lda=d, B=st, ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.gx, ldc=d, R=G, ldr=d)
+                self._nt(L, A=G, lda=d, B=st, ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.gx[i], ldc=d, R=G, ldr=d)
                 self._nt(L, A=G, lda=d, B=st[d:], ldb=d, M=T, N=d, K=d, epi=E['TFX_EPI_BF16'], C=self.dskip[src[i]], ldc=d)
-                g = self.gx
+                g = self.gx[i]
             else:
                 g = G
         sync('tfx_join', 63)                       # every weight gradient is complete before the list returns
         # ---- gradient wrt the transformer input x0 = hid[0] = xres[0]
-        self._raw(L, lib.tfx_add_bf16, g.data_ptr(), self.dH[0].data_ptr(), self.dx0.data_ptr(), T * d)
-        if 0 in pushed:
-            self._raw(L, lib.tfx_add_bf16, self.dx0.data_ptr(), self.dskip[0].data_ptr(), self.dx0.data_ptr(), T * d)
+        if pull:
+            a_pull = pull_args(0, None, g, self.dx0)              # hidden 0 = the transformer input: every layer mixed it; + the chain gradient g
+            self._raw(L, lib.tfx_attnres_pull_bwd, ctypes.addressof(a_pull), None)
+            self._raw(L, lib.tfx_attnres_finish, self._src_tab.data_ptr(), D, d)
+        else:
+            self._raw(L, lib.tfx_add_bf16, g.data_ptr(), self.dH[0].data_ptr(), self.dx0.data_ptr(), T * d)
+            if 0 in pushed:
+                self._raw(L, lib.tfx_add_bf16, self.dx0.data_ptr(), self.dskip[0].data_ptr(), self.dx0.data_ptr(), T * d)
         self._raw(L, lib.tfx_onehot_bf16, self.text_ids.data_ptr(), self.tok_inst.data_ptr(), self.onehot.data_ptr(), T, md.vp)
         self._tn(L, T, md.vocab, d, A=self.onehot, lda=md.vp, a_cols=md.vp, B=self.dx0, ldb=d, b_cols=d, C=gp('text_embed.weight'), ldc=d)
         for t, r in self.R.items():

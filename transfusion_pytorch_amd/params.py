@@ -92,9 +92,13 @@ def param_specs(md: ModelDims):
                   (f'{p}.1.layernorm_gamma', (d,)), (f'{p}.1.layerscale', (d,)),
                   (f'{p}.2.layernorm_gamma', (d,)), (f'{p}.2.layerscale', (d,)),
                   (f'{p}.2.fn.net.0.weight', (2 * di, d)), (f'{p}.2.fn.net.0.bias', (2 * di,)),
-                  (f'{p}.2.fn.net.3.weight', (d, di)), (f'{p}.2.fn.net.3.bias', (d,)),
-                  (f'{p}.3.pseudo_queries', (d,)), (f'{p}.3.norm_keys.gamma', (d,))]
+                  (f'{p}.2.fn.net.3.weight', (d, di)), (f'{p}.2.fn.net.3.bias', (d,))]
     specs.append(('transformer.norm.gamma', (d,)))
+    # the AttentionResidual parameters sit behind the layer blocks: layer j's AttentionResidual mixes every earlier hidden, so in the pull-form
+    # backward (engine.Plan, tfx_attnres_pull_bwd) its gradient keeps receiving terms until the backward reaches hidden 0 - it is final with the
+    # embeddings, not with its layer, and travels in the tail of the overlapped gradient exchange (optim.GradReducer)
+    for i in range(D):
+        specs += [(f'transformer.layers.{i}.3.pseudo_queries', (d,)), (f'transformer.layers.{i}.3.norm_keys.gamma', (d,))]
     for t, dl in enumerate(md.dim_latents):
         if t in md.ext_types:
             continue
