@@ -183,6 +183,7 @@ typedef struct {
   /* forward, optional (training plans): the depth softmax of every token is kept for the pull-form backward (tfx_attnres_pull_bwd):
    * save[(t * L + l) * 4 + {0, 1, 2}] = softmax weight a_l, 1 / |h_l|, score s_l = <h_l, w> / |h_l| */
   float* save;
+  tfx_bf16* err;                              /* with `save`: [T,d] what the bf16 rounding of `out` dropped (exact mix - stored out), for <g, out> in the backward */
 } tfx_attnres_args;
 int tfx_attnres_fwd(const tfx_attnres_args* a, void* stream);
 int tfx_attnres_bwd(const tfx_attnres_args* a, void* stream);
@@ -202,7 +203,7 @@ int tfx_layer_end_fwd(const tfx_adaln_post_args* post, const tfx_attnres_args* a
  * With `post` the feed-forward wrapper's output side (tfx_adaln_post_bwd on g = the dh_l just written) runs in the same launch. */
 typedef struct {
   const tfx_bf16* g;                          /* [T,d] gradient wrt the output of this layer's AttentionResidual (final) */
-  const float* save;                          /* [T, L, 4] its saved forward state (tfx_attnres_args.save) */
+  float* save;                                /* [T, L, 4] its saved forward state (tfx_attnres_args.save); entry [t][0][3] receives <g, out> in the backward */
   float* dsum;                                /* [T] <g, out>: written by the launch that lists this layer first with `out_own`, read by later ones */
   float* w; float* dw;                        /* [d] fp32: (1 + gamma) * pseudo_queries (tfx_attnres_prep); its gradient accumulator (atomics) */
   const float* gamma; const float* pq;        /* norm_keys.gamma, pseudo_queries [d] */
@@ -214,9 +215,14 @@ typedef struct {
   const tfx_bf16* h;                          /* [T,d] hidden l */
   const tfx_attnres_src* src;                 /* DEVICE array [n_src], lowest layer first */
   const tfx_bf16* out_own;                    /* optional [T,d]: the forward output of src[0]'s AttentionResidual - its dsum is formed here */
+  const tfx_bf16* out_err;                    /* optional [T,d]: what rounding that output to bf16 dropped (tfx_attnres_args.err) */
   const tfx_bf16* add;                        /* optional [T,d] addend (gradient that reaches the hidden directly) */
   tfx_bf16* dh;                               /* [T,d] result (stored) */
   const int32_t* seg_start; const int32_t* seg_len; int32_t n_seg;   /* token segments (tfx_adaln_pre_args); n_seg == 0: one token per wave */
+  /* d w of the sources: with k1 == NULL (allowed for n_src <= 8, d <= 512) it accumulates inside the launch into src[j].dw; otherwise the launch
+   * only writes k1[t * ld_k1 + j] = the per-token coefficient of source j (bf16, ld_k1 >= n_src, a multiple of 8) and the caller adds
+   * dw[j] += sum_t k1[t][j] h[t]  with one tfx_gemm_tn (A = k1, B = h, C = src[0].dw, ldc = d: the dw rows of consecutive sources are contiguous) */
+  tfx_bf16* k1; int32_t ld_k1;
 } tfx_attnres_pull_args;
 int tfx_attnres_prep(const tfx_attnres_src* src_dev, int32_t n, int32_t d, void* stream);     /* w = (1 + gamma) pq ; dw = 0, for n layers */
 int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_args* post, void* stream);
@@ -301,6 +307,10 @@ int tfx_output_to_flow(float* pred, const float* x, const float* eps, const int3
  * untouched (active NULL = all rows).  out_ids: int32 [B]. */
 int tfx_sample_tokens(const float* logits, int32_t ld, int32_t B, int32_t V, float temperature, float min_p, const float* uniforms,
                       const int32_t* active, int32_t* out_ids, void* stream);
+/* the same with the DRAW restricted to the first V_draw columns while the maximum (hence the min-p threshold, and the argmax at temperature 0)
+ * still runs over all V: `generate_text_only` (T:2690-2698) filters over every logit, then masks everything but the text tokens */
+int tfx_sample_tokens_range(const float* logits, int32_t ld, int32_t B, int32_t V, int32_t V_draw, float temperature, float min_p, const float* uniforms,
+                            const int32_t* active, int32_t* out_ids, void* stream);
 /* ODE state update of the fixed-grid midpoint solver (torchdiffeq semantics; T:2468-2525) fused with classifier-free
  * guidance (T:2516-2521): f = f_uncond ? f_uncond + cfg_scale * (f_cond - f_uncond) : f_cond;  out = y + a * f   (fp32, n elements) */
 int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, float cfg_scale, float a, float* out, int64_t n, void* stream);

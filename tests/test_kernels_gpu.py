@@ -667,10 +667,10 @@ def test_attnres_pull_backward_stack(T, d, D, segs, post):
     gm = torch.randn(D, d, device=DEV) * 0.3; pq = torch.randn(D, d, device=DEV) * 0.5
     G = rnd(D, T, d)                                              # gradient wrt the output of layer j's AttentionResidual
     extra = rnd(T, d)                                             # direct gradient of hidden 0
-    outs = torch.zeros(D, T, d, device=DEV, dtype=BF)
+    outs = torch.zeros(D, T, d, device=DEV, dtype=BF); errs = torch.zeros(D, T, d, device=DEV, dtype=BF)
     saves = [torch.zeros(T, j + 2, 4, device=DEV) for j in range(D)]
     for j in range(D):
-        a = capi.make_args('tfx_attnres_args', T=T, d=d, L=j + 2, hiddens=H, stride_h=T * d, gamma=gm[j], pq=pq[j], out=outs[j], save=saves[j])
+        a = capi.make_args('tfx_attnres_args', T=T, d=d, L=j + 2, hiddens=H, stride_h=T * d, gamma=gm[j], pq=pq[j], out=outs[j], save=saves[j], err=errs[j])
         capi.call('tfx_attnres_fwd', a, stream())
     # reference
     Hr = H.float().requires_grad_(True); gr = gm.clone().requires_grad_(True); pr = pq.clone().requires_grad_(True)
@@ -701,10 +701,13 @@ def test_attnres_pull_backward_stack(T, d, D, segs, post):
     dH = torch.full((D + 1, T, d), float('nan'), device=DEV, dtype=BF)
     ld = 3 * d + 8
     table = torch.randn(I, ld, device=DEV) * 0.5; ls = torch.randn(d, device=DEV) * 0.3; y = rnd(T, d)
+    k1 = torch.full((T, 32), float('nan'), device=DEV, dtype=BF)
     for l in range(D, -1, -1):
         j0 = max(l - 1, 0)
+        export = (D - j0) > 8 or d > 512          # d w = K1^T . h by one weight-gradient GEMM behind the launch (include/tfx.h tfx_attnres_pull_args.k1)
         a = capi.make_args('tfx_attnres_pull_args', T=T, d=d, l=l, n_src=D - j0, h=H[l], src=tab.data_ptr() + j0 * ctypes.sizeof(SRC),
-                           out_own=outs[l - 1] if l >= 1 else None, add=extra if l == 0 else None, dh=dH[l], **seg)
+                           out_own=outs[l - 1] if l >= 1 else None, out_err=errs[l - 1] if l >= 1 else None, add=extra if l == 0 else None, dh=dH[l],
+                           k1=k1 if export else None, ld_k1=32, **seg)
         if post and l == D:
             dy = torch.zeros(T, d, device=DEV, dtype=BF); dt = torch.zeros_like(table); dls = torch.zeros(d, device=DEV); db = torch.zeros(d, device=DEV)
             b = capi.make_args('tfx_adaln_post_args', T=T, d=d, y=y, tok_inst=tok_inst, table=table, ld_table=ld, layerscale=ls, g=dH[l], dy=dy,
@@ -718,6 +721,10 @@ def test_attnres_pull_backward_stack(T, d, D, segs, post):
             check('fused output side dtable', dt, dt2, 1e-5); check('fused dlayerscale', dls, dls2, 1e-5); check('fused dbias', db, db2, 1e-5)
         else:
             capi.check(lib.tfx_attnres_pull_bwd(ctypes.byref(a), None, stream()), 'pull')
+        if export:
+            tn = capi.make_args('tfx_gemm_tn_args', A=k1, lda=32, a_cols=32, B=H[l], ldb=d, b_cols=d, M=T, N=D - j0, K=d, C=wtab[1, j0], ldc=d,
+                                k_valid=d, splits=8, accumulate=1, alpha=1.0)
+            capi.call('tfx_gemm_tn', tn, stream())
     capi.check(lib.tfx_attnres_finish(tab.data_ptr(), D, d, stream()), 'finish')
     torch.cuda.synchronize()
     for l in range(D + 1):

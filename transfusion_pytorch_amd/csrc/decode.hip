@@ -10,7 +10,7 @@ namespace tfx {
 //                      cumulative mass crossing u * (total surviving mass) is drawn (inverse CDF in index order - the same
 //                      distribution torch.multinomial samples from)
 __global__ __launch_bounds__(256) void sample_tokens_k(const float* logits, int ld, int B, int V, float temperature, float min_p, const float* uniforms,
-                                                       const int* active, int* out_ids) {
+                                                       const int* active, int* out_ids, int V_draw) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= B) return;
   if (active && !active[row]) return;
@@ -27,16 +27,16 @@ __global__ __launch_bounds__(256) void sample_tokens_k(const float* logits, int 
   // pass 2: surviving mass.  p_c / p_max = exp((l_c - l_max) / T): the min-p test needs no normaliser
   const float it = 1.f / temperature;
   float mass = 0.f;
-  for (int c = lane; c < V; c += 64) { const float r = __expf((lg[c] - best) * it); mass += r >= min_p ? r : 0.f; }
+  for (int c = lane; c < V_draw; c += 64) { const float r = __expf((lg[c] - best) * it); mass += r >= min_p ? r : 0.f; }
   mass = wave_sum(mass);
   // pass 3: inverse CDF in index order, 64 columns per step with a wave prefix sum
   const float target = uniforms[row] * mass;
   float run = 0.f; int pick = bi;                       // falls back to the mode if rounding leaves the target unreached
   bool done = false;
-  for (int c0 = 0; c0 < V && !done; c0 += 64) {
+  for (int c0 = 0; c0 < V_draw && !done; c0 += 64) {
     const int c = c0 + lane;
     float r = 0.f;
-    if (c < V) { r = __expf((lg[c] - best) * it); r = r >= min_p ? r : 0.f; }
+    if (c < V_draw) { r = __expf((lg[c] - best) * it); r = r >= min_p ? r : 0.f; }
     float pre = r;                                      // inclusive prefix sum across the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(pre, o, 64); if (lane >= o) pre += t; }
@@ -204,7 +204,14 @@ int tfx_sample_tokens(const float* logits, int32_t ld, int32_t B, int32_t V, flo
   if (!logits || !out_ids || V <= 0 || ld < V) return -1;
   if (temperature != 0.f && !uniforms) return -2;
   if (temperature < 0.f) return -3;
-  hipLaunchKernelGGL(sample_tokens_k, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, B, V, temperature, min_p, uniforms, active, out_ids);
+  hipLaunchKernelGGL(sample_tokens_k, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, B, V, temperature, min_p, uniforms, active, out_ids, V);
+  return (int)hipGetLastError();
+}
+int tfx_sample_tokens_range(const float* logits, int32_t ld, int32_t B, int32_t V, int32_t V_draw, float temperature, float min_p, const float* uniforms,
+                            const int32_t* active, int32_t* out_ids, void* s) {
+  if (B <= 0) return 0;
+  if (!logits || !out_ids || V <= 0 || V_draw <= 0 || V_draw > V || ld < V || (temperature != 0.f && !uniforms)) return -1;
+  hipLaunchKernelGGL(sample_tokens_k, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)s, logits, ld, B, V, temperature, min_p, uniforms, active, out_ids, V_draw);
   return (int)hipGetLastError();
 }
 int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, float cfg_scale, float a, float* out, int64_t n, void* s) {

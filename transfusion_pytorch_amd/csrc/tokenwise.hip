@@ -1,6 +1,10 @@
 // Token-wise (HBM-bound) kernels: one 64-lane wave per token row, 16-byte bf16x8 accesses, wavefront
 // shuffle reductions.  A lane owns chunks c = lane + 64*i (8 contiguous elements each), i < NC.
 #include "tfx_kernels.h"
+#include <map>
+#include <mutex>
+#include <utility>
+#include <cstdlib>
 
 namespace tfx {
 
@@ -63,6 +67,12 @@ template <int NC> TFX_DEV void load_raw(RowRaw<NC>& r, const bf16* p, int d, int
       for (int e = 0; e < 8; e++) r.v[i][e] = f2bf(0.f);
     }
   }
+}
+// no instruction: what is computed from the row afterwards cannot be scheduled above this point (keeps prefetched rows in their 4-register
+// raw form until their turn instead of widening all of them as soon as they land)
+template <int NC> TFX_DEV void pin_raw(RowRaw<NC>& r) {
+#pragma unroll
+  for (int i = 0; i < NC; i++) asm volatile("" : "+v"(r.v[i]));
 }
 template <int NC> TFX_DEV void widen(Row<NC>& o, const RowRaw<NC>& r) {
 #pragma unroll
@@ -593,6 +603,13 @@ template <int NC> __global__ __launch_bounds__(256) void attnres_fwd_k(tfx_attnr
 #pragma unroll
     for (int e = 0; e < 8; e++) o.v[i][e] *= inv;
   store_row(o, p.out + (size_t)t * d, d, lane);
+  if (p.err) {
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) o.v[i][e] -= bf2f(f2bf(o.v[i][e]));
+    store_row(o, p.err + (size_t)t * d, d, lane);
+  }
 }
 
 // decode steps: end of a layer in one launch (include/tfx.h tfx_layer_end_fwd): h = x + y * scale ; out = AttentionResidual(h_0 .. h_{L-2}, h) ;
@@ -650,6 +667,14 @@ template <int NC> __global__ __launch_bounds__(256) void layer_end_fwd_k(tfx_ada
   if (a.save) attnres_save(a.save, t, a.L, lane, s_l, inv_l, m, den);
   const float inv = 1.f / den;
   float sm = 0.f;
+  if (a.err) {                                               // what the rounding of the output drops (training plans; see tfx_attnres_args.err)
+    Row<NC> er;
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const float ex = o.v[i][e] * inv; er.v[i][e] = ex - bf2f(f2bf(ex)); }
+    store_row(er, a.err + (size_t)t * d, d, lane);
+  }
 #pragma unroll
   for (int i = 0; i < NC; i++)
 #pragma unroll
@@ -897,7 +922,9 @@ template <int NC> TFX_DEV float row_dot(const Row<NC>& a, const Row<NC>& b) {
 }
 TFX_DEV float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
-template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_bwd_k(tfx_attnres_pull_args p, tfx_adaln_post_args q, int has_post) {
+// register form, kept for A/B (TFX_PULL_VARIANT=1): at most NJ sources, d w partials in registers, w rows in LDS, every row of a token requested
+// at once and held in registers until used (255 registers: two waves per SIMD, bytes in flight only while a wave waits)
+template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_reg_k(tfx_attnres_pull_args p, tfx_adaln_post_args q, int has_post) {
   extern __shared__ float dyn[];                            // [n_src][d]
   __shared__ float smem[SEG_WAVES * NC * 512];
   __shared__ tfx_attnres_src srcs[PULL_MAX_SRC];
@@ -940,12 +967,12 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_bw
     const int tend = t0 + len;
     for (int t = t0; t < tend; t++) {
       // every row this token needs is requested before the first use (raw bf16: 4 * NC registers per row)
-      RowRaw<NC> hr, xo, ad, yr, gr[JC];
+      RowRaw<NC> hr, xo, xe, ad, yr, gr[JC];
       load_raw(hr, p.h + (size_t)t * d, d, lane);
 #pragma unroll
       for (int jj = 0; jj < JC; jj++)
         if (jj < ns) load_raw(gr[jj], srcs[jj].g + (size_t)t * d, d, lane);
-      if (p.out_own) load_raw(xo, p.out_own + (size_t)t * d, d, lane);
+      if (p.out_own) { load_raw(xo, p.out_own + (size_t)t * d, d, lane); if (p.out_err) load_raw(xe, p.out_err + (size_t)t * d, d, lane); }
       if (p.add) load_raw(ad, p.add + (size_t)t * d, d, lane);
       if (has_post) load_raw(yr, q.y + (size_t)t * d, d, lane);
       // lane k: the saved softmax state of source k at (t, l), and its <g, out>
@@ -979,8 +1006,15 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_bw
           float dsum;
           if (j == 0 && p.out_own) {
             Row<NC> o; widen(o, xo);
+            if (p.out_err) {
+              Row<NC> oe; widen(oe, xe);
+#pragma unroll
+              for (int i = 0; i < NC; i++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) o.v[i][e] += oe.v[i][e];
+            }
             dsum = row_dot<NC>(gj, o);
-            if (lane == 0) srcs[0].dsum[t] = dsum;
+            if (lane == 0) { srcs[0].dsum[t] = dsum; srcs[0].save[(size_t)t * srcs[0].L * 4 + 3] = dsum; }   // (the ring form reads it from the saved state)
           } else dsum = lane_bcast(dsl, j);
           const float a = lane_bcast(sv[0], j), inv = lane_bcast(sv[1], j), sj = lane_bcast(sv[2], j);
           const float ds = a * (da - dsum);
@@ -1062,6 +1096,291 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_bw
       const float v = dyn[i];
       if (v != 0.f) atomicAdd(srcs[j].dw + c, v);
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Pull form, LDS-DMA ring (the product form).  The kernels above keep the rows of a token in registers between request and use, so a wave has
+// bytes in flight only while it waits (and the register forms run at two waves per SIMD): 3.2 TB/s.  Here every row a wave will need - the
+// hidden, the n_src gradient rows, the forward output and its rounding residual, the wrapper's y, the per-source scalars, the segment's scale
+// row - is one entry of a fixed ORDER known in advance, and the wave streams that order through a private ring of LDS slots with
+// global_load_lds_dwordx4 (no registers, no waiting): the DMA of row r + AHEAD is issued when row r is consumed, `s_waitcnt vmcnt(AHEAD * NC)`
+// certifies row r (vmcnt retires in order; any other memory operation issued in between only makes the wait conservative).
+//   stream of a wave:  per segment [scale row: 2 slots, fp32] (with the wrapper's output side), then per token
+//                      [scalars][h][out][out residual][addend][y] (those present) [g_0] .. [g_{ns-1}]
+//   d w = sum_t sum_l k1 h:  NJ > 0 - at most NJ sources, per-lane partials in registers (the j loop is unrolled);
+//                            NJ == 0 - any number of sources: the k1 of every (token, source) are written out as a bf16 [T, ld_k1] matrix and
+//                            d w += K1^T H is one weight-gradient GEMM behind the launch (tfx_gemm_tn; ds_add_f32 accumulators in LDS were
+//                            measured at ~200 clocks per wave instruction - 4.5x the whole kernel)
+//   w rows: fp32 in LDS, or bf16 (W16) when fp32 would leave the rings too few slots
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+template <int NC> TFX_DEV void ring_raw(RowRaw<NC>& r, const lds_u8* slot, int lane, int d) {
+#pragma unroll
+  for (int i = 0; i < NC; i++) {
+    if ((lane + 64 * i) * 8 < d) r.v[i] = *(const __attribute__((address_space(3))) bf16x8*)(slot + i * 1024 + lane * 16);
+    else {                                                      // past the end of a row narrower than NC * 512: zeros (the DMA fetched a dummy there)
+#pragma unroll
+      for (int e = 0; e < 8; e++) r.v[i][e] = f2bf(0.f);
+    }
+  }
+}
+template <int NC, int AHEAD, bool W16, int NJ>
+__global__ __launch_bounds__(512) void attnres_pull_dma_k(tfx_attnres_pull_args p, tfx_adaln_post_args q, int has_post) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char dynb[];
+  __shared__ tfx_attnres_src srcs[PULL_MAX_SRC];
+  __shared__ unsigned long long rbase[8 + PULL_MAX_SRC];          // row k >= 1 of a token: base pointer (every row advances d * 2 bytes per token)
+  constexpr int RING = AHEAD + 1, SLOT = NC * 1024;
+  constexpr bool REG = NJ > 0;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int d = p.d, ns = p.n_src;
+  const size_t wbytes = (((size_t)ns * d * (W16 ? 2 : 4)) + 1023) & ~(size_t)1023;
+  lds_u8* ring = (lds_u8*)dynb + wbytes + (size_t)wave * RING * SLOT;
+  for (int i = threadIdx.x; i < ns * (int)(sizeof(tfx_attnres_src) / 8); i += blockDim.x)
+    ((unsigned long long*)srcs)[i] = ((const unsigned long long*)p.src)[i];
+  __syncthreads();
+  // row table of a token: k = 0 scalars (special), 1 h, then the optional fixed rows, then the sources
+  const int own = p.out_own != nullptr, has_err = own && p.out_err != nullptr, has_add = p.add != nullptr;
+  const int k_out = 2, k_err = k_out + own, k_add = k_err + has_err, k_y = k_add + has_add, k_src = k_y + (has_post ? 1 : 0);
+  const int nr = k_src + ns;
+  if (threadIdx.x == 0) {
+    rbase[1] = (unsigned long long)p.h;
+    if (own) rbase[k_out] = (unsigned long long)p.out_own;
+    if (has_err) rbase[k_err] = (unsigned long long)p.out_err;
+    if (has_add) rbase[k_add] = (unsigned long long)p.add;
+    if (has_post) rbase[k_y] = (unsigned long long)q.y;
+  }
+  for (int j = threadIdx.x; j < ns; j += blockDim.x) rbase[k_src + j] = (unsigned long long)srcs[j].g;
+  for (int i = threadIdx.x; i < ns * d; i += blockDim.x) {
+    const int j = i / d, c = i - j * d;
+    if (W16) ((bf16*)dynb)[i] = f2bf(srcs[j].w[c]); else ((float*)dynb)[i] = srcs[j].w[c];
+  }
+  __syncthreads();
+
+  const bool tok_mode = p.n_seg <= 0;
+  const int n_items = tok_mode ? p.T : p.n_seg;
+  const int stride_items = gridDim.x * SEG_WAVES;
+  const int hdr = has_post ? -2 : 0;                            // header rows of a segment: the scale row (fp32 d floats = 2 slots)
+  // ---- issue side: walks the same (segment, token, row) order AHEAD rows in front of the consumer
+  int is_ = blockIdx.x * SEG_WAVES + wave, it_ = 0, itend = 0, ik = 0, islot = 0;
+  const float* iscp = nullptr;                                  // scale row of the issue side's segment
+  bool ilive = is_ < n_items;
+  auto seg_open = [&](int s, int& t0, int& tend) {
+    t0 = tok_mode ? s : p.seg_start[s];
+    tend = t0 + (tok_mode ? 1 : p.seg_len[s]);
+  };
+  auto scale_row = [&](int t0) -> const float* {
+    const int inst = q.tok_inst[t0];
+    return inst < 0 ? q.layerscale : q.table + (size_t)inst * q.ld_table + 2 * d;
+  };
+  if (ilive) { seg_open(is_, it_, itend); ik = hdr; if (has_post) iscp = scale_row(it_); }
+  auto issue_one = [&]() {
+    lds_u8* dst = ring + islot * SLOT;
+    islot = islot + 1 == RING ? 0 : islot + 1;
+#pragma unroll
+    for (int pc = 0; pc < NC; pc++) {
+      const bf16* gp = p.h;                                     // (any valid address: what lands is never read)
+      if (ilive) {
+        if (ik < 0) {                                           // scale row, half (ik + 2): floats [half * d/2, ...)
+          const int f = pc * 256 + lane * 4;
+          if (f < (d >> 1)) gp = (const bf16*)(iscp + (ik + 2) * (d >> 1) + f);
+        } else if (ik == 0) {                                   // lane k: saved state of source k at (t, l); lane 32 + k: its entry 0 (carries <g, out>)
+          if (pc == 0 && lane < ns) gp = (const bf16*)(srcs[lane].save + ((size_t)it_ * srcs[lane].L + p.l) * 4);
+          else if (pc == 0 && lane >= 32 && lane - 32 < ns) gp = (const bf16*)(srcs[lane - 32].save + (size_t)it_ * srcs[lane - 32].L * 4);
+        } else {
+          const int col = (pc * 64 + lane) * 8;
+          if (col < d) gp = (const bf16*)rbase[ik] + (size_t)it_ * d + col;
+        }
+      }
+      glds16_asm(gp, (const bf16*)(dst + pc * 1024));
+    }
+    if (ilive) {
+      ik++;
+      if (ik == nr) {
+        it_++;
+        if (it_ < itend) ik = 0;
+        else {
+          is_ += stride_items;
+          ilive = is_ < n_items;
+          if (ilive) { seg_open(is_, it_, itend); ik = hdr; if (has_post) iscp = scale_row(it_); }
+        }
+      }
+    }
+  };
+  int cslot = 0;
+  auto acquire = [&]() -> const lds_u8* {
+    issue_one();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * NC) : "memory");
+    const lds_u8* sp = ring + cslot * SLOT;
+    cslot = cslot + 1 == RING ? 0 : cslot + 1;
+    return sp;
+  };
+#pragma unroll 1
+  for (int i = 0; i < AHEAD; i++) issue_one();
+
+  Row<NC> pl, pb;
+  Row<NC> pw[REG ? NJ : 1];
+#pragma unroll
+  for (int i = 0; i < NC; i++)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      pl.v[i][e] = 0.f; pb.v[i][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < (REG ? NJ : 1); j++) pw[j].v[i][e] = 0.f;
+    }
+  for (int s = blockIdx.x * SEG_WAVES + wave; s < n_items; s += stride_items) {
+    int t0, tend; seg_open(s, t0, tend);
+    const int inst = has_post ? q.tok_inst[t0] : -1;
+    Row<NC> sc, az;
+    if (has_post) {
+      // (a slot is valid until the NEXT acquire - that one re-issues into it: each half is read right behind its own acquire)
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const lds_u8* sh = acquire();
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          const int f0 = (lane + 64 * i) * 8 - half * (d >> 1);   // this lane's first column, relative to the half
+          if (f0 >= 0 && f0 < (d >> 1)) {
+            const f32x4 a = *(const __attribute__((address_space(3))) f32x4*)(sh + f0 * 4), b = *(const __attribute__((address_space(3))) f32x4*)(sh + f0 * 4 + 16);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { sc.v[i][e] = a[e]; sc.v[i][4 + e] = b[e]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float z = (lane + 64 * i) * 8 < d ? sc.v[i][e] : 0.f;
+          sc.v[i][e] = inst < 0 ? 1.f + z : sigmoidf_(z); az.v[i][e] = 0.f;
+        }
+    }
+    for (int t = t0; t < tend; t++) {
+      const f32x4 sv = *(const __attribute__((address_space(3))) f32x4*)(acquire() + lane * 16);
+      RowRaw<NC> rr;
+      Row<NC> h, o, G, yy;
+      ring_raw(rr, acquire(), lane, d); widen(h, rr);
+      if (own) {
+        ring_raw(rr, acquire(), lane, d); widen(o, rr);
+        if (has_err) {
+          Row<NC> oe; ring_raw(rr, acquire(), lane, d); widen(oe, rr);
+#pragma unroll
+          for (int i = 0; i < NC; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) o.v[i][e] += oe.v[i][e];
+        }
+      }
+      if (has_add) { ring_raw(rr, acquire(), lane, d); widen(G, rr); }
+      else {
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) G.v[i][e] = 0.f;
+      }
+      if (has_post) { ring_raw(rr, acquire(), lane, d); widen(yy, rr); }
+      float k1_l = 0.f;                                         // lane j: k1 of source j (exported when NJ == 0)
+      auto one_source = [&](int j, Row<NC>& pwj) {
+        Row<NC> gj; ring_raw(rr, acquire(), lane, d); widen(gj, rr);
+        const float da = row_dot<NC>(gj, h);
+        float dsum;
+        if (j == 0 && own) {
+          // <g, out> with the forward output as it was BEFORE rounding to bf16 (stored row + stored residual): the score gradient
+          // a_l (<g, h_l> - <g, out>) cancels to the difference of nearby hiddens, which the rounding of `out` alone would swamp
+          dsum = row_dot<NC>(gj, o);
+          if (lane == 0) { srcs[0].dsum[t] = dsum; srcs[0].save[(size_t)t * srcs[0].L * 4 + 3] = dsum; }
+        } else dsum = lane_bcast(sv[3], 32 + j);
+        const float a = lane_bcast(sv[0], j), inv = lane_bcast(sv[1], j), sj = lane_bcast(sv[2], j);
+        const float ds = a * (da - dsum);
+        const float k1 = ds * inv, k2 = k1 * sj * inv;
+        if (!REG && lane == j) k1_l = k1;
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          const int c = lane + 64 * i;
+          if (c * 8 >= d) continue;
+          float w[8];
+          if (W16) {
+            const bf16x8 w8 = *(const bf16x8*)((const bf16*)dynb + (size_t)j * d + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) w[e] = bf2f(w8[e]);
+          } else {
+            const float* wj = (const float*)dynb + (size_t)j * d + c * 8;
+            const f32x4 w0 = *(const f32x4*)wj, w1 = *(const f32x4*)(wj + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { w[e] = w0[e]; w[4 + e] = w1[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            G.v[i][e] += a * gj.v[i][e] + k1 * w[e] - k2 * h.v[i][e];
+            if (REG) pwj.v[i][e] += k1 * h.v[i][e];
+          }
+        }
+      };
+      if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+          if (j < ns) one_source(j, pw[j]);
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < ns; j++) one_source(j, pw[0]);
+        if (lane < ns) p.k1[(size_t)t * p.ld_k1 + lane] = f2bf(k1_l);
+      }
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) G.v[i][e] = bf2f(f2bf(G.v[i][e]));     // what the next kernel reads back
+      store_row(G, p.dh + (size_t)t * d, d, lane);
+      if (has_post) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          const int c = lane + 64 * i;
+          if (c * 8 >= d) continue;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const float gy = G.v[i][e] * yy.v[i][e];
+            if (tok_mode && inst >= 0) atomicAdd(q.dtable + (size_t)inst * q.ld_table + 2 * d + c * 8 + e, gy * sc.v[i][e] * (1.f - sc.v[i][e]));
+            else az.v[i][e] += gy;
+            G.v[i][e] *= sc.v[i][e]; pb.v[i][e] += G.v[i][e];
+          }
+        }
+        store_row(G, q.dy + (size_t)t * d, d, lane);
+      }
+    }
+    if (has_post) {
+      if (inst < 0) {
+#pragma unroll
+        for (int i = 0; i < NC; i++)
+#pragma unroll
+          for (int e = 0; e < 8; e++) pl.v[i][e] += az.v[i][e];
+      } else if (!tok_mode) {
+        float* dt = q.dtable + (size_t)inst * q.ld_table + 2 * d;
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          int c = lane + 64 * i;
+          if (c * 8 >= d) continue;
+          f32x4 a0, a1;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            a0[e] = az.v[i][e] * sc.v[i][e] * (1.f - sc.v[i][e]);
+            a1[e] = az.v[i][4 + e] * sc.v[i][4 + e] * (1.f - sc.v[i][4 + e]);
+          }
+          *(f32x4*)(dt + c * 8) = a0; *(f32x4*)(dt + c * 8 + 4) = a1;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing (unread) DMAs land before the ring area is reused below
+  __syncthreads();
+  float* smem = (float*)(dynb + wbytes);                       // the rings are idle now: staging area of the closing reductions (8 * NC * 2 KiB <= 8 rings)
+  if (has_post) {
+    flush_col_partials<NC>(pl, q.dlayerscale, d, smem);
+    if (q.dbias) flush_col_partials<NC>(pb, q.dbias, d, smem);
+  }
+  if constexpr (REG) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+      if (j < ns) flush_col_partials<NC>(pw[j], srcs[j].dw, d, smem);
   }
 }
 
@@ -1592,18 +1911,74 @@ using namespace tfx;
 #define ST(s) ((hipStream_t)(s))
 #define RET() return (int)hipGetLastError()
 
+// blocks of `threads` threads that are RESIDENT at once on the chip for kernel `fn` (registers / LDS): segment kernels walk their items with a
+// grid stride from exactly that many blocks, so that every wave gets the same share of the (length-sorted) segments instead of the
+// hardware back-filling whole blocks whose waves finish at different times
+template <typename F> static int resident_blocks(F fn, int threads, size_t dyn) {
+  // (the occupancy query costs microseconds of host time: asked once per kernel and LDS size)
+  static std::map<std::pair<const void*, size_t>, int> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair((const void*)fn, dyn);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, dyn) != hipSuccess || per_cu < 1) per_cu = 1;
+  static int cus = 0;
+  if (!cus) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+  return cache[key] = per_cu * cus;
+}
+// grid of a segment kernel (8 waves = 8 segments per 512-thread block): every block resident at once, each wave walking its share of the
+// length-sorted segments with a grid stride (packing.token_segments balance=True); TFX_SEG_GRID=<n> forces a block count (A/B: 1024 = round 2)
+template <typename F> static int seg_grid(F fn, int n_seg) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("TFX_SEG_GRID"); forced = e ? atoi(e) : 0; }
+  int g = (n_seg + 7) / 8;
+  const int cap = forced > 0 ? forced : resident_blocks(fn, 512, 0);
+  if (g > cap) g = cap;
+  return g < 1 ? 1 : g;
+}
+template <int NC, int AHEAD, bool W16, int NJ> static int launch_pull_dma(const tfx_attnres_pull_args& a, const tfx_adaln_post_args& b, int has_post, size_t dyn, hipStream_t s) {
+  auto fn = attnres_pull_dma_k<NC, AHEAD, W16, NJ>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr = true; }
+  const int items = a.n_seg > 0 ? a.n_seg : a.T;
+  int grid = (items + 7) / 8;
+  const int cap = resident_blocks(fn, 512, dyn);
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(512), dyn, s, a, b, has_post);
+  return (int)hipGetLastError();
+}
+template <int NC, int NJ> static int pull_dma(const tfx_attnres_pull_args& a, const tfx_adaln_post_args& b, int has_post, hipStream_t s) {
+  // LDS: [w rows: fp32, or bf16 when fp32 would leave the rings fewer than 6 slots][8 rings of (AHEAD + 1) row slots]; 160 KiB per CU, ~4 KiB static
+  const size_t budget = 154 * 1024, slot8 = (size_t)8 * NC * 1024;
+  const size_t w32 = (((size_t)a.n_src * a.d * 4) + 1023) & ~(size_t)1023, w16 = (((size_t)a.n_src * a.d * 2) + 1023) & ~(size_t)1023;
+  const bool w_bf16 = w32 + 6 * slot8 > budget;
+  const size_t fixed = w_bf16 ? w16 : w32;
+  if (fixed + 3 * slot8 > budget) return -4;
+  const size_t slots = (budget - fixed) / slot8;
+#define TFX_PULL_GO(AH) do { const size_t dyn = fixed + ((AH) + 1) * slot8; \
+    return w_bf16 ? launch_pull_dma<NC, AH, true, NJ>(a, b, has_post, dyn, s) : launch_pull_dma<NC, AH, false, NJ>(a, b, has_post, dyn, s); } while (0)
+  if (slots >= 14 && NC == 1) TFX_PULL_GO(13);
+  if (slots >= 10) TFX_PULL_GO(9);
+  if (slots >= 6) TFX_PULL_GO(5);
+  if (slots >= 4) TFX_PULL_GO(3);
+  TFX_PULL_GO(2);
+#undef TFX_PULL_GO
+}
+
 extern "C" {
 
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
-static inline int grid_segs(int n_seg) { int g = (n_seg + 7) / 8; return g < 1024 ? (g < 1 ? 1 : g) : 1024; }   // 8 segments (waves) per 512-thread block
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) {
-  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(512), 0, ST(s), *a)); }
+  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(seg_grid(adaln_pre_bwd_seg_k<NC>, a->n_seg)), dim3(512), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }
 int tfx_adaln_post_fwd(const tfx_adaln_post_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_adaln_post_bwd(const tfx_adaln_post_args* a, void* s) {
-  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(512), 0, ST(s), *a)); }
+  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_seg_k<NC>, dim3(seg_grid(adaln_post_bwd_seg_k<NC>, a->n_seg)), dim3(512), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_post_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }
@@ -1632,7 +2007,7 @@ int tfx_adaln_pre_post_bwd(const tfx_adaln_pre_args* a, const tfx_adaln_post_arg
     return rc ? rc : tfx_adaln_post_bwd(b, s);
   }
   if (a->dx_add || b->dbias) return -3;
-  DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_post_bwd_seg_k<NC>, dim3(grid_segs(a->n_seg)), dim3(512), 0, ST(s), *a, *b)); RET();
+  DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_post_bwd_seg_k<NC>, dim3(seg_grid(adaln_pre_post_bwd_seg_k<NC>, a->n_seg)), dim3(512), 0, ST(s), *a, *b)); RET();
 }
 int tfx_attnres_prep(const tfx_attnres_src* src, int32_t n, int32_t d, void* s) {
   if (n <= 0) return 0;
@@ -1642,22 +2017,39 @@ int tfx_attnres_finish(const tfx_attnres_src* src, int32_t n, int32_t d, void* s
   if (n <= 0) return 0;
   hipLaunchKernelGGL(attnres_finish_k, dim3((d + 255) / 256, n), dim3(256), 0, ST(s), src, d); RET();
 }
+static int pull_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TFX_PULL_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
 int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_args* b, void* s) {
-  if (!a || a->n_src < 1 || a->n_src > PULL_MAX_SRC) return -2;
+  if (!a || a->n_src < 1 || a->n_src > PULL_MAX_SRC || (a->d & 7) || a->d > 2048) return -2;
   if (b && (b->T != a->T || b->d != a->d || (const void*)b->g != (const void*)a->dh)) return -3;
   tfx_adaln_post_args none = {};
-  const int items = a->n_seg > 0 ? a->n_seg : a->T;
-  int grid = (items + 7) / 8; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
-  const size_t dyn = (size_t)a->n_src * a->d * sizeof(float);
-  if (dyn > 100 * 1024) return -4;
-  if (a->d <= 512 && a->n_src <= 8) {
-    hipLaunchKernelGGL((attnres_pull_bwd_k<1, 8>), dim3(grid), dim3(512), dyn, ST(s), *a, b ? *b : none, b ? 1 : 0);
-  } else {
-    // d w accumulates in LDS: fewer, fatter blocks keep the closing atomics per launch down
-    if (grid > 512) grid = 512;
-    DISPATCH_NC(a->d, hipLaunchKernelGGL((attnres_pull_bwd_k<NC, 0>), dim3(grid), dim3(512), dyn, ST(s), *a, b ? *b : none, b ? 1 : 0));
+  const tfx_adaln_post_args& bb = b ? *b : none;
+  const int hp = b ? 1 : 0;
+  const size_t acc = (size_t)a->n_src * a->d * sizeof(float);
+  // few narrow sources (depth <= 8 at d <= 512): the register form (1.79 ms / step at depth 8 against 1.97 for the ring form, whose per-row issue
+  // code is the larger part of its instruction stream there); everything else: the LDS-DMA ring form (depth 24 / d 1024: 18.5 ms / step against
+  // 32.3 for the push form + the separate wrapper launch).  TFX_PULL_VARIANT (A/B): 2 = ring form everywhere, 5 = register form on a 1024-block grid
+  const int var = pull_variant();
+  const bool small = a->d <= 512 && a->n_src <= 8 && !a->k1;
+  if ((var == 0 && !small) || var == 2) {
+    if (a->d > 1024) return -6;
+    // d w partials in registers for few narrow sources, else exported (a->k1) for one weight-gradient GEMM behind this launch
+    if (small) return pull_dma<1, 8>(*a, bb, hp, ST(s));
+    if (!a->k1 || a->ld_k1 < a->n_src) return -5;
+    return a->d <= 512 ? pull_dma<1, 0>(*a, bb, hp, ST(s)) : pull_dma<2, 0>(*a, bb, hp, ST(s));
   }
-  RET();
+  if (small) {
+    // few sources, narrow rows: d w partials in registers, every row of the token in flight at once
+    auto fn = attnres_pull_reg_k<1, 8>;
+    const int items = a->n_seg > 0 ? a->n_seg : a->T;
+    int grid = (items + 7) / 8; const int cap = var == 5 ? 1024 : resident_blocks(fn, 512, acc);
+    if (grid > cap) grid = cap; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), acc, ST(s), *a, bb, hp); RET();
+  }
+  return -6;                                               // no other form for this size
 }
 int tfx_embed_fwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
 int tfx_embed_bwd(const tfx_embed_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(embed_bwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }

@@ -226,9 +226,10 @@ class Plan:
         self.seg_start = z(max(T, 1), dtype=torch.int32); self.seg_len = z(max(T, 1), dtype=torch.int32)
         # AttentionResidual backward in pull form (tfx_attnres_pull_bwd): every layer's depth softmax is kept per token by the forward;
         # TFX_ATTNRES_PULL=0 keeps the push form (tfx_attnres_bwd: one read-modify-write sweep over all earlier hiddens per layer; A/B)
-        self.pull = training and D <= 32 and os.environ.get('TFX_ATTNRES_PULL', '1') != '0'
+        self.pull = training and D <= 32 and md.dim <= 1024 and os.environ.get('TFX_ATTNRES_PULL', '1') != '0'
         if self.pull:
             self.arsave = [e(T, i + 2, 4, dtype=torch.float32) for i in range(D)]
+            self.arerr = e(D, T, d)                          # what rounding each AttentionResidual output to bf16 dropped
         self._build_forward()
         if training:
             self.dH = e(D + 1, T, d)
@@ -372,7 +373,7 @@ class Plan:
                                      table=tf, ld_table=nt3, layerscale=pp(f'{p}.2.layerscale'))
             a_ar = capi.make_args('tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
                                   gamma=pp(f'{p}.3.norm_keys.gamma'), pq=pp(f'{p}.3.pseudo_queries'), out=self.xres[i + 1],
-                                  save=self.arsave[i] if self.pull else None)
+                                  save=self.arsave[i] if self.pull else None, err=self.arerr[i] if self.pull else None)
             if fuse:
                 # the end of the layer is ONE launch - feed-forward output side, AttentionResidual, and (when the next layer reads
                 # the result directly, i.e. has no U-Net skip projection in front) the next layer's attention-side AdaLN-pre
@@ -571,7 +572,7 @@ class Plan:
             # layer's AttentionResidual output (the backward's last write to that buffer), its saved softmax state, its w = (1 + gamma) pq
             self.dsum = torch.empty(D, T, device=ps.device, dtype=torch.float32)
             self.wtab = torch.empty(2, D, d, device=ps.device, dtype=torch.float32)          # w rows | d w accumulators
-            self.nbytes += self.dsum.numel() * 4 + self.wtab.numel() * 4 + sum(t.numel() * 4 for t in self.arsave)
+            self.nbytes += self.dsum.numel() * 4 + self.wtab.numel() * 4
             SRC = capi.STRUCTS['tfx_attnres_src']
             recs = (SRC * D)()
             for j in range(D):
@@ -584,14 +585,23 @@ class Plan:
             self._src_tab = raw.to(ps.device)
             self._src_size = ctypes.sizeof(SRC)
             self._raw(L, lib.tfx_attnres_prep, self._src_tab.data_ptr(), D, d)
-        def pull_args(l, out_own, add, dh):
-            """gradient of hidden l from the layers j >= max(l - 1, 0) that mixed it"""
+        def pull_launch(l, out_own, add, dh, post):
+            """gradient of hidden l from the layers j >= max(l - 1, 0) that mixed it (+ the output side `post` of the wrapper that produced the hidden).
+            d w of those layers accumulates inside the launch for few narrow sources; otherwise the launch exports the per-token coefficients and
+            one weight-gradient GEMM K1^T . h adds them (rows j0.. of the d w table are contiguous)"""
             j0 = max(l - 1, 0)
-            a = capi.make_args('tfx_attnres_pull_args', T=T, d=d, l=l, n_src=D - j0, h=self.hid[l], src=self._src_tab.data_ptr() + j0 * self._src_size,
-                               out_own=out_own, add=add, dh=dh, seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
+            ns = D - j0
+            export = ns > 8 or d > 512
+            if export and not hasattr(self, 'k1buf'):
+                self.k1buf = torch.zeros(T, 32, device=ps.device, dtype=BF16); self.nbytes += self.k1buf.numel() * 2
+            a = capi.make_args('tfx_attnres_pull_args', T=T, d=d, l=l, n_src=ns, h=self.hid[l], src=self._src_tab.data_ptr() + j0 * self._src_size,
+                               out_own=out_own, out_err=self.arerr[l - 1] if out_own is not None else None, add=add, dh=dh,
+                               seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0, k1=self.k1buf if export else None, ld_k1=32)
             self._seg_args.append(a)
-            self._keep = getattr(self, '_keep', []) + [a]
-            return a
+            self._keep = getattr(self, '_keep', []) + [a, post]
+            self._raw(L, lib.tfx_attnres_pull_bwd, ctypes.addressof(a), ctypes.addressof(post) if post is not None else None)
+            if export:
+                self._tn(L, T, ns, d, A=self.k1buf, lda=32, a_cols=32, B=self.hid[l], ldb=d, b_cols=d, C=self.wtab[1, j0], ldc=d)
         for i in range(D - 1, -1, -1):
             p = f'transformer.layers.{i}'
             x_in = self.xres[i]
@@ -609,9 +619,7 @@ class Plan:
             if pull:
                 # dH[i+1] = gradient of hidden i + 1 from the AttentionResiduals of layers i .. D-1 (all final), formed ONCE; the feed-forward
                 # wrapper's output side rides in the same launch
-                a_pull = pull_args(i + 1, self.xres[i + 1], None, G)
-                self._keep.append(a_postf)
-                self._raw(L, lib.tfx_attnres_pull_bwd, ctypes.addressof(a_pull), ctypes.addressof(a_postf))
+                pull_launch(i + 1, self.xres[i + 1], None, G, a_postf)
             else:
                 g2 = self.dskip[i + 1] if (i + 1) in pushed else None
                 self._k(L, 'tfx_attnres_bwd', 'tfx_attnres_args', T=T, d=d, L=i + 2, hiddens=self.hid, stride_h=T * d,
@@ -696,8 +704,7 @@ class Plan:
         sync('tfx_join', 63)                       # every weight gradient is complete before the list returns
         # ---- gradient wrt the transformer input x0 = hid[0] = xres[0]
         if pull:
-            a_pull = pull_args(0, None, g, self.dx0)              # hidden 0 = the transformer input: every layer mixed it; + the chain gradient g
-            self._raw(L, lib.tfx_attnres_pull_bwd, ctypes.addressof(a_pull), None)
+            pull_launch(0, None, g, self.dx0, None)               # hidden 0 = the transformer input: every layer mixed it; + the chain gradient g
             self._raw(L, lib.tfx_attnres_finish, self._src_tab.data_ptr(), D, d)
         else:
             self._raw(L, lib.tfx_add_bf16, g.data_ptr(), self.dH[0].data_ptr(), self.dx0.data_ptr(), T * d)

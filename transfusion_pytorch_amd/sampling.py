@@ -68,6 +68,18 @@ def _sample_text_token(logits, V, temperature, min_p, stream):
     return out
 
 
+def _pick_text_only(logits, V, N, temperature, min_p, stream):
+    """the draw of `generate_text_only` (T:2690-2698) on the device: temperature 0 -> argmax over ALL V logits; else the min-p filter over all V
+    logits (threshold relative to the global maximum), then the text-only mask (first N columns), then the draw."""
+    assert logits.dim() == 2 and logits.dtype == torch.float32 and logits.stride(1) == 1
+    B = logits.shape[0]
+    out = torch.empty(B, dtype=torch.int32, device=logits.device)
+    u = torch.rand(B, device=logits.device) if temperature != 0. else None
+    capi.check(capi.lib().tfx_sample_tokens_range(logits.data_ptr(), logits.stride(0), B, V, N if temperature != 0. else V, float(temperature), float(min_p),
+                                                  capi.ptr(u), None, out.data_ptr(), ctypes.c_void_p(stream)), 'tfx_sample_tokens_range')
+    return out.long()
+
+
 def _ode_axpy(y, f_cond, f_uncond, cfg_scale, a, stream):
     """out = y + a * (f_uncond + cfg_scale * (f_cond - f_uncond)) (or y + a * f_cond): one fused launch (tfx_ode_axpy)"""
     out = torch.empty_like(y)
@@ -612,14 +624,7 @@ class Sampler:
         stream = m._stream()
 
         def pick(logits):
-            """T:2690-2698: temperature 0 -> argmax over ALL logits; else min-p filter over all logits, then the text-only mask, then the
-            draw.  The filter's threshold is relative to the global maximum, the draw runs over the first N columns."""
-            if temperature == 0.:
-                return _sample_text_token(logits, md.vocab, 0., min_p, stream).long()
-            lg = logits[:, :md.vocab] / temperature
-            probs = lg.softmax(dim=-1)
-            lg = torch.where(probs < min_p * probs.amax(dim=-1, keepdim=True), torch.full_like(lg, float('-inf')), lg)[:, :N]
-            return torch.multinomial(lg.softmax(dim=-1), 1).squeeze(-1)
+            return _pick_text_only(logits, md.vocab, N, temperature, min_p, stream)
 
         plan, S = m._forward_plain([[row] for row in prompt], torch.ones(B, 1, device=dev), add_meta=False)
         n_pad = S['n']

@@ -574,7 +574,7 @@ class Transfusion(nn.Module):
                 P.row_pos[t] = ((rp // old) * n_new + (rp % old)).astype(np.int32)
             P.n_full = n_new
         tm = token_maps(P, n, self.num_modalities)
-        seg_start, seg_len = token_segments(tm.tok_inst)
+        seg_start, seg_len = token_segments(tm.tok_inst, balance=os.environ.get('TFX_SEG_BALANCE', '1') != '0')
         D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         R = {t: int(len(v)) for t, v in P.row_inst.items()}
         row_tok = {}
@@ -1100,7 +1100,7 @@ class Transfusion(nn.Module):
         if S is None:
             ar = torch.arange(n, dtype=torch.int32)
             tok_inst = np.full((b, n), -1, dtype=np.int32)
-            seg_start, seg_len = token_segments(tok_inst)
+            seg_start, seg_len = token_segments(tok_inst, balance=os.environ.get('TFX_SEG_BALANCE', '1') != '0')
             D = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev)
             S = self._struct_cache[key] = dict(tok_inst=D(tok_inst.reshape(-1)), kv_end=D((ar + 1).repeat(b)), q_start=D(ar.repeat(b)),
                                                rot_pos=D(ar.repeat(b)), seg_start=D(seg_start), seg_len=D(seg_len))
@@ -1484,10 +1484,23 @@ class Transfusion(nn.Module):
         return out[0] if single else out
 
     @torch.no_grad()
-    def sample_one(self, prompt=None, max_length=2048, text_temperature=1., text_min_p=0.1, cache_kv=False, fixed_modality_shape=None,
+    def sample_one(self, prompt=None, max_length=2048, text_temperature=1., text_min_p=0.1, cache_kv=None, fixed_modality_shape=None,
                    force_modality_at_start=None, init_modality_noise=None, modality_steps=16, return_unprocessed_modalities=False, cfg_scale=3.):
         """T:1845-1858.  The reference asserts sample_many == per-prompt sample_one (tests/test_transfusion.py:758-808); here
-        sample_one IS the batch-of-one case of the KV-cached decoder (`cache_kv` is accepted for signature parity)."""
+        sample_one IS the batch-of-one case of the KV-cached decoder.
+        `cache_kv`: None (the default here; the reference's default is False) and True run that decoder - it is always KV-cached.  An EXPLICIT
+        False runs the reference's un-cached loop instead (T:1858-2075 written against `forward()`, `_sample_one_through_forward`: one full
+        forward per text token / ODE evaluation, no cache) - the arithmetic the reference's cache-equivalence tests compare the cached path with."""
+        if cache_kv is False and not self._ext:
+            was_training = self.training
+            self.eval()
+            try:
+                out = self._sample_one_through_forward(prompt, max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p, cache_kv=False,
+                                                       fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
+                                                       init_modality_noise=init_modality_noise, modality_steps=modality_steps, cfg_scale=cfg_scale)
+                return out if return_unprocessed_modalities else self.decode_modalities(out)
+            finally:
+                self.train(was_training)
         return self.sample_many([prompt], max_length=max_length, text_temperature=text_temperature, text_min_p=text_min_p,
                                 fixed_modality_shape=fixed_modality_shape, force_modality_at_start=force_modality_at_start,
                                 init_modality_noise=init_modality_noise, modality_steps=modality_steps,
@@ -1599,12 +1612,22 @@ class Transfusion(nn.Module):
 
     @torch.no_grad()
     def generate_text_only(self, prompt, seq_len, temperature=1.0, min_p=0.1, cache_kv=True):
-        """T:2666-2707; always KV-cached (`cache_kv` kept for signature parity).  Returns the generated ids (b, seq_len - prompt_len)."""
-        from .sampling import Sampler
+        """T:2666-2707.  Returns the generated ids (b, seq_len - prompt_len).  cache_kv=True: the KV-cached decoder (prefill + one-row decode
+        steps); cache_kv=False: the reference's un-cached loop - `forward_text` over the whole sequence for every new token (T:2686-2698)."""
+        from .sampling import Sampler, _pick_text_only
         was_training = self.training
         self.eval()
         try:
-            return Sampler(self).generate_text_only(prompt, seq_len, temperature, min_p)
+            if cache_kv:
+                return Sampler(self).generate_text_only(prompt, seq_len, temperature, min_p)
+            out = prompt.to(self.device)
+            stream = self._stream()
+            for _ in range(max(seq_len - prompt.shape[-1], 0)):
+                logits = self.forward_text(out, return_loss=False)                         # (b, n, vocabulary)
+                last = logits[:, -1].float().contiguous()
+                tok = _pick_text_only(last, last.shape[-1], self.num_text_tokens, temperature, min_p, stream).to(out.dtype)
+                out = torch.cat((out, tok.reshape(-1, 1)), dim=-1)
+            return out[:, prompt.shape[-1]:]
         finally:
             self.train(was_training)
 
