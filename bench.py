@@ -42,6 +42,27 @@ def canonical_batch(b, device, gen, num_text_tokens=256, dim_latent=384, n_inst=
     return batch
 
 
+def ragged_batch(b, device, gen, num_text_tokens=256, dim_latent=384, seed=0):
+    """a batch whose STRUCTURE is new: per sample a random number of [text, latent] pairs with random text lengths (latents of 2..6 rows), packed
+    lengths between ~960 and 1024 tokens - what a real corpus hands the packer every step (the reference re-packs every step, MP:850-936)"""
+    import random
+    rng = random.Random(seed)
+    batch = []
+    for _ in range(b):
+        parts, total, target = [], 0, rng.randint(980, 1020)
+        while True:
+            tl, ll = rng.randint(12, 36), rng.randint(2, 6)
+            cost = tl + ll + 3                                     # + [meta] shape string + [som] + [eom] of the instance
+            if total + cost > target:
+                break
+            parts.append(torch.randint(0, num_text_tokens, (tl,), device=device, generator=gen))
+            parts.append(torch.randn(ll, dim_latent, device=device, generator=gen))
+            total += cost
+        parts.append(torch.randint(0, num_text_tokens, (max(target - total, 1),), device=device, generator=gen))
+        batch.append(parts)
+    return batch
+
+
 def f_core_per_sample(d=512, D=8, h=8, dh=64, n=1024, n_inst=32, L=4):
     """F_core = 6 n D (P_attn + P_ff + SDPA) flop / sample, mask-aware SDPA pairs."""
     hd, di = h * dh, int(d * 8 / 3)
@@ -164,6 +185,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-profile', action='store_true')
     ap.add_argument('--sample', action='store_true', help='time sample_many (SURVEY 8(d) config 5) instead of the training step')
+    ap.add_argument('--ragged-steps', type=int, default=10, help='timed steps of the ragged steady state (every batch a new structure signature); 0 = skip')
     args = ap.parse_args()
     if args.sample:
         return bench_sample(args)
@@ -196,6 +218,8 @@ def main():
                         transformer=dict(dim=args.dim, depth=args.depth)).to(dev).train()
     opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
     opt.always_sync = use_pg
+    opt.time_exchange = use_pg
+    overlap = use_pg and os.environ.get('TFX_DP_OVERLAP', '1') != '0'
     if use_pg and os.environ.get('TFX_DP_OVERLAP', '1') != '0':
         # the gradient all-reduce goes out in 4 layer groups DURING the backward; fp32 on the links like the reference's DDP (TFX_DP_BF16=1: bf16)
         opt.overlap_grad_sync(groups=4, exchange_dtype=torch.bfloat16 if os.environ.get('TFX_DP_BF16') == '1' else None)
@@ -257,12 +281,26 @@ def main():
         import pstats
         pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(18)
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t0                      # this rank's own clock, before it waits for the others
     if use_pg:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     Plan.run = orig_run
     capi.lib().tfx_set_single_stream(0)
+    exchange_ms = opt.exchange_ms() if use_pg else None
+    # ragged steady state: EVERY batch has a structure the model has never seen (new signature, its own packed lengths) - the host scan, token maps,
+    # segments and index uploads are paid on every step, as on a real corpus; steps are issued back to back (no sync in between), so whatever of
+    # that host work hides behind the previous step's GPU work is hidden here too.  Two warm-up steps create the plan of the padded length.
+    ragged_ms = None
+    if args.ragged_steps > 0:
+        rb = [ragged_batch(args.batch, dev, gen, seed=1000 * rank + k) for k in range(args.ragged_steps + 2)]
+        step(rb[0]); step(rb[1])
+        torch.cuda.synchronize(); tr0 = time.perf_counter()
+        for batch in rb[2:]:
+            step(batch)
+        torch.cuda.synchronize(); ragged_ms = (time.perf_counter() - tr0) / args.ragged_steps * 1e3
+        del rb
     # one step on a structure the model has never seen (same packed length, different text / latent placement): host structure scan, index
     # uploads and - at a new padded length - a new plan are paid here and nowhere in `value`
     miss = canonical_batch(args.batch, dev, gen, text_len=23, last_text_len=54)
@@ -271,8 +309,14 @@ def main():
     torch.cuda.synchronize(); structure_miss_ms = (time.perf_counter() - tm0) * 1e3
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    per_rank = [my_elapsed / args.steps * 1e3]
     if use_pg:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([my_elapsed / args.steps * 1e3, exchange_ms or 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x[0]) for x in allr]
+        exchange_ms = max(float(x[1]) for x in allr)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
@@ -297,13 +341,18 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'Transfusion dim={args.dim} depth={args.depth} heads=8 dim_head=64 num_text_tokens=256 dim_latent=384; '
                                    f'per-GPU batch {args.batch} x seq 1024 (32 x [24 text tokens + (4,384) latent] per sample); '
-                                   'step = pack + fwd + bwd + grad all-reduce (4 layer groups, overlapped with the backward) + clip(0.5) + Adam(3e-4)',
+                                   'step = pack + fwd + bwd + ' + (('grad all-reduce (4 layer groups + tail = 5 collective launches, overlapped with the backward) + '
+                                                                   if overlap else 'ONE grad all-reduce after the backward + ') if use_pg else '')
+                                   + 'clip(0.5) + Adam(3e-4)' + ('' if use_pg else ' (one GPU: no gradient exchange)'),
                        'global_batch': world * args.batch, 'seq_len': 1024, 'parallelism': f'dp{world}'},
             'loss': float(loss.detach()),
             'model_flops_utilization': value / world * fcore / (PEAK_BF16_TFLOPS * 1e12),
             'f_core_gflop_per_sample': fcore / 1e9,
             'host_ms_per_step': host_t / args.steps * 1e3,
             'structure_miss_ms': structure_miss_ms,
+            'ragged_ms_per_step': ragged_ms,                    # every batch a never-seen structure, steps back to back (rank 0)
+            'per_rank_ms_per_step': per_rank,                   # each rank's own clock over the timed steps (before the closing barrier)
+            'grad_exchange_exposed_ms': exchange_ms,            # max over ranks: compute-stream time per step inside the exchange section (tail collective + waits)
             'fresh_batch_every_step': True,
             'roofline': {'bound': 'mfma', 'kernel': args.roofline_kernel, 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src, 'launches_per_step': n_launch / max(n_sampled, 1), 'sampled_steps': n_sampled,

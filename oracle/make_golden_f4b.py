@@ -147,6 +147,28 @@ def make_pos():
     print('pos: loss', float(loss), 'fm', float(lm), 'sample', [p.shape if torch.is_tensor(p) else p[2].shape for p in parts])
 
 
+def make_pos_clean():
+    """`add_pos_emb` together with `model_output_clean` (T:1297): the model-space conversion subtracts the PROJECTED noised tokens
+    (`processed.packed`, MP:786-792) - the positional embedding joins the stream afterwards (T:3173-3176) and is not part of the subtrahend"""
+    tp = import_reference()
+    cfg, sd, batch, times, noise, xm, nm, tm, prompt, init_noise = pos_case()
+    model = tp.Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=16, modality_default_shape=(2, 3), add_pos_emb=True, modality_num_dim=2,
+                           modality_processing='flat', prob_uncond=0., model_output_clean=True,
+                           transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith('pos_emb_mlp') for k in missing), (missing, unexpected)
+    fill_module_(model.pos_emb_mlp, 'f4b/pos/mlp')
+    pos_sd = {k: v.clone() for k, v in model.state_dict().items() if k.startswith('pos_emb_mlp')}
+    model.train()
+    with patched('randn_like', [noise]):
+        loss, bd = model(batch, times=times, return_breakdown=True)
+    loss.backward()
+    gn, gh = summarize(grads_of(model))
+    torch.save(dict(pos_sd=pos_sd, loss=loss.detach(), text_loss=bd.text.detach(), flow_losses=[f.detach() for f in bd.flow], grad_norms=gn, grad_heads=gh),
+               os.path.join(OUT, 'f4b_pos_clean.pt'))
+    print('pos + model_output_clean: loss', float(loss), 'flow', [float(f) for f in bd.flow])
+
+
 def make_unet():
     tp = import_reference()
     cfg, sd, batch, times, noises, xm, nm, tm, g0 = unet_case()
@@ -197,5 +219,11 @@ def make_unet():
 
 
 if __name__ == '__main__':
-    make_pos()
-    make_unet()
+    import sys
+    which = sys.argv[1:] or ['pos', 'unet', 'pos_clean']
+    if 'pos' in which:
+        make_pos()
+    if 'unet' in which:
+        make_unet()
+    if 'pos_clean' in which:
+        make_pos_clean()

@@ -30,13 +30,18 @@ CFG_DEEP = dict(num_text_tokens=256, dim=256, depth=8, dim_latents=(32,), heads=
 DEEP_KW = dict(max_length=64, text_temperature=0., modality_steps=16, fixed_modality_shape=(4,), cfg_scale=3.)
 # the model of SURVEY 8(d) config 5 (dim 1024 / depth 24 / dim_latent 384: 885 M parameters): a short run of the same sampler, forced modality first
 CFG_BIG = dict(num_text_tokens=256, dim=1024, depth=24, dim_latents=(384,), heads=8, dim_head=64)
-BIG_KW = dict(max_length=20, text_temperature=0., modality_steps=4, fixed_modality_shape=(4,), cfg_scale=3., force_modality_at_start=0)
+# (round 3: 8 prompts - the four README prompt kinds twice -, max_length 64, 16 ODE grid points, as the timed workload uses them; round 2 pinned
+#  2 prompts / max_length 20 / 4 grid points)
+BIG_KW = dict(max_length=64, text_temperature=0., modality_steps=16, fixed_modality_shape=(4,), cfg_scale=3., force_modality_at_start=0)
 
 
 def big_case():
     cfg = OracleConfig(**CFG_BIG)
     sd = D.det_state_dict(cfg.state_dict_shapes(), tag='sampling_big')
-    prompts = [D.det_randint('spb/p0', (10,), 0, 256), [D.det_randint('spb/p1', (5,), 0, 256), (0, D.det_normalish('spb/p1m', (3, 384)))]]
+    prompts = []
+    for k in range(2):
+        prompts += [D.det_randint(f'spb/p0/{k}', (16,), 0, 256), (0, D.det_normalish(f'spb/p1/{k}', (4, 384))), None,
+                    [D.det_randint(f'spb/p3/{k}', (8,), 0, 256), (0, D.det_normalish(f'spb/p3m/{k}', (6, 384)))]]
     noise = D.det_normalish('spb/noise', (8, 384))
     return cfg, sd, prompts, noise
 

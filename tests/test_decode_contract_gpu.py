@@ -190,3 +190,19 @@ def test_forward_text_cache_and_hiddens():
         assert cache[1] == 18
         with pytest.raises(NotImplementedError):
             m.forward_text(seq, return_kv_cache=True)                                      # a loss and a cache in one call: not in the native path
+
+
+def test_forward_refuses_a_replaced_registry_entry():
+    """the reference dispatches through `PROCESSING_STRATEGIES[self.modality_processing]` on every forward (T:3104-3107): a replaced entry must not be
+    ignored - the fused step cannot run a foreign packer, so it says so"""
+    from transfusion_pytorch_amd.modality_processing import PROCESSING_STRATEGIES
+    m, cfg, prompts, noise = native_model()
+    name = m.modality_processing
+    orig = PROCESSING_STRATEGIES[name]
+    try:
+        PROCESSING_STRATEGIES[name] = lambda *a, **k: orig(*a, **k)
+        with pytest.raises(NotImplementedError, match='not the native packer'):
+            m([[prompts[0].cuda()]], return_loss=False)
+    finally:
+        PROCESSING_STRATEGIES[name] = orig
+    assert m([[prompts[0].cuda()]], return_loss=False).shape[0] == 1

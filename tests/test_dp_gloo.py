@@ -112,3 +112,166 @@ def test_overlapped_gradient_exchange_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _cpu_plan(depth=5, groups=3):
+    """a REAL training Plan (engine.Plan: the launch lists the GPU replays) built on the CPU: nothing is launched, but the lists, their order and
+    the cut points `bwd_cuts` are the product's own"""
+    import collections
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.engine import Plan
+    from transfusion_pytorch_amd.params import geglu_phys_to_ref_rows
+    torch.manual_seed(0)
+    m = Transfusion(num_text_tokens=16, dim_latent=(32, 8), transformer=dict(dim=64, depth=depth, heads=1))
+    ps = m.store
+    ps.grad = torch.zeros(ps.numel)
+    ps.shadows = collections.defaultdict(lambda: torch.zeros(8, 8, dtype=torch.bfloat16))      # bf16 kernel-layout copies: only their addresses enter the lists
+    ps._map('geglu', geglu_phys_to_ref_rows(m.md.di, m.md.dip))
+    plan = Plan(ps, b=2, n=64, I=4, R={0: 8, 1: 4}, training=True, dp_groups=groups)
+    return m, ps, plan
+
+
+def _grad_pointers(item, lo, hi):
+    """every address inside the flat gradient buffer that a launch item carries (struct fields or positional arguments)"""
+    import ctypes
+    fn, a = item
+    vals = []
+    if isinstance(a, (tuple, list)):
+        vals = [v for v in a if isinstance(v, int)]
+    elif isinstance(a, ctypes.Structure):
+        vals = [getattr(a, f) for f, t in a._fields_ if t is ctypes.c_void_p and getattr(a, f)]
+        # argument structs passed by address (fused launches) ride in the positional form above; nested structs are kept alive in plan._keep
+    return [v for v in vals if lo <= v < hi]
+
+
+def test_real_plan_cuts_leave_exchanged_ranges_untouched():
+    """with the overlapped exchange a layer group's gradient ranges go out at `Plan.bwd_cuts`; nothing the backward list launches
+    AFTER a cut may write into a range that left at or before it.  Checked on the product's own launch list (built on the CPU), including the
+    structs the fused launches reference by address and the AttentionResidual source table (its gradients land in the tail by construction)."""
+    import ctypes
+    from transfusion_pytorch_amd import capi
+    from transfusion_pytorch_amd.optim import GradReducer
+    m, ps, plan = _cpu_plan()
+    red = GradReducer(m, None, groups=3)
+    base = ps.grad.data_ptr(); lo, hi = base, base + 4 * ps.numel
+    assert [c[1:] for c in plan.bwd_cuts] == [(4, 4), (2, 3), (0, 1)]              # depth 5 in 3 groups of <= 2 layers, last group first
+    # structs referenced by address from positional launches (tfx_attnres_pull_bwd, tfx_adaln_pre_post_bwd, ...)
+    by_addr = {ctypes.addressof(k): k for k in getattr(plan, '_keep', []) if isinstance(k, ctypes.Structure)}
+    def pointers(idx):
+        item = plan.bwd[idx]
+        out = _grad_pointers(item, lo, hi)
+        fn, a = item
+        if isinstance(a, (tuple, list)):
+            for v in a:
+                if isinstance(v, int) and v in by_addr:
+                    out += _grad_pointers(('', by_addr[v]), lo, hi)
+        return out
+    sent = []
+    cuts = {idx: (first, last) for idx, first, last in plan.bwd_cuts}
+    n_written = 0
+    for idx in range(len(plan.bwd)):
+        if idx in cuts:
+            sent += red.ranges(*cuts[idx])
+        for ptr in pointers(idx):
+            off = (ptr - base) // 4
+            n_written += 1
+            assert not any(a <= off < b for a, b in sent), (idx, plan.bwd[idx][0], off, sent)
+    assert n_written >= 12 * 5                                                      # (the scan really saw the weight / bias / gain gradients: >= 12 per layer)
+    # the AttentionResidual gradients are written when the backward reaches hidden 0 (tfx_attnres_finish): they must sit in the tail
+    tab = bytes(plan._src_tab.numpy().tobytes())
+    SRC = capi.STRUCTS['tfx_attnres_src']
+    recs = (SRC * 5).from_buffer_copy(tab)
+    covered = [r for first in (4, 2, 0) for r in red.ranges(first, min(first + 1, 4))]
+    for j in range(5):
+        for ptr in (recs[j].dgamma, recs[j].dpq):
+            off = (ptr - base) // 4
+            assert lo <= ptr < hi and not any(a <= off < b for a, b in covered), j
+
+
+def _worker_plan_overlap(rank, world, port, q):
+    """the exchange driven by a REAL plan's cut list (not a hand-derived order): groups + 1 collective launches, every element exactly once, the
+    result equal to one all-reduce; then the step on the mean gradient is identical on every rank"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from transfusion_pytorch_amd.optim import GradReducer
+    m, ps, plan = _cpu_plan()
+    local = torch.randn(ps.numel, generator=torch.Generator().manual_seed(100 + rank))
+    ok = True
+    for dt in (None, torch.bfloat16):
+        ps.grad.copy_(local)
+        red = GradReducer(m, None, groups=3, exchange_dtype=dt)
+        red.begin()
+        for _, first, last in plan.bwd_cuts:                    # the order the backward replay hands the groups over (transfusion._native_backward)
+            red.group_ready(first, last)
+        try:
+            red.check_fresh(); ok = False                       # a second backward before the step must be refused
+        except RuntimeError:
+            pass
+        red.finish()
+        ok &= red.launches == 3 + 1
+        expect = local.clone()
+        dist.all_reduce(expect, op=dist.ReduceOp.SUM)
+        if dt is None:
+            ok &= bool(torch.equal(ps.grad, expect))
+        else:
+            both = [torch.randn(ps.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+            ok &= bool(((ps.grad - expect).abs() <= 2 ** -7 * sum(a.abs() for a in both) + 1e-6).all())
+    g = expect / world
+    g = g * min(1., 0.5 / (float(g.norm()) + 1e-6))
+    new = ps.flat.detach() - 3e-4 * g / (g.abs() + 1e-8)
+    ref = new.clone()
+    dist.all_reduce(ref, op=dist.ReduceOp.MAX)
+    ok &= bool(torch.equal(ref, new))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_exchange_follows_real_plan_cuts_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_plan_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_ext(rank, world, port, q):
+    """external parameters (positional-embedding MLPs): a rank whose batch produced NO gradient for them still takes part in the same collective
+    (zeros), and ends up with the summed gradient - replicas cannot diverge on ragged multi-modal data"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    m = Transfusion(num_text_tokens=16, dim_latent=32, modality_default_shape=(2, 2), add_pos_emb=True, modality_num_dim=2, transformer=dict(dim=64, depth=2, heads=1))
+    ps = m.store
+    ps.grad = torch.zeros(ps.numel)
+    opt = FusedAdam(m, lr=1e-3)
+    ok = len(opt.ext_params) > 0
+    if rank == 0:                                               # only rank 0 saw the modality
+        for i, p in enumerate(opt.ext_params):
+            p.grad = torch.full_like(p, float(i + 1))
+    opt.sync_grads()
+    for i, p in enumerate(opt.ext_params):
+        ok &= p.grad is not None and bool((p.grad == float(i + 1)).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_external_parameter_gradients_with_missing_modalities_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ext, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

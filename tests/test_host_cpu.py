@@ -11,7 +11,7 @@ import torch
 from oracle.cases import build_case
 from oracle.transfusion_oracle import kv_end_from_positions, pack_batch, rotary_positions
 from transfusion_pytorch_amd import Transfusion, capi
-from transfusion_pytorch_amd.packing import fast_signature, scan_batch, token_maps, token_segments
+from transfusion_pytorch_amd.packing import fast_signature, scan_batch, scan_signature, token_maps, token_segments
 
 
 def test_c_abi_library_exports_every_declared_symbol():
@@ -237,6 +237,18 @@ def test_packer_matches_oracle_on_random_ragged_batches():
         P = scan_batch(batch, num_modalities=2, dim_latents=cfg.dim_latents, sos_id=cfg.sos_id, eos_id=cfg.eos_id, meta_id=cfg.meta_id,
                        som_ids=cfg.som_ids, eom_ids=cfg.eom_ids, add_sos_eos=True)
         assert P.positions == O.positions and P.total_tokens == O.total_tokens and P.n_full == O.text.shape[1], trial
+        # the product's scan runs on the structure signature alone (packing.scan_signature): field by field the same packed batch, both layouts
+        for meta in (True, False):
+            sig, tx, lat = fast_signature(batch)
+            kw = dict(num_modalities=2, dim_latents=cfg.dim_latents, sos_id=cfg.sos_id, eos_id=cfg.eos_id, meta_id=cfg.meta_id, som_ids=cfg.som_ids,
+                      eom_ids=cfg.eom_ids, add_sos_eos=meta, add_meta=meta)
+            A, B = scan_batch(batch, **kw), scan_signature(sig, tx, lat, **kw)
+            assert (A.b, A.n_full, A.total_tokens, A.positions, A.inst_shape) == (B.b, B.n_full, B.total_tokens, B.positions, B.inst_shape), trial
+            for f in ('text_host', 'text_dest', 'cfg_droppable', 'inst_b', 'inst_m', 'inst_type', 'inst_off', 'inst_len', 'lens'):
+                assert np.array_equal(getattr(A, f), getattr(B, f)), (trial, f)
+            assert A.row_inst.keys() == B.row_inst.keys() == A.latents.keys() == B.latents.keys()
+            for t in A.row_inst:
+                assert np.array_equal(A.row_inst[t], B.row_inst[t]) and np.array_equal(A.row_pos[t], B.row_pos[t]) and len(A.latents[t]) == len(B.latents[t])
         text = P.text_host.copy().reshape(-1)
         if P.user_text:
             text[P.text_dest] = torch.cat([t.reshape(-1) for t in P.user_text]).numpy()

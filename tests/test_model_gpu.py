@@ -623,3 +623,46 @@ def test_large_vocabulary_multi_axial_latents_long_ragged_rows_match_live_oracle
     assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-3 * max(1., abs(float(ref['loss'].detach())))
     plan = model._live[0]
     assert rel(plan.logits.view(plan.b, plan.n, -1)[:, :model._live_n_true, :cfg.vocab].float().cpu(), ref['logits'].detach()) <= LOGIT_TOL
+
+
+def test_ragged_batches_share_one_bucketed_training_plan(monkeypatch):
+    """Ragged corpora change the instance and latent-row counts with every batch: the training plan is built for counts rounded up (instances to 64,
+    rows to 256) and shared.  (1) two batches of different structure run through ONE plan; (2) each gives the loss and the gradients of its own
+    exact-count plan (TFX_PLAN_BUCKETS=0) - padding rows / instances contribute nothing."""
+    from transfusion_pytorch_amd import Transfusion
+    torch.manual_seed(0)
+    model = Transfusion(num_text_tokens=64, dim_latent=(24, 16), modality_default_shape=((3,), (2,)), transformer=dict(dim=128, depth=2, dim_head=64, heads=2),
+                        prob_uncond=0.).cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    T_ = lambda n: torch.randint(0, 64, (n,), device='cuda', generator=g)
+    Lt = lambda t, n: (t, torch.randn(n, (24, 16)[t], device='cuda', generator=g))
+    batches = [[[T_(5), Lt(0, 3), T_(7), Lt(1, 2), T_(3)], [T_(9), Lt(0, 4)]],
+               [[Lt(1, 5), T_(11)], [T_(4), Lt(0, 2), T_(6), Lt(0, 6), T_(2), Lt(1, 1)], ]]
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TFX_PLAN_BUCKETS', mode)
+        model._plans, model._struct_cache = {}, {}
+        plans = []
+        for k, batch in enumerate(batches):
+            times = torch.full((2, 3), 0.4, device='cuda')
+            noise = {t: torch.randn(sum(p[1].shape[0] for s in batch for p in s if isinstance(p, tuple) and p[0] == t), (24, 16)[t],
+                                    device='cuda', generator=torch.Generator(device='cuda').manual_seed(10 * k + t)) for t in (0, 1)}
+            model._noise_override = noise
+            for p in model.parameters():
+                p.grad = None
+            loss = model(batch, times=times)
+            loss.backward()
+            torch.cuda.synchronize()
+            plans.append(model._live[0])
+            out[(mode, k)] = (float(loss), {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+        if mode == '1':
+            assert plans[0] is plans[1] and plans[0].R == {0: 256, 1: 256} and plans[0].I == 64       # one plan for both structures
+        else:
+            assert plans[0] is not plans[1]
+    model._noise_override = None
+    for k in range(2):
+        lb, gb = out[('1', k)]; le, ge = out[('0', k)]
+        assert abs(lb - le) <= 1e-5 * max(1., abs(le)), (k, lb, le)
+        worst = max(rel(gb[n], ge[n]) for n in ge if float(ge[n].norm()) > 1e-8)
+        print(f'batch {k}: loss {lb:.6f} / {le:.6f}, worst gradient rel diff bucketed vs exact {worst:.2e}')
+        assert worst <= 2e-3

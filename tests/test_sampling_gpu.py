@@ -64,6 +64,7 @@ def walk(native, ref, margins):
     return n_dec, n_tie, mod_errs, None
 
 
+BIG_MIN_COMPARED = 0.8          # share of the reference's decisive greedy steps that must be reached (and identical) before near-tie divergences
 RUNS = [('free', {}), ('forced', dict(force_modality_at_start=0)), ('forced_nocfg', dict(force_modality_at_start=0, cfg_scale=1.))]
 
 
@@ -235,4 +236,5 @@ def test_sample_many_at_the_config5_model_size_matches_reference_golden():
         tot_dec += n_dec; tot_all += all_dec; n_mod += len(errs)
         for e in errs:
             assert e <= 5e-2
-    assert n_mod >= 2 and tot_dec >= 0.5 * tot_all
+    print(f'[big] {tot_dec} of {tot_all} decisive steps compared ({tot_dec / max(tot_all, 1):.1%}), {n_mod} decoded modalities')
+    assert n_mod >= 8 and tot_dec >= BIG_MIN_COMPARED * tot_all

@@ -179,6 +179,10 @@ class Plan:
             self.row_tok = {t: self.rowbuf[k * rs:k * rs + r] for k, t in enumerate(R)}
             self.ctl = self.rowbuf[2 * len(R) * rs:].view(torch.float32)
         self.row_inst = {t: z(r, dtype=torch.int32) for t, r in R.items()}
+        # gather form of row_tok (dropped / padding rows, -1 there, clamped to row 0): the row-GATHERING GEMM operands index with it - what they read
+        # for such rows is multiplied by zeros or ignored (`set_rows`)
+        self.row_gat = {t: z(r, dtype=torch.int32) for t, r in R.items()} if (training and cache is None) else self.row_tok
+        self._rows_dep = {t: [] for t in R}      # per type: (object, field or list index) holding the number of REAL latent rows of the step
         # ---- forward activations
         self.hid = e(D + 1, T, d)
         self.xres = [self.hid[0]] + [e(T, d) for _ in range(D)]
@@ -297,6 +301,13 @@ class Plan:
         S = ps.shadows
         L = self.fwd
         pp = ps.ptr
+        if self.cache is not None:
+            # decode plans: `row_src` = row_tok with the dropped rows (-1) clamped to 0, so a gather never reads out of bounds (those rows are ignored by the caller)
+            self.row_src = {t: torch.zeros(r, device=self.ps.device, dtype=torch.int32) for t, r in self.R.items()}
+            if self.rowbuf is not None:
+                r, M, rs = next(iter(self.R.values())), len(self.R), self.row_stride
+                self.row_src = {t: self.rowbuf[(M + k) * rs:(M + k) * rs + r] for k, t in enumerate(self.R)}
+        self._clean_launch, self.clean_mode = {}, ('model' if self.cache is not None else 'latent')
         for t, r in self.R.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
             if t in self.ext:     # rows from the user's encoder: scatter them into the stream
@@ -307,9 +318,20 @@ class Plan:
                 self.noise_args[t] = L[-1][1]
                 if dl == d:       # nn.Identity latent_to_model (T:1478): the noised rows ARE the tokens - scatter them into the stream
                     self._raw(L, capi.lib().tfx_scatter_rows_bf16, lt['xt'].data_ptr(), dlp, d, self.hid[0].data_ptr(), d, self.row_tok[t].data_ptr(), r)
+                    lt['proj'] = lt['xt']
+                elif md.model_output_clean:
+                    # `model_output_clean`: the projected noised tokens (`processed.packed`, MP:786-792) are kept as rows of their own - the model-space
+                    # conversion subtracts W proj, and its backward needs proj again, WITHOUT what joins the stream afterwards (the positional embedding,
+                    # T:3173-3176).  latent_to_model writes them to `proj`, one more launch scatters them into the stream.
+                    lt['proj'] = torch.zeros(r, d, device=self.ps.device, dtype=BF16); self.nbytes += r * d * 2
+                    self._nt(L, algo_k=dl, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=lt['proj'], ldc=d,
+                             bias=pp(f'latent_to_model_projs.{t}.bias'))
+                    self._raw(L, capi.lib().tfx_scatter_rows_bf16, lt['proj'].data_ptr(), d, d, self.hid[0].data_ptr(), d, self.row_tok[t].data_ptr(), r)
                 else:
                     self._nt(L, algo_k=dl, A=lt['xt'], lda=dlp, B=S[f'in{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_BF16'], C=self.hid[0], ldc=d,
                              bias=pp(f'latent_to_model_projs.{t}.bias'), rowmap=self.row_tok[t])
+            if md.model_output_clean and t not in self.ext:
+                self._clean_q(L, t, r)                    # q = model_to_latent(proj)
             if t in self.ext_add:     # tokens += positional embedding rows (T:3173-3176): identity GEMM, mapped RESID epilogue
                 self._nt(L, A=lt['add'], lda=d, B=S['eye'], ldb=d, M=r, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.hid[0], ldc=d,
                          R=self.hid[0], ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
@@ -393,32 +415,25 @@ class Plan:
         self._nt(L, A=self.embed, lda=d, B=S['logits'], ldb=d, M=T, N=md.vp, K=d, algo_n=md.vocab, epi=E['TFX_EPI_F32'], C=self.logits, ldc=md.vp)   # zero pad rows: N % 4 == 0 keeps the LDS-DMA kernel
         self.fwd_logits_end = len(L)
         if self.cache is not None:
-            # decode plans: flow prediction only (model_to_latent on the modality rows), no losses.  `row_src` = row_tok with
-            # the dropped rows (-1) clamped to 0, so the gather never reads out of bounds (those rows are ignored by the caller)
-            self.row_src = {t: torch.zeros(r, device=self.ps.device, dtype=torch.int32) for t, r in self.R.items()}
-            if self.rowbuf is not None:
-                r, M, rs = next(iter(self.R.values())), len(self.R), self.row_stride
-                self.row_src = {t: self.rowbuf[(M + k) * rs:(M + k) * rs + r] for k, t in enumerate(self.R)}
+            # decode plans: flow prediction only (model_to_latent on the modality rows), no losses
             for t, r in self.R.items():
                 if t in self.ext:
                     continue
                 dl = md.dim_latents[t]; lt = self.lat[t]
                 self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_src[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
-            self._clean_launch, self.clean_mode = {}, 'model'
             if md.model_output_clean:        # decode: always the model-space form (T:2446-2456), see below
                 for t, r in self.R.items():
                     if t not in self.ext:
-                        self._clean_model_space(L, t, r, self.row_src[t])
+                        self._clean_flow(L, t, r)
             self.fwd_pred_end = len(L)
             return
         native = {t: r for t, r in self.R.items() if t not in self.ext}      # types whose projections / losses run here
         for t, r in native.items():          # flow predictions first, so that a loss-free forward can stop at fwd_pred_end
             dl = md.dim_latents[t]; lt = self.lat[t]
-            self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_tok[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
-        self._clean_launch, self.clean_mode = {}, 'latent'
+            self._nt(L, A=self.embed, lda=d, a_rowmap=self.row_gat[t], B=S[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['pred'], ldc=dl)
         if md.model_output_clean:            # pred <- (pred - noised) / max(1 - t, eps): the model predicts the clean latent (MP:100-126)
             for t, r in native.items():
-                self._clean_model_space(L, t, r, self.row_tok[t])
+                self._clean_flow(L, t, r)
         self.fwd_pred_end = len(L)
         self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
                                        dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
@@ -448,7 +463,14 @@ class Plan:
                                                **(dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}))
             self.rec.append(('tfx_mse_fwd_bwd', self._rec_args[t]))
 
-    def _clean_model_space(self, L, t, r, rowmap):
+    def _clean_q(self, L, t, r):
+        """q = W proj of `_clean_flow`: one GEMM over the type's projected token rows"""
+        md, d = self.md, self.md.dim
+        dl = md.dim_latents[t]; lt = self.lat[t]
+        lt['q'] = torch.empty(r, dl, device=self.ps.device, dtype=torch.float32)
+        self._nt(L, A=lt['proj'], lda=lt['proj'].shape[1], B=self.ps.shadows[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['q'], ldc=dl)
+
+    def _clean_flow(self, L, t, r):
         """`model_output_clean` (T:1297).  Two conversions exist in the reference:
           latent space (forward_modality, T:2772-2810):   flow = (model_to_latent(embed) - x_t) / max(1 - t, eps)
           model space  (interleaved forward MP:786-792, sample_many T:2446-2456):   flow = model_to_latent((embed - proj) / max(1 - t, eps)),
@@ -456,10 +478,8 @@ class Plan:
         model_to_latent is linear without bias, so the model-space form is (W embed - W proj) / max(1 - t, eps): the cancellation of the two
         O(1) model-space vectors is carried out AFTER the projection, between two fp32 GEMM results `pred` and `q = W proj` - never in bf16.
         Both forms run through ONE launch (`tfx_output_to_flow`): `set_clean_mode` points its subtrahend at x / eps (latent) or at q (model)."""
-        md, d = self.md, self.md.dim
+        md = self.md
         dl = md.dim_latents[t]; lt = self.lat[t]
-        lt['q'] = torch.empty(r, dl, device=self.ps.device, dtype=torch.float32)
-        self._nt(L, A=self.hid[0], lda=d, a_rowmap=rowmap, B=self.ps.shadows[f'outp{t}'], ldb=d, M=r, N=dl, K=d, epi=E['TFX_EPI_F32'], C=lt['q'], ldc=dl)
         self._clean_launch[t] = [lt['pred'].data_ptr(), lt['q'].data_ptr() if self.clean_mode == 'model' else lt['x'].data_ptr(), None,
                                  self.row_inst[t].data_ptr(), self.inst_time.data_ptr(), r, dl, float(md.clean_eps)]
         L.append((capi.lib().tfx_output_to_flow, self._clean_launch[t]))
@@ -503,6 +523,29 @@ class Plan:
         for a in self._seg_args:
             a.n_seg = n_seg
 
+    def set_rows(self, R_true: dict):
+        """latent rows of this step, per type (<= the plan's capacity `R`: training plans are built for row counts rounded up, so that ragged batches
+        share them).  Rows past the real ones scatter nowhere (row_tok = -1) and gather row 0 (row_gat); the kernels whose RESULT would see them -
+        the noising, the flow losses, the bias column sum - run over the real rows only, and the operands the weight-gradient GEMMs still
+        multiply them with (xt, dpred) are zero there."""
+        for t, r in R_true.items():
+            assert r <= self.R[t]
+            for obj, key in [(self.noise_args.get(t), 'R'), (getattr(self, '_mse_args', {}).get(t), 'R'), (getattr(self, '_vel_args', {}).get(t), 'R'),
+                             (getattr(self, '_rec_args', {}).get(t), 'R'), *self._rows_dep[t]]:
+                if obj is None:
+                    continue
+                if isinstance(obj, list):
+                    obj[key] = r
+                else:
+                    setattr(obj, key, r)
+            lt = self.lat[t]
+            if r < self.R[t] and 'xt' in lt:
+                lt['xt'][r:].zero_()
+                if 'dpred' in lt:
+                    lt['dpred'][r:].zero_()
+            if self.row_gat is not self.row_tok:
+                torch.clamp(self.row_tok[t], min=0, out=self.row_gat[t])
+
     def set_noise(self, t: int, eps_ptr):
         """noise source of modality type t for this run: a device pointer (training: x_t = t x + (1 - t) eps) or None (no noising)"""
         self.noise_args[t].eps = eps_ptr
@@ -538,7 +581,7 @@ class Plan:
                 dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
                 lt['ndpred'] = torch.zeros(r, dlp, device=self.ps.device, dtype=BF16)
                 self._raw(C, lib.tfx_scale_bf16_copy, lt['dpred'].data_ptr(), lt['ndpred'].data_ptr(), r * dlp, -1.0)
-                self._tn(C, r, dl, d, A=lt['ndpred'], lda=dlp, a_cols=dlp, B=self.hid[0], ldb=d, b_cols=d, b_rowmap=self.row_tok[t],
+                self._tn(C, r, dl, d, A=lt['ndpred'], lda=dlp, a_cols=dlp, B=lt['proj'], ldb=lt['proj'].shape[1], b_cols=d,
                          C=gp(f'model_to_latent_projs.{t}.weight'), ldc=d)
                 if dl != d:
                     lt['dpx'] = torch.empty(r, d, device=self.ps.device, dtype=BF16)
@@ -555,7 +598,7 @@ class Plan:
                 continue
             self._nt(L, algo_k=dl, A=lt['dpred'], lda=dlp, B=S[f'outp_t{t}'], ldb=dlp, M=r, N=d, K=dlp, epi=E['TFX_EPI_RESID'], C=self.dembed, ldc=d,
                      R=self.dembed, ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
-            self._tn(L, r, dl, d, A=lt['dpred'], lda=dlp, a_cols=dlp, B=self.embed, ldb=d, b_cols=d, b_rowmap=self.row_tok[t],
+            self._tn(L, r, dl, d, A=lt['dpred'], lda=dlp, a_cols=dlp, B=self.embed, ldb=d, b_cols=d, b_rowmap=self.row_gat[t],
                      C=gp(f'model_to_latent_projs.{t}.weight'), ldc=d)
         self._k(L, 'tfx_rmsnorm_bwd', 'tfx_rmsnorm_args', T=T, d=d, x=self.xres[D], gamma=pp('transformer.norm.gamma'), dy=self.dembed,
                 dx=self.gfin, dgamma=gp('transformer.norm.gamma'))
@@ -716,9 +759,11 @@ class Plan:
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
             if dl == d or t in self.ext:
                 continue                                   # Identity latent_to_model / the user's encoder: no parameters here (`dx0` rows go back through autograd)
-            self._tn(L, r, d, dl, A=self.dx0, lda=d, a_cols=d, a_rowmap=self.row_tok[t], B=lt['xt'], ldb=dlp, b_cols=dlp,
+            self._tn(L, r, d, dl, A=self.dx0, lda=d, a_cols=d, a_rowmap=self.row_gat[t], B=lt['xt'], ldb=dlp, b_cols=dlp,
                      C=gp(f'latent_to_model_projs.{t}.weight'), ldc=dl)
-            self._raw(L, lib.tfx_colsum_bf16, self.dx0.data_ptr(), d, r, d, None, self.row_tok[t].data_ptr(), gp(f'latent_to_model_projs.{t}.bias'))
+            cs = [self.dx0.data_ptr(), d, r, d, None, self.row_tok[t].data_ptr(), gp(f'latent_to_model_projs.{t}.bias')]      # (mutable: the row count follows the step)
+            self._rows_dep[t].append((cs, 2))
+            L.append((lib.tfx_colsum_bf16, cs))
         if I > 0:
             # (dtab_bf = bf16 table gradients, cast layer by layer above - the join before this point covers the side stream)
             self._nt(L, A=self.dtab_bf, lda=nt3, B=S['ada_t'], ldb=nt3, M=I, N=4 * d, K=nt3, epi=E['TFX_EPI_BF16'], C=self.dcond, ldc=4 * d)

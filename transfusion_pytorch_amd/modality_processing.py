@@ -9,7 +9,8 @@ name maps to the ONE native packer: the host structure scan (packing.scan_batch,
 embeddings are evaluated per instance by the model's MLP, `pre_post_transformer_enc_dec` types go through the user's encoder (projected lengths, MP:738-741).
 
 `Transfusion.forward` does not go through this function (its plan fuses the same launches into the step's launch list); it is the drop-in
-entry point for callers that use the registry directly, and the tests compare the two.
+entry point for callers that use the registry directly, and the tests compare the two.  `forward` does CONSULT the registry: if the entry of the
+model's strategy name is no longer the native packer it raises instead of ignoring the replacement (tests/test_decode_contract_gpu.py).
 """
 from __future__ import annotations
 

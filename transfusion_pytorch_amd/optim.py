@@ -16,9 +16,10 @@ class GradReducer:
     """Overlap of the data-parallel gradient exchange with the backward (reference practice: DDP's bucketed all-reduce under `accelerate`,
     train_mnist.py:114-126).  The flat gradient buffer completes BACK TO FRONT during the hand-written backward - the heads first, then the
     layers from the last to the first (their AdaLN conditioning weights included: engine.Plan forms those per layer), the embeddings last -
-    so the buffer is exchanged in `groups` layer groups: as soon as a group's gradients are final (`Plan.bwd_cuts`), its three contiguous
-    ranges (AdaLN weights, AdaLN biases, the layers' own parameters) are all-reduced asynchronously on the collective's stream while the
-    backward of the earlier layers runs; what is left (time conditioning, embeddings, input projections) follows the backward.
+    so the buffer is exchanged in `groups` layer groups: as soon as a group's gradients are final (`Plan.bwd_cuts`), its two contiguous
+    ranges (AdaLN weights, the layers' own parameters) go out as ONE asynchronous collective launch on the collective's stream while the
+    backward of the earlier layers runs; what is left (AdaLN biases, time conditioning, the AttentionResidual parameters, embeddings, input /
+    output projections) follows the backward as one more launch: groups + 1 collectives per step (5 by default).
     Every element is reduced exactly once (tests/test_dp_gloo.py).  One process per GPU, RCCL over xGMI via torch.distributed."""
 
     def __init__(self, model, process_group=None, groups: int = 4, exchange_dtype=None):
@@ -40,33 +41,63 @@ class GradReducer:
         self._mid = (end(f'transformer.layers.{D - 1}.2.to_ada_ln_zero.bias'), self._core[0])     # time conditioning MLP
 
     def ranges(self, lo: int, hi: int):
-        """flat [start, end) ranges that hold exactly the gradients of layers lo..hi (inclusive)"""
-        return [(self._w0 + lo * self._wl, self._w0 + (hi + 1) * self._wl), (self._b0 + lo * self._bl, self._b0 + (hi + 1) * self._bl),
-                (self._core[lo], self._core[hi + 1])]
+        """flat [start, end) ranges of the gradients of layers lo..hi (inclusive) that go out with the group: the layers' AdaLN conditioning
+        weights and their own parameters.  (Their AdaLN biases - 6 d floats per layer, adjacent to the time-conditioning MLP - travel with the tail.)"""
+        return [(self._w0 + lo * self._wl, self._w0 + (hi + 1) * self._wl), (self._core[lo], self._core[hi + 1])]
 
     def _reduce(self, ranges, async_op):
+        """ONE collective launch for all `ranges`: fp32 in place through torch.distributed's coalescing manager (RCCL: one grouped launch, no
+        staging copy; gloo: allreduce_coalesced), or - `exchange_dtype` - one all-reduce of a staged reduced-precision copy of the ranges"""
         g = self.model.store.grad
+        ranges = [(a, b) for a, b in ranges if b > a]
+        if not ranges:
+            return
+        if self.exchange_dtype is not None:
+            buf = torch.cat([g[a:b].to(self.exchange_dtype) for a, b in ranges])
+            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                self.handles.append(h); self.staged.append((ranges, buf))
+            else:
+                self._unstage(ranges, buf)
+        elif len(ranges) == 1:
+            a, b = ranges[0]
+            h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                self.handles.append(h)
+        else:
+            with dist._coalescing_manager(group=self.group, async_ops=async_op) as cm:
+                for a, b in ranges:
+                    dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            if async_op:
+                self.handles.append(cm)
+        self.done += ranges
+        self.launches += 1
+
+    def _unstage(self, ranges, buf):
+        g, off = self.model.store.grad, 0
         for a, b in ranges:
-            if b > a:
-                if self.exchange_dtype is not None:
-                    buf = g[a:b].to(self.exchange_dtype)
-                    h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-                    if async_op:
-                        self.handles.append(h); self.staged.append((a, b, buf))
-                    else:
-                        g[a:b].copy_(buf)
-                else:
-                    h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-                    if async_op:
-                        self.handles.append(h)
-                self.done.append((a, b))
+            g[a:b].copy_(buf[off:off + b - a]); off += b - a
+
+    launches = 0             # collective launches of the current step (<= groups + 1)
 
     def begin(self):
         self.handles, self.done, self.staged = [], [], []
+        self.exchanged = False
+        self.launches = 0
+
+    exchanged = False        # a backward has sent layer groups out and no optimizer step has consumed them yet
 
     def group_ready(self, lo: int, hi: int):
         """called between two segments of the backward list: layers lo..hi are final (and, at the first cut, nothing else is)"""
         self._reduce(self.ranges(lo, hi), async_op=True)
+        self.exchanged = True
+
+    def check_fresh(self):
+        """one backward per optimizer step (like DDP without `no_sync`): a second backward would accumulate into ranges that are already summed
+        over the ranks (counting the first micro-batch `world` times) and race with the collectives in flight"""
+        if self.exchanged:
+            raise RuntimeError('overlap_grad_sync: a second backward() before optimizer.step() - gradient accumulation needs the un-overlapped exchange '
+                               '(FusedAdam without overlap_grad_sync: one all-reduce in step())')
 
     def finish(self):
         """after the backward: exchange whatever no cut covered, then make the current stream wait for every collective"""
@@ -83,9 +114,8 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
-        g = self.model.store.grad
-        for a, b, buf in self.staged:                 # reduced-precision ranges come back into the fp32 buffer
-            g[a:b].copy_(buf)
+        for ranges, buf in self.staged:               # reduced-precision ranges come back into the fp32 buffer
+            self._unstage(ranges, buf)
         self.staged = []
         assert sum(b - a for a, b in self.done) == n, 'every gradient element must be reduced exactly once'
 
@@ -99,6 +129,8 @@ class FusedAdam:
         self.average = average_grads
         self.step_count = 0
         self.always_sync = False        # run the collective even at world size 1 (exercises the RCCL path on a 1-GPU box)
+        self.time_exchange = False      # bench.py: bracket the exchange section of every step with events on the compute stream (`exchange_ms`)
+        self._xev = []
         self.m = self.v = self.sumsq = None
         self.reducer = None             # set by `overlap_grad_sync`: the exchange then runs in layer groups during the backward
         # parameters that live OUTSIDE the flat buffer: the positional-embedding MLPs and the user's pre / post transformer encoder-decoder
@@ -124,19 +156,38 @@ class FusedAdam:
         """the ONE collective of a data-parallel step: all-reduce(sum) of the flat gradient buffer (RCCL over xGMI)."""
         world = self._world()
         if world > 1 or (self.always_sync and dist.is_initialized()):
+            timed = self.time_exchange and self.model.store.grad is not None and self.model.store.grad.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if self.reducer is not None and self.reducer.done:
                 self.reducer.finish()                  # the groups went out during the backward: tail + wait
                 self.reducer.begin()
             else:
                 dist.all_reduce(self.model.store.grad, op=dist.ReduceOp.SUM, group=self.group)
-            grads = [p.grad for p in self.ext_params if p.grad is not None]
-            if grads:                                      # the external parameters: one more (small) collective over their coalesced gradients
-                flat = torch.cat([g.reshape(-1) for g in grads])
+            if self.ext_params:
+                # the external parameters: one more (small) collective over ALL of them, in declaration order, zeros where this rank's batch
+                # produced no gradient (ragged multi-modal data: a rank without a modality type, or with text only, has `grad is None` for that
+                # type's MLP / encoder) - every rank issues the same collective and, below, the same Adam step
+                flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in self.ext_params])
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 off = 0
-                for g in grads:
-                    g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+                for p in self.ext_params:
+                    g = flat[off:off + p.numel()].view_as(p).to(p.dtype); off += p.numel()
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.copy_(g)
+            if timed:
+                e1.record(); self._xev.append((e0, e1))
         return world
+
+    def exchange_ms(self):
+        """mean time per step the compute stream spent in the exchange section of `step()` - the tail collective plus the wait for the groups still
+        in flight, i.e. what the overlap did NOT hide (call after a device synchronize; `time_exchange` must be on)"""
+        ms = [a.elapsed_time(b) for a, b in self._xev]
+        self._xev = []
+        return sum(ms) / len(ms) if ms else 0.0
 
     def step(self):
         ps = self.model.store
@@ -162,6 +213,8 @@ class FusedAdam:
                 coef = coef * (max_norm / (self.sumsq[0].sqrt() * gscale + 1e-6)).clamp(max=1.)
             for g in ext_grads:
                 g.mul_(coef)
+            for grp in self.ext_opt.param_groups:          # a schedule that sets `opt.lr = ...` (re-read by the fused kernel every step) reaches these too
+                grp['lr'], grp['betas'], grp['eps'], grp['weight_decay'] = self.lr, tuple(self.betas), self.eps, self.weight_decay
             self.ext_opt.step()
         a = capi.make_args('tfx_adam_args', p=ps.flat, g=ps.grad, m=self.m, v=self.v, n=ps.numel, lr=self.lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, max_norm=max_norm,

@@ -138,6 +138,84 @@ def scan_batch(modalities, *, num_modalities, dim_latents, sos_id, eos_id, meta_
         inst_shape=inst_shape, latents=latents, row_inst=row_inst, row_pos=row_pos, lens=lens, total_tokens=int(lens.sum()))
 
 
+def scan_signature(sig, user_text, latents, *, num_modalities, dim_latents, sos_id, eos_id, meta_id, som_ids, eom_ids,
+                   add_sos_eos: bool, add_meta: bool = True) -> PackedBatch:
+    """`scan_batch` from the structure SIGNATURE of `fast_signature` (per sample a tuple of entries: int = a text run of that length,
+    (type, *axial, dim_latent) = a modality instance) and the tensors it collected: no tensor is touched again and the per-token arrays come out of
+    array operations over the parts - the Python work is one pass over the entries plus one dictionary lookup per instance.  Same result as
+    `scan_batch` on the same batch (tests/test_host_cpu.py)."""
+    b = len(sig)
+    nparts = np.fromiter((len(ss) for ss in sig), dtype=np.int64, count=b)
+    entries = [e for ss in sig for e in ss]
+    N = len(entries)
+    part_b = np.repeat(np.arange(b, dtype=np.int64), nparts)
+    is_mod = np.fromiter((type(e) is tuple for e in entries), dtype=bool, count=N)
+    tlen = np.fromiter((0 if type(e) is tuple else e for e in entries), dtype=np.int64, count=N)
+    mods = [e for e in entries if type(e) is tuple]
+    M = len(mods)
+    inst_type = np.fromiter((e[0] for e in mods), dtype=np.int32, count=M)
+    assert M == 0 or (0 <= int(inst_type.min()) and int(inst_type.max()) < num_modalities), \
+        f'received a modality index that is out of range. only {num_modalities} modalities specified'
+    inst_shape = [e[1:-1] for e in mods]
+    for e in mods:
+        assert e[-1] == dim_latents[e[0]], f'mismatch for modality latent dimension - expected {dim_latents[e[0]]} but received {e[-1]}'
+    inst_len = np.fromiter((math.prod(a) for a in inst_shape), dtype=np.int64, count=M)
+    lit_cache, lits = {}, []
+    if add_meta:
+        for ty, ax in zip(inst_type.tolist(), inst_shape):
+            lit = lit_cache.get((ax, ty))
+            if lit is None:
+                lit = lit_cache[(ax, ty)] = np.array([meta_id, *(ord(c) + meta_id + 1 for c in ','.join(map(str, ax))), som_ids[ty]], dtype=np.int32)
+            lits.append(lit)
+    lit_len = np.fromiter((len(a) for a in lits), dtype=np.int64, count=M) if add_meta else np.zeros(M, np.int64)
+    # tokens per part, and every part's offset inside its sample's row
+    cnt = tlen.copy()
+    cnt[is_mod] = lit_len + inst_len + (1 if add_meta else 0)
+    lead = 1 if add_sos_eos else 0
+    csum = np.cumsum(cnt) - cnt                                          # exclusive, over all parts
+    first_part = np.cumsum(nparts) - nparts                              # index of every sample's first part
+    per_sample = np.add.reduceat(cnt, first_part[nparts > 0]) if N else np.zeros(0, np.int64)
+    tok_per_sample = np.zeros(b, np.int64); tok_per_sample[nparts > 0] = per_sample
+    sample_base = np.zeros(b, np.int64); sample_base[nparts > 0] = csum[first_part[nparts > 0]]
+    off = csum - sample_base[part_b] + lead                              # offset of the part in its row
+    lens = tok_per_sample + 2 * lead
+    n_full = int(lens.max()) if b else 0
+    text_host = np.full(b * n_full, -1, dtype=np.int32)
+    cfg_drop = np.zeros(b * n_full, dtype=bool)
+    row0 = np.arange(b, dtype=np.int64) * n_full
+    if add_sos_eos:
+        text_host[row0] = sos_id; cfg_drop[row0] = True
+        text_host[row0 + lens - 1] = eos_id; cfg_drop[row0 + lens - 1] = True
+    # text runs: ids come from the device (text_dest), the slots are CFG-droppable
+    t_sel = ~is_mod
+    t_start = part_b[t_sel] * n_full + off[t_sel]
+    text_dest = _ranges(t_start, tlen[t_sel])
+    cfg_drop[text_dest] = True
+    # instances: [meta] shape [som] literal, L latent slots (id -1, not droppable = the initial values), [eom]
+    m_b, m_off = part_b[is_mod], off[is_mod]
+    inst_off = m_off + lit_len
+    if add_meta and M:
+        text_host[_ranges(m_b * n_full + m_off, lit_len)] = np.concatenate(lits)
+        text_host[m_b * n_full + inst_off + inst_len] = np.asarray(eom_ids, dtype=np.int32)[inst_type]
+    # index of the instance inside its sample
+    first_inst = np.cumsum(np.bincount(m_b, minlength=b)) - np.bincount(m_b, minlength=b) if M else np.zeros(b, np.int64)
+    inst_m = np.arange(M, dtype=np.int64) - first_inst[m_b] if M else np.zeros(0, np.int64)
+    positions = [[] for _ in range(b)]
+    for bi, ty, o, L in zip(m_b.tolist(), inst_type.tolist(), inst_off.tolist(), inst_len.tolist()):
+        positions[bi].append((ty, o, L))
+    row_inst, row_pos, lat = {}, {}, {}
+    for t in range(num_modalities):
+        sel = np.flatnonzero(inst_type == t)
+        if sel.size:
+            row_pos[t] = _ranges(m_b[sel] * n_full + inst_off[sel], inst_len[sel]).astype(np.int32)
+            row_inst[t] = np.repeat(sel.astype(np.int32), inst_len[sel])
+            lat[t] = latents[t]
+    return PackedBatch(
+        b=b, n_full=n_full, text_host=text_host.reshape(b, n_full), user_text=user_text, text_dest=text_dest, cfg_droppable=cfg_drop.reshape(b, n_full),
+        positions=positions, inst_b=m_b, inst_m=inst_m, inst_type=inst_type, inst_off=inst_off.astype(np.int32), inst_len=inst_len.astype(np.int32),
+        inst_shape=[tuple(a) for a in inst_shape], latents=lat, row_inst=row_inst, row_pos=row_pos, lens=lens, total_tokens=int(lens.sum()))
+
+
 @dataclass
 class TokenMaps:
     """per-token index arrays over the (b, n) view the transformer sees."""

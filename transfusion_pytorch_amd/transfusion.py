@@ -17,7 +17,7 @@ from torch import nn
 
 from . import capi
 from .engine import Plan
-from .packing import fast_signature, is_int_tensor, scan_batch, token_maps, token_segments
+from .packing import fast_signature, is_int_tensor, scan_batch, scan_signature, token_maps, token_segments
 from .axial import ContinuousAxialPositionalEmbedding
 from .params import ModelDims, ParamStore
 
@@ -551,12 +551,17 @@ class Transfusion(nn.Module):
         self._plans[key] = plan                                      # (re-)insert at the most recent position
         return plan
 
-    def _build_structure(self, modalities, return_loss, add_meta=True, pad_n=1):
+    def _build_structure(self, modalities, return_loss, add_meta=True, pad_n=1, presig=None):
         """full structure scan (host) + upload of every derived index array; cached per structure signature.
         `add_meta=False`: the decode-time layout (`return_embed` in the reference, MP:330): no [meta][shape][som][eom]
-        tokens are added around modalities.  `pad_n`: round the packed length up (keeps the number of distinct plans small)."""
+        tokens are added around modalities.  `pad_n`: round the packed length up (keeps the number of distinct plans small).
+        `presig`: (signature, text tensors, latent tensors) of `fast_signature` on the same batch - the scan then runs on the signature alone."""
         dev = self.device
-        P = self._scan(modalities, add_sos_eos=return_loss, add_meta=add_meta)
+        if presig is not None:
+            P = scan_signature(*presig, num_modalities=self.num_modalities, dim_latents=self.dim_latents, sos_id=self.sos_id, eos_id=self.eos_id,
+                               meta_id=self.meta_id, som_ids=self.som_ids, eom_ids=self.eom_ids, add_sos_eos=return_loss, add_meta=add_meta)
+        else:
+            P = self._scan(modalities, add_sos_eos=return_loss, add_meta=add_meta)
         b = P.b
         n = P.n_full - 1 if return_loss else P.n_full
         n_true = n
@@ -575,21 +580,36 @@ class Transfusion(nn.Module):
             P.n_full = n_new
         tm = token_maps(P, n, self.num_modalities)
         seg_start, seg_len = token_segments(tm.tok_inst, balance=os.environ.get('TFX_SEG_BALANCE', '1') != '0')
-        D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        # every index array of the structure goes up in ONE pinned, asynchronous copy (an int32 arena; the device tensors below are views of it): a
+        # structure miss used to issue ~16 pageable host-to-device copies, each a blocking round trip of the host (0.55 ms apiece under load)
         R = {t: int(len(v)) for t, v in P.row_inst.items()}
-        row_tok = {}
+        num_mod = np.bincount(P.inst_b, minlength=b)
+        host = dict(text_host=P.text_host, text_dest=P.text_dest, cfg_droppable=P.cfg_droppable, tok_inst=tm.tok_inst, kv_end=tm.kv_end, q_start=tm.q_start,
+                    rot_pos=tm.rot_pos, inst_b=P.inst_b, inst_m=P.inst_m, seg_start=seg_start, seg_len=seg_len, num_mod=num_mod)
         for t in R:
             rp = P.row_pos[t].astype(np.int64)
             rb, rl = rp // P.n_full, rp % P.n_full
-            row_tok[t] = D(np.where(rl < n, rb * n + rl, -1).astype(np.int32))
-        tok_inst = D(tm.tok_inst)
-        S = dict(P=P, tm=tm, b=b, n=n, n_true=n_true, I=len(P.inst_b), R=R, num_mod=np.bincount(P.inst_b, minlength=b),
-                 text_host=D(P.text_host), text_dest=D(P.text_dest), cfg_droppable=D(P.cfg_droppable), tok_inst=tok_inst,
-                 kv_end=D(tm.kv_end.reshape(-1)), q_start=D(tm.q_start.reshape(-1)), rot_pos=D(tm.rot_pos.reshape(-1)),
+            host[('row_tok', t)] = np.where(rl < n, rb * n + rl, -1)
+            host[('row_inst', t)] = P.row_inst[t]
+        offs, pos = {}, 0
+        for k, a in host.items():
+            offs[k] = (pos, a.size, a.shape); pos += (a.size + 3) // 4 * 4              # 16-byte aligned slices
+        arena = torch.empty(max(pos, 4), dtype=torch.int32, pin_memory=(dev.type == 'cuda'))
+        av = arena.numpy()
+        for k, a in host.items():
+            o, sz, _ = offs[k]
+            av[o:o + sz] = np.asarray(a).reshape(-1)
+        darena = arena.to(dev, non_blocking=True)
+        D = lambda k: darena[offs[k][0]:offs[k][0] + offs[k][1]].view(offs[k][2])
+        tok_inst = D('tok_inst')
+        S = dict(P=P, tm=tm, b=b, n=n, n_true=n_true, I=len(P.inst_b), R=R, num_mod=num_mod,
+                 text_host=D('text_host'), text_dest=D('text_dest').long(), cfg_droppable=D('cfg_droppable') != 0, tok_inst=tok_inst,
+                 kv_end=D('kv_end').reshape(-1), q_start=D('q_start').reshape(-1), rot_pos=D('rot_pos').reshape(-1),
                  is_mod=tok_inst >= 0, minus1=torch.full((b, n), -1, dtype=torch.int32, device=dev),
-                 inst_b=D(P.inst_b), inst_m=D(P.inst_m), row_tok=row_tok, row_inst={t: D(P.row_inst[t]) for t in R},
-                 seg_start=D(seg_start), seg_len=D(seg_len))
-        S['num_mod_dev'] = D(S['num_mod'].astype(np.float32))
+                 inst_b=D('inst_b').long(), inst_m=D('inst_m').long(), row_tok={t: D(('row_tok', t)) for t in R}, row_inst={t: D(('row_inst', t)) for t in R},
+                 seg_start=D('seg_start'), seg_len=D('seg_len'), _arena=(arena, darena))
+        S['num_mod_dev'] = D('num_mod').float()
+        D = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         if self.has_recon_loss and return_loss:
             # reconstruction loss = mean over the instances of a type of the per-instance mse (T:3422-3426): every row weighs 1 / (instances x its rows)
             n_inst = np.bincount(P.inst_type, minlength=self.num_modalities).astype(np.float64)
@@ -677,6 +697,14 @@ class Transfusion(nn.Module):
                 return_only_pred_flows=False, return_loss=True, return_breakdown=False, return_embed=False, return_hiddens=False,
                 return_kv_cache=False, return_times=False, prob_uncond=None):
         self._require_gpu()
+        # the reference looks its packer up in the registry on every call (get_processing_strategy, MP:1252-1256, called at T:3104-3107).  The fused
+        # step packs with the native packer only (every name the reference ships maps to it): an entry someone replaced or added must not be
+        # ignored silently
+        from .modality_processing import process_native
+        if PROCESSING_STRATEGIES.get(self.modality_processing) is not process_native:
+            raise NotImplementedError(f'PROCESSING_STRATEGIES[{self.modality_processing!r}] is not the native packer: Transfusion.forward runs the fused MI355X step, '
+                                      'whose packing (host structure scan + tfx_noise_mix + the row-scattered latent_to_model GEMM) is part of its launch list; '
+                                      'call a custom strategy directly (it receives the model) or restore the registry entry')
         if torch.is_tensor(modalities):
             if modalities.dtype in (torch.int32, torch.int64):                             # T:2967-2968
                 return self.forward_text(modalities, return_loss=return_loss, return_embed=return_embed, cache=cache,
@@ -733,7 +761,7 @@ class Transfusion(nn.Module):
                 self._struct_cache.pop(next(iter(self._struct_cache)))
             # training lengths are bucketed to multiples of 64 (TFX_TRAIN_PAD; 1 = exact): ragged data then shares a handful of plans - a plan
             # owns every activation of the step and its launch lists, building one costs far more than the padding columns
-            S = self._build_structure(modalities, return_loss, add_meta=add_meta, pad_n=_TRAIN_PAD if return_loss else 1)
+            S = self._build_structure(modalities, return_loss, add_meta=add_meta, pad_n=_TRAIN_PAD if return_loss else 1, presig=(sig, user_text, latents))
         self._struct_cache[skey] = S
         P, tm, b, n, I, R = S['P'], S['tm'], S['b'], S['n'], S['I'], S['R']
         self._live_n_true = S['n_true']
@@ -748,15 +776,27 @@ class Transfusion(nn.Module):
             times = times * (1. - velocity_consistency_delta_time)
 
         ps.refresh_shadows(stream)
-        plan = self._plan(b, n, I, R, training=return_loss)
+        # Ragged corpora change the number of modality instances and of latent rows with every batch.  A training plan owns every activation of the
+        # step and its launch lists (building one costs far more than a step), so in the plain training case the plan is built for both counts ROUNDED
+        # UP - instances to 64, rows per type to 256 - and shared: padding instances are referenced by no token (their table gradients stay zero),
+        # padding rows scatter nowhere and are kept out of the losses (engine.Plan.set_rows).  TFX_PLAN_BUCKETS=0: exact counts (one plan per pair).
+        bucket = (return_loss and not self._ext and not md.pos_types and ema is None and not return_only_pred_flows and not self.has_recon_loss
+                  and not md.model_output_clean and os.environ.get('TFX_PLAN_BUCKETS', '1') != '0')
+        Ip = -(-I // 64) * 64 if (bucket and I > 0) else I
+        Rp = {t: -(-r // 256) * 256 for t, r in R.items()} if bucket else R
+        plan = self._plan(b, n, Ip, Rp, training=return_loss)
         if md.model_output_clean:
             plan.set_clean_mode('model')                    # interleaved path: the model-space conversion (MP:786-792)
         if plan.loaded_structure is not S:
             plan.set_rope_tables(*self._rope_tables(int(tm.rot_pos.max()) if tm.rot_pos.size else 0))
             plan.tok_inst.copy_(S['tok_inst'].view(-1)); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['q_start']); plan.rot_pos.copy_(S['rot_pos'])
             plan.set_segments(S['seg_start'], S['seg_len'])
-            for t in R:
-                plan.row_tok[t].copy_(S['row_tok'][t]); plan.row_inst[t].copy_(S['row_inst'][t])
+            for t, r in R.items():
+                if r < Rp[t]:
+                    plan.row_tok[t].fill_(-1); plan.row_inst[t].zero_()
+                plan.row_tok[t][:r].copy_(S['row_tok'][t]); plan.row_inst[t][:r].copy_(S['row_inst'][t])
+            if return_loss:
+                plan.set_rows(R)
             plan.loaded_structure = S
 
         # ---- token ids on device (values never visit the host)
@@ -774,7 +814,7 @@ class Transfusion(nn.Module):
             lab = torch.where(S['is_mod'] | (lab == self.null_text_id), S['minus1'], lab)    # T:3320-3323
             plan.labels.copy_(lab.reshape(-1))
         if I > 0:
-            plan.inst_time.copy_(times[S['inst_b'], S['inst_m']])
+            plan.inst_time[:I].copy_(times[S['inst_b'], S['inst_m']])
         rows_in = []                                                      # rows PyTorch hands to the engine: (kind, type, tensor with autograd history)
         for t in R:
             lt = plan.lat[t]
@@ -787,10 +827,10 @@ class Transfusion(nn.Module):
                 lt['tok'].copy_(rows.detach())
                 rows_in.append(('tok', t, rows))
                 continue
-            lt['x'].copy_(torch.cat(latents[t]), non_blocking=True)          # one cat on the source device, one transfer
+            lt['x'][:R[t]].copy_(torch.cat(latents[t]), non_blocking=True)   # one cat on the source device, one transfer
             if return_loss:
                 if self._noise_override is not None:
-                    lt['eps'].copy_(self._noise_override[t])
+                    lt['eps'][:R[t]].copy_(self._noise_override[t])
                 else:
                     lt['eps'].normal_()                                                     # MP:654
             # without a loss there is no noising (MP:658-660): noise_mix with eps = NULL copies x
@@ -1243,6 +1283,8 @@ class Transfusion(nn.Module):
             plan.tok_inst.copy_(S['tok_inst']); plan.kv_end.copy_(S['kv_end']); plan.q_start.copy_(S['zeros']); plan.rot_pos.copy_(S['zeros'])
             plan.set_segments(S['empty'], S['empty'])             # one instance spans a whole row: per-token atomics for the instance gradients
             plan.row_tok[t].copy_(S['row_tok']); plan.row_inst[t].copy_(S['tok_inst'])
+            if return_loss:
+                plan.set_rows({t: rows})                                            # (fills the gather form of the row map)
             plan.text_ids.zero_()
             plan.loaded_structure = S
         plan.inst_time.copy_(times)
@@ -1421,6 +1463,7 @@ class Transfusion(nn.Module):
             Plan.run(plan.bwd, stream)
             return
         # data parallel with overlap: replay the list group by group; a finished group's gradient ranges go out while the rest runs
+        red.check_fresh()                                   # one backward per optimizer step (the groups of the previous one are already summed over the ranks)
         red.begin()
         lo = 0
         for idx, first, last in plan.bwd_cuts:
@@ -1490,8 +1533,9 @@ class Transfusion(nn.Module):
         sample_one IS the batch-of-one case of the KV-cached decoder.
         `cache_kv`: None (the default here; the reference's default is False) and True run that decoder - it is always KV-cached.  An EXPLICIT
         False runs the reference's un-cached loop instead (T:1858-2075 written against `forward()`, `_sample_one_through_forward`: one full
-        forward per text token / ODE evaluation, no cache) - the arithmetic the reference's cache-equivalence tests compare the cached path with."""
-        if cache_kv is False and not self._ext:
+        forward per text token / ODE evaluation, no cache) - the arithmetic the reference's cache-equivalence tests compare the cached path with
+        (not for `model_output_clean` models: the decode contract of `forward()` raises for them, they keep the decoder)."""
+        if cache_kv is False and not self._ext and not self.model_output_clean:       # (`forward()`'s decode contract has no model_output_clean conversion: those models keep the decoder)
             was_training = self.training
             self.eval()
             try:
