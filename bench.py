@@ -128,18 +128,12 @@ def sample_prompts(n_each, dev, gen, dim_latent=384):
     return prompts
 
 
-def bench_sample(args):
-    """`--sample`: wall time of `sample_many` (dim1024/depth24, 64 mixed prompts, max_length 256, 16 ODE grid
-    points, cfg 3, greedy text, fixed initial noise; free-running and with a forced modality at the start), plus the reduced configuration
-    (dim512/depth8, 8 prompts, max_length 32) the CPU reference was timed on.  Prints ONE JSON line."""
+def time_sample_many(dev):
+    """wall time of `sample_many` (dim1024/depth24, 64 mixed prompts, max_length 256, 16 ODE grid points, cfg 3,
+    greedy text, fixed initial noise; free-running and with a forced modality at the start), plus the reduced configuration (dim512/depth8,
+    8 prompts, max_length 32) the CPU reference was timed on.  Returns the `runs` dict."""
     from transfusion_pytorch_amd import Transfusion
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(dev)
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    out = {'metric': 'sample_many wall time, dim1024 d24, 64 mixed prompts, max_length 256, 16 ODE steps, cfg 3', 'unit': 's', 'n_gpus': 1,
-           'higher_is_better': False, 'dtype': 'bf16', 'data': 'synthetic', 'runs': {}}
+    out = {'runs': {}}
     for name, dim, depth, n_each, max_len in (('config5', 1024, 24, 16, 256), ('reduced', 512, 8, 2, 32)):
         torch.manual_seed(0)
         m = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=dim, depth=depth)).to(dev).eval()
@@ -161,6 +155,18 @@ def bench_sample(args):
                 'config': f'dim={dim} depth={depth} max_length={max_len} modality_steps=16 cfg_scale=3 greedy force_modality_at_start={force}'}
         del m
         torch.cuda.empty_cache()
+    return out['runs']
+
+
+def bench_sample(args):
+    """`--sample`: `time_sample_many` as ONE JSON line of its own"""
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    out = {'metric': 'sample_many wall time, dim1024 d24, 64 mixed prompts, max_length 256, 16 ODE steps, cfg 3', 'unit': 's', 'n_gpus': 1,
+           'higher_is_better': False, 'dtype': 'bf16', 'data': 'synthetic', 'runs': time_sample_many(dev)}
     out['value'] = out['runs']['config5_forced']['seconds']
     # the CPU side of SURVEY 8(d): the UNMODIFIED reference on the reduced configuration, timed in the build container (the reference tree
     # is not on the GPU box) by oracle/time_reference_sampling.py and committed as a fixture - NOT a same-box measurement
@@ -185,6 +191,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-profile', action='store_true')
     ap.add_argument('--sample', action='store_true', help='time sample_many (SURVEY 8(d) config 5) instead of the training step')
+    ap.add_argument('--no-sample', action='store_true', help='skip the sample_many timing (SURVEY 8(d) config 5) that rides in the N = 1 line')
     ap.add_argument('--ragged-steps', type=int, default=10, help='timed steps of the ragged steady state (every batch a new structure signature); 0 = skip')
     args = ap.parse_args()
     if args.sample:
@@ -330,7 +337,7 @@ def main():
         # HBM bytes per launch of the roofline kernel family: rocprofv3 PMC passes of this same command, committed under
         # profiles/ (tools/pmc_traffic.sh; FETCH_SIZE x2 gfx950 correction applied there) - counters cannot be read in-process
         traffic, traffic_src = None, None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_traffic.json')
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_traffic.json')
         if os.path.exists(tj) and (args.batch, args.dim, args.depth) == (64, 512, 8):
             tr = json.load(open(tj))
             if tr.get('kernel_family') == args.roofline_kernel:
@@ -361,6 +368,19 @@ def main():
                          'measured_peak': MEASURED_PEAK_TFLOPS, 'measured_peak_frac': achieved / MEASURED_PEAK_TFLOPS,
                          'measured_peak_source': 'profiles/r02_power_clock.txt (tools/mfma_peak.hip: register-resident MFMA loop, uniform random operands, 1.66-1.77 GHz sustained)'},
         }
+        if world == 1 and not args.no_sample and (args.batch, args.dim, args.depth) == (64, 512, 8):
+            # SURVEY 8(d) config 5 rides in the same line (outside the timed region): the training model's plans are dropped first
+            model._plans, model._struct_cache = {}, {}
+            torch.cuda.empty_cache()
+            runs = time_sample_many(dev)
+            fx = os.path.join(ROOT, 'tests', 'golden', 'reference_sampling_time.json')
+            out['sample_many'] = {'config5_forced_s': runs['config5_forced']['seconds'], 'config5_free_s': runs['config5']['seconds'],
+                                  'config5_forced_tokens': runs['config5_forced']['tokens_returned'], 'config5_free_tokens': runs['config5']['tokens_returned'],
+                                  'config5_forced_modalities': runs['config5_forced']['modality_instances'], 'config5_free_modalities': runs['config5']['modality_instances'],
+                                  'reduced_forced_s': runs['reduced_forced']['seconds'], 'reduced_free_s': runs['reduced']['seconds'],
+                                  'workload': 'dim1024 depth24, 64 mixed prompts, max_length 256, 16 ODE grid points, cfg 3, greedy; reduced = dim512 depth8, 8 prompts, max_length 32',
+                                  'cpu_reference_reduced': json.load(open(fx)) if os.path.exists(fx) else None,
+                                  'cpu_reference_note': 'the UNMODIFIED reference on the reduced configuration, timed in the build container (the reference tree is not on the GPU box; the oracle restatement has no sampler) - NOT a same-box measurement'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         sys.stdout.flush()

@@ -5,7 +5,7 @@ TAG=${1:-r}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 export TMPDIR=/tmp
-(cd /tmp && TFX_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_prof -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /tmp/ev_prof.log 2>&1)
+(cd /tmp && TFX_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_prof -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --ragged-steps 0 --no-sample > /tmp/ev_prof.log 2>&1)
 python tools/prof_summary.py /tmp/ev_prof/p_kernel_trace.csv --steady > gpurun_out/ev_${TAG}_kernel_summary.txt
 python tools/prof_gaps.py /tmp/ev_prof/p_kernel_trace.csv --steps 2 | grep -A3 "step -2" > gpurun_out/ev_${TAG}_gaps.txt
 bash tools/pmc_traffic.sh ev_$TAG gemm_nt > /dev/null 2>&1; cp gpurun_out/traffic_ev_$TAG.txt gpurun_out/ev_${TAG}_traffic_gemm_nt.txt

@@ -9,6 +9,6 @@ python -m pytest tests/test_sampling_gpu.py -q -s -k "config5 or big" 2>&1 | gre
 python -m pytest tests/test_model_gpu.py -q -s -k "cfg3_1024 or canon512" 2>&1 | grep "argmax agreement\|gradients:" | cut -c1-200
 for i in 1 2; do
   for v in "TFX_PREFETCH=1" "TFX_PREFETCH=0"; do
-    env $v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --ragged-steps 12 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', {k: round(d[k],2) for k in ('ms_per_step','host_ms_per_step','structure_miss_ms','ragged_ms_per_step')})"
+    env $v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --ragged-steps 0 --no-sample --ragged-steps 12 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', {k: round(d[k],2) for k in ('ms_per_step','host_ms_per_step','structure_miss_ms','ragged_ms_per_step')})"
   done
 done

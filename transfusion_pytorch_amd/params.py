@@ -197,12 +197,26 @@ class ParamStore:
             if name.endswith('weight') and len(shape) == 2:
                 fan_in[name[:-len('weight')]] = shape[1]
         with torch.no_grad():
-            for name, shape in self.specs:
+            # the random initialisers draw in MODULE order (a layer's AttentionResidual parameters right behind its feed-forward, as the reference
+            # constructs them) - not in flat-buffer order, where those parameters sit behind the layer blocks: a seed then gives the same weights
+            # whatever the layout
+            shapes = dict(self.specs)
+            is_ar = lambda n: n.endswith(('.3.pseudo_queries', '.3.norm_keys.gamma'))
+            order = [n for n, _ in self.specs if not is_ar(n)]
+            for i in range(md.depth):
+                at = order.index(f'transformer.layers.{i}.2.fn.net.3.bias') + 1
+                order[at:at] = [f'transformer.layers.{i}.3.pseudo_queries', f'transformer.layers.{i}.3.norm_keys.gamma']
+            assert sorted(order) == sorted(shapes)
+            for name in order:
+                shape = shapes[name]
                 o = self.offsets[name][0]
                 view = self.flat[o:o + int(np.prod(shape))].view(shape)
                 if name.endswith('bias') and not name.endswith('to_ada_ln_zero.bias'):
                     view._fan_in_bound = 1. / math.sqrt(fan_in[name[:-len('bias')]])
                 init_param_(name, view)
+            for name, shape in self.specs:
+                o = self.offsets[name][0]
+                view = self.flat[o:o + int(np.prod(shape))].view(shape)
                 prm = nn.Parameter(view, requires_grad=True)
                 self.params[name] = prm
                 _attach(root, name, prm)
