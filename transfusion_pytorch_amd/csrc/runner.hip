@@ -98,14 +98,25 @@ struct SideStream {
     return 0;
   }
 };
-SideStream g_side;
+// one side stream (and its event slots) PER DEVICE: a process that drives several GPUs - or two models on two devices - gets an independent
+// set for each; the list is replayed on the device that is current when tfx_run_list is called (the caller's stream lives there)
+constexpr int kMaxDevices = 16;
+SideStream g_sides[kMaxDevices];
 bool g_single_stream = false;
+inline SideStream* side_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  return &g_sides[dev];
+}
 
 }  // namespace
 
 extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* failed_at) {
   if (n < 0 || (n > 0 && !list)) return -1;
   hipStream_t main_s = (hipStream_t)stream;
+  SideStream* sp = side_of_current_device();
+  if (!sp) return -112;
+  SideStream& g_side = *sp;
   for (int32_t i = 0; i < n; ++i) {
     const tfx_launch& l = list[i];
     int rc = 0;
