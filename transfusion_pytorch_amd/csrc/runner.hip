@@ -114,9 +114,13 @@ inline SideStream* side_of_current_device() {
 extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* failed_at) {
   if (n < 0 || (n > 0 && !list)) return -1;
   hipStream_t main_s = (hipStream_t)stream;
-  SideStream* sp = side_of_current_device();
-  if (!sp) return -112;
-  SideStream& g_side = *sp;
+  // resolved on first use: a list without side work (and the empty list) never asks the runtime which device is current
+  SideStream* sp = nullptr;
+  auto side = [&](int& rc) -> SideStream* {
+    if (!sp && !(sp = side_of_current_device())) { rc = -112; return nullptr; }
+    rc = sp->ensure();
+    return rc == 0 ? sp : nullptr;
+  };
   for (int32_t i = 0; i < n; ++i) {
     const tfx_launch& l = list[i];
     int rc = 0;
@@ -124,7 +128,8 @@ extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int
     else if (l.op >= TFX_OP_FORK && l.op <= TFX_OP_JOIN_WAIT) {
       if (l.stream < 0 || l.stream >= 64) rc = -3;
       else if (g_single_stream) rc = 0;
-      else if ((rc = g_side.ensure()) == 0) {
+      else if (SideStream* gs = side(rc)) {
+        SideStream& g_side = *gs;
         if (l.op == TFX_OP_FORK) {
           rc = (int)hipEventRecord(g_side.fork_ev[l.stream], main_s);
           if (rc == 0) rc = (int)hipStreamWaitEvent(g_side.stream, g_side.fork_ev[l.stream], 0);
@@ -134,7 +139,7 @@ extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int
         }
       }
     } else if (l.stream == 1 && !g_single_stream) {
-      if ((rc = g_side.ensure()) == 0) rc = run_one(l, (void*)g_side.stream);
+      if (SideStream* gs = side(rc)) rc = run_one(l, (void*)gs->stream);
     } else if (l.stream == 1) {
       rc = run_one(l, stream);
     } else if (l.stream == 0) {
@@ -147,11 +152,14 @@ extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int
 
 // ---- hipGraph form of a launch list (decode plans) ------------------------------------------------------------------------------
 namespace {
-hipStream_t g_capture_stream = nullptr;
+hipStream_t g_capture_streams[kMaxDevices] = {};
 }
 extern "C" int tfx_graph_create(const tfx_launch* list, int32_t n, void** graph_out) {
   if (!graph_out || n <= 0 || !list) return -1;
   *graph_out = nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return -112;
+  hipStream_t& g_capture_stream = g_capture_streams[dev];
   if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) return -120;
   // thread-local mode: other host threads (and other streams of this thread) keep working while the list is recorded
   if (hipStreamBeginCapture(g_capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -121;
