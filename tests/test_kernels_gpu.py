@@ -153,7 +153,8 @@ def test_gemm_nt_geglu_fwd_bwd(M):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM TN
-@pytest.mark.parametrize('M,N,K,splits', [(1000, 200, 136, 1), (1000, 200, 136, 4), (4096, 1544, 512, 8), (100, 64, 64, 3)])
+@pytest.mark.parametrize('M,N,K,splits', [(1000, 200, 136, 1), (1000, 200, 136, 4), (4096, 1544, 512, 8), (100, 64, 64, 3),
+                                          (4096, 1544, 512, 0), (8192, 512, 1408, 0), (4096, 300, 700, 16), (2048, 2816, 512, 1), (64, 130, 260, 0), (16384, 32, 512, 0)])
 def test_gemm_tn(M, N, K, splits):
     torch.manual_seed(4)
     lda = (N + 7) // 8 * 8 + 8
@@ -173,7 +174,8 @@ def test_gemm_tn(M, N, K, splits):
     check(f'gemm_tn {M}x{N}x{K} splits={splits}', C, ref, 5e-3)
 
 
-@pytest.mark.parametrize('M,N,K,splits,kg', [(4096, 1544, 512, 8, 0), (1000, 200, 136, 4, 0), (2048, 128, 256, 8, 8), (2048, 384, 192, 16, 32)])
+@pytest.mark.parametrize('M,N,K,splits,kg', [(4096, 1544, 512, 8, 0), (1000, 200, 136, 4, 0), (2048, 128, 256, 8, 8), (2048, 384, 192, 16, 32),
+                                             (8192, 2816, 512, 0, 0), (4096, 520, 320, 0, 40)])
 def test_gemm_tn_folded_bias_gradient_and_head_compaction(M, N, K, splits, kg):
     """`colsum`: the bias gradient (column sums of A through the row map) rides on the weight-gradient GEMM - LDS-DMA kernel (M % 64 == 0)
     and the register-staged fallback; `k_group`: per-head padded product columns are compacted into the unpadded gradient."""

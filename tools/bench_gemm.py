@@ -48,6 +48,13 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'pad':
     for pad in (0, 64): nt(8192, 8192, 8192, pad=pad, padc=pad)
     sys.exit(0)
 
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'tn':      # weight-gradient shapes: library-chosen splits (0) and a sweep
+    T = 65536
+    for (N, K) in [(2816, 512), (1544, 512), (512, 1408), (512, 512), (1024, 1024), (4096, 1024)]:
+        for s in (0, 8, 16, 32, 64):
+            tn(T, N, K, s)
+    sys.exit(0)
+
 if __name__ == '__main__':
     T = 65536
     for (N, K) in [(1544, 512), (512, 512), (2816, 512), (512, 1408), (512, 1600), (512, 2816), (1408, 512)]:

@@ -9,6 +9,7 @@
 // (row scatter map) is one lookup per lane.
 #include "tfx_common.h"
 #include "tfx_kernels.h"
+#include <type_traits>
 
 namespace tfx {
 
@@ -1191,116 +1192,235 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 #undef PP_STAMP
 }
 
-// TN, 4-stage ring of 32-row slabs (16 KiB per stage, 64 KiB per block -> 2 blocks per CU), three slabs in flight.
-constexpr int MS_ROWS = 32, MS_NST = 4;
-template <bool SUM>
-__global__ __launch_bounds__(256, 2) void gemm_tn_ms_kernel(GemmTN p) {
+// TN with LDS-DMA (round 3: one template for every tiling).  A wave owns (32 FA) x (32 FB) of the output, WN x WK waves share a block tile
+// of (32 FA WN) x (32 FB WK); operands arrive as 32-row slabs of 128-column sub-slabs (swizzled [32][128] layout above) in an NST-slot ring,
+// NST - 1 slabs in flight, one barrier per slab.  Instantiated as
+//   <2,2,2,2,4>  128 x 128, 4 waves, 16 KiB slabs, 64 KiB  -> 2 blocks per CU   (round 2's kernel; few-tile products: 512 x 512)
+//   <2,4,2,2,3> / <4,2,2,2,3>  128 x 256 / 256 x 128, 4 waves, 24 KiB slabs, 72 KiB -> 2 blocks per CU   (TFX_TN_TILE=1, A/B only)
+//   <2,4,4,2,4>  256 x 256, 8 waves, 32 KiB slabs, 128 KiB -> 1 block per CU    (7.8 KiB of L2 -> LDS traffic per MFLOP instead of 15.6)
+// What the counters and stamps said (profiles/r03_c_*): no bank conflicts and 3.5 % LDS issue stalls with either fragment ratio (1.0 or 0.75
+// transposed reads per MFMA) - the loop was neither LDS- nor MFMA-bound; the three tilings ran within 2 % of each other until the DMA issue
+// was spread (SPREAD below), after which the wide tiles lead: 2816 x 512 at M = 65536 713 -> 850 TFLOP/s, 4096 x 1024 830 -> 1100.
+// Fragments that lie wholly outside N / k_valid skip their MFMAs (wave-uniform), so the ragged last tile of N = 1544 costs its DMA only.
+constexpr int MW_ROWS = 32;
+template <bool SUM, int FA, int FB, int WN, int WK, int NST, bool SPREAD>
+__global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p) {
+  constexpr int NW = WN * WK;
+  constexpr int TILE_N = 32 * FA * WN, TILE_K = 32 * FB * WK;
+  constexpr int SA = TILE_N / 128, SB = TILE_K / 128, NSUB = SA + SB;   // 128-column sub-slabs per stage
+  constexpr int SUBE = MW_ROWS * 128, STAGE = NSUB * SUBE;               // elements
+  constexpr int NPW = NSUB * 8 / NW;                                     // DMA pieces (4 rows x 256 B) per wave and slab
+  static_assert(NSUB * 8 % NW == 0 && TILE_N % 128 == 0 && TILE_K % 128 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16* As = (bf16*)smem_raw;                         // [4][32*128]
-  bf16* Bs = As + MS_NST * MS_ROWS * 128;             // [4][32*128]
+  bf16* S = (bf16*)smem_raw;                                             // [NST][NSUB][32 * 128]
 
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = w >> 1, wk = w & 1;
-  const int ntn = (p.N + 127) / 128, ntk = (p.K + 127) / 128;
+  const int wn = w / WK, wk = w % WK;
+  const int ntn = (p.N + TILE_N - 1) / TILE_N, ntk = (p.K + TILE_K - 1) / TILE_K;
   const int ntile = ntn * ntk;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int split = p.splits == 1 ? 0 : xcd + 8 * (local / ntile);
   const int bid = p.splits == 1 ? xcd_remap(blockIdx.x, gridDim.x) : local % ntile;
-  const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
+  const int n0 = (bid / ntk) * TILE_N, k0 = (bid % ntk) * TILE_K;
   const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
   const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
   if (mbeg >= mend) return;
-  const int nst = (mend - mbeg) / MS_ROWS;
+  const int nst = (mend - mbeg) / MW_ROWS;
 
-  // wave w stages rows [8w, 8w+8) of each slab: 2 DMA pieces of 4 rows x 256 B per operand
-  const bf16 *ga[2], *gb[2];
+  // piece q = w * NPW + j of a slab: sub-slab q / 8 (A's first), rows 4 (q % 8) ... + 3
+  const bf16* gp[NPW];
+  size_t gstep[NPW];
+  int loff[NPW];
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int row = w * 8 + j * 4 + (l >> 4);
+  for (int j = 0; j < NPW; j++) {
+    const int q = w * NPW + j, sub = q >> 3, g = q & 7;
+    const int row = g * 4 + (l >> 4);
     const int c = (l & 15) ^ ((row & 3) << 2);
-    const int ca = min(n0 + c * 8, p.a_cols - 8), cb = min(k0 + c * 8, p.b_cols - 8);
-    ga[j] = p.A + (size_t)(mbeg + row) * p.lda + ca;
-    gb[j] = p.B + (size_t)(mbeg + row) * p.ldb + cb;
+    if (sub < SA) {
+      gp[j] = p.A + (size_t)(mbeg + row) * p.lda + min(n0 + sub * 128 + c * 8, p.a_cols - 8);
+      gstep[j] = (size_t)MW_ROWS * p.lda;
+    } else {
+      gp[j] = p.B + (size_t)(mbeg + row) * p.ldb + min(k0 + (sub - SA) * 128 + c * 8, p.b_cols - 8);
+      gstep[j] = (size_t)MW_ROWS * p.ldb;
+    }
+    loff[j] = sub * SUBE + g * 4 * 128;
   }
-  const size_t stepA = (size_t)MS_ROWS * p.lda, stepB = (size_t)MS_ROWS * p.ldb;
   auto issue = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      glds16_asm(ga[j], As + buf * MS_ROWS * 128 + (w * 8 + j * 4) * 128);
-      glds16_asm(gb[j], Bs + buf * MS_ROWS * 128 + (w * 8 + j * 4) * 128);
-      ga[j] += stepA; gb[j] += stepB;
+    for (int j = 0; j < NPW; j++) {
+      glds16_asm(gp[j], S + buf * STAGE + loff[j]);
+      gp[j] += gstep[j];
     }
   };
+  static_assert(!SPREAD || NPW <= FA * FB, "one DMA piece per MFMA pair");
 
-  f32x16 acc[2][2];
+  bool live_a[FA], live_b[FB];                                          // wave-uniform: the fragment holds at least one written row / column
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < FA; i++) live_a[i] = n0 + (wn * FA + i) * 32 < p.N;
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+  for (int j = 0; j < FB; j++) live_b[j] = k0 + (wk * FB + j) * 32 < p.k_valid;
+
+  f32x16 acc[FA][FB];
+#pragma unroll
+  for (int i = 0; i < FA; i++)
+#pragma unroll
+    for (int j = 0; j < FB; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // bias gradient folded in: the waves that own the first K tile also multiply their A fragments with a ones operand
-  const bool do_sum = SUM && k0 == 0 && wk == 0;                       // wave-uniform (SUM: p.colsum != NULL)
-  f32x16 accs[2];
+  const bool do_sum = SUM && k0 == 0 && wk == 0;                       // bias gradient: A^T x ones on the waves of the first K columns
+  f32x16 accs[SUM ? FA : 1];
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; e++) ones[e] = f2bf(1.f);
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < (SUM ? FA : 1); i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) accs[i][r] = 0.f;
 
-  const int pre = min(nst, MS_NST - 1);
+#ifdef TFX_TN_TIMING      // tools/tn_timing.py: per-block stamps through `a_rowmap` (0 start, 1 first slab landed, 2 loop done, 3 atomics issued, 4 retired,
+                          // 5 / 6 / 7 = cycles summed over the loop in [waitcnt + barrier] / [DMA issue] / [fragment reads + MFMA issue])
+  unsigned long long* stamps = (unsigned long long*)p.a_rowmap + (size_t)blockIdx.x * 8;
+  unsigned long long tw = 0, ti = 0, tc = 0, c0 = 0, c1 = 0, c2 = 0;
+#define TN_STAMP(i) { if (t == 0) stamps[i] = __builtin_readcyclecounter(); }
+#define TN_CLK(x) x = __builtin_readcyclecounter();
+#else
+#define TN_STAMP(i)
+#define TN_CLK(x)
+#endif
+  TN_STAMP(0)
+  const int pre = min(nst, NST - 1);
   for (int s0 = 0; s0 < pre; s0++) issue(s0);
-  for (int st = 0; st < nst; st++) {
-    const int ahead = min(MS_NST - 2, nst - 1 - st);            // slabs issued beyond `st` at this point (4 DMAs each)
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                 // slab st landed for every wave; slab st-1's buffer is free
-    if (st + MS_NST - 1 < nst) issue((st + MS_NST - 1) % MS_NST);
-    const bf16* as = As + (st % MS_NST) * MS_ROWS * 128;
-    const bf16* bs = Bs + (st % MS_NST) * MS_ROWS * 128;
-    bf16x8 af[2][2], bfr[2][2];
+  int buf = 0, nbuf = NST - 1;                                          // slab st lives in `buf`; slab st + NST - 1 goes to `nbuf`
+  // One slab.  MORE: slab st + NST - 1 exists and is fetched here (every iteration but the last NST - 1); CHECK: some fragment of this wave lies
+  // outside N / k_valid and its MFMAs are skipped.  Both are template-like flags so that the common loop body is ONE basic block: with a branch
+  // per MFMA hipcc gathers the conditional DMA issues back into a burst (sched_barrier only orders within a block).
+  auto slab = [&](int st, auto more_c, auto check_c) {
+    constexpr bool MORE = decltype(more_c)::value, CHECK = decltype(check_c)::value;
+    TN_CLK(c0)
+#ifdef TFX_TN_TIMING
+    if (st > 0) tc += c0 - c2;
+#endif
+    if (MORE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NPW) : "memory");
+    else {
+      const int ahead = min(NST - 2, nst - 1 - st);                     // slabs issued beyond `st` at this point (NPW DMAs each)
+      if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+      else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                       // slab st landed for every wave; slab st - 1's slot is free
+    TN_CLK(c1)
+#ifdef TFX_TN_TIMING
+    tw += c1 - c0;
+    if (st == 0) TN_STAMP(1)
+#endif
+    if (!SPREAD && MORE) issue(nbuf);
+    TN_CLK(c2)
+#ifdef TFX_TN_TIMING
+    ti += c2 - c1;
+#endif
+    const bf16* sa = S + buf * STAGE;
+    const bf16* sb = sa + SA * SUBE;
+    bf16x8 af[2][FA], bfr[2][FB];
 #pragma unroll
-    for (int i = 0; i < 2; i++) { af[0][i] = lds_tr8_swz(as, 8 * hi, 8 * hi + 4, wn * 64 + i * 32); bfr[0][i] = lds_tr8_swz(bs, 8 * hi, 8 * hi + 4, wk * 64 + i * 32); }
+    for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) { af[1][i] = lds_tr8_swz(as, 16 + 8 * hi, 20 + 8 * hi, wn * 64 + i * 32); bfr[1][i] = lds_tr8_swz(bs, 16 + 8 * hi, 20 + 8 * hi, wk * 64 + i * 32); }
+      for (int i = 0; i < FA; i++) {
+        const int c = (wn * FA + i) * 32;
+        af[ks][i] = lds_tr8_swz(sa + (c >> 7) * SUBE, 16 * ks + 8 * hi, 16 * ks + 8 * hi + 4, c & 127);
+      }
+#pragma unroll
+      for (int j = 0; j < FB; j++) {
+        const int c = (wk * FB + j) * 32;
+        bfr[ks][j] = lds_tr8_swz(sb + (c >> 7) * SUBE, 16 * ks + 8 * hi, 16 * ks + 8 * hi + 4, c & 127);
+      }
+    }
+    // SPREAD: the next slab's DMA pieces go out one per MFMA pair instead of as a burst behind the barrier.  Phase stamps of the burst form
+    // (tools/tn_timing.py, 2816 x 512): of 1570 clocks per slab and wave, 570 pass in the six `global_load_lds` issues - every wave of the CU
+    // queues its pieces at the address unit at the same moment (64 B/clk, 16 clocks per 1 KiB piece) and feeds no MFMA meanwhile.
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < FA; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FB; j++) {
+          if (!CHECK || (live_a[i] && live_b[j])) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+          const int idx = (ks * FA + i) * FB + j;
+          if (SPREAD && MORE && (idx & 1) && (idx >> 1) < NPW) {
+            glds16_asm(gp[idx >> 1], S + nbuf * STAGE + loff[idx >> 1]);
+            gp[idx >> 1] += gstep[idx >> 1];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
     if (do_sum) {
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-        for (int i = 0; i < 2; i++) accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], ones, accs[i], 0, 0, 0);
+        for (int i = 0; i < (SUM ? FA : 1); i++) accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], ones, accs[i], 0, 0, 0);
     }
+    buf = buf + 1 == NST ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+  };
+  bool all_live = true;
+#pragma unroll
+  for (int i = 0; i < FA; i++) all_live = all_live && live_a[i];
+#pragma unroll
+  for (int j = 0; j < FB; j++) all_live = all_live && live_b[j];
+  const int n_main = max(0, nst - (NST - 1));
+  using yes = std::true_type; using no = std::false_type;
+  if (all_live) {
+    for (int st = 0; st < n_main; st++) slab(st, yes{}, no{});
+    for (int st = n_main; st < nst; st++) slab(st, no{}, no{});
+  } else {
+    for (int st = 0; st < n_main; st++) slab(st, yes{}, yes{});
+    for (int st = n_main; st < nst; st++) slab(st, no{}, yes{});
   }
+  TN_STAMP(2)
 
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < FA; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int n = n0 + (wn * FA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (n >= p.N) continue;
       const int no = p.rowmap ? p.rowmap[n] : n;
       if (no < 0) continue;
-      if (do_sum && (l & 31) == 0) atomicAdd(p.colsum + no, accs[i][r]);      // every column of A^T x ones holds the row sum
+      if (SUM && do_sum && (l & 31) == 0) atomicAdd(p.colsum + no, accs[SUM ? i : 0][r]);
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int k = k0 + wk * 64 + j * 32 + (l & 31);
+      for (int j = 0; j < FB; j++) {
+        const int k = k0 + (wk * FB + j) * 32 + (l & 31);
         if (k < p.k_valid) {
           const int ko = tn_out_col(p, k);
           if (ko >= 0) atomicAdd(p.C + (size_t)no * p.ldc + ko, acc[i][j][r] * p.alpha);
         }
       }
     }
+  TN_STAMP(3)
+#ifdef TFX_TN_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TN_STAMP(4)
+  if (t == 0) { unsigned long long e = __builtin_readcyclecounter(); tc += stamps[2] - c2; stamps[5] = tw; stamps[6] = ti; stamps[7] = tc; (void)e; }
+#endif
+#undef TN_STAMP
+#undef TN_CLK
+}
+
+// split count of a TN launch with `tiles` output tiles over M rows (tfx.h: splits == 0).  Each XCD owns whole row chunks and holds `resident`
+// blocks (1 or 2 per CU): minimise (block rounds per XCD) x (rows per block) plus a price per split for the fp32 atomics onto cold
+// gradient lines (0.03 of a full-M pass, tuned on the full training step, not on the L2-hot microbenchmark).
+static int tn_auto_splits(int M, int tiles, int resident) {
+  if (tiles >= 8 * resident) return 1;
+  static const int cand[6] = {8, 16, 24, 32, 48, 64};
+  double best = 1e30;
+  int splits = 8;
+  for (int s : cand) {
+    if (s > 8 && M / s < 256) break;
+    const int rounds = (tiles * s / 8 + resident - 1) / resident;
+    const double cost = rounds * (8.0 / s) + 0.03 * s;
+    if (cost < best - 1e-9) { best = cost; splits = s; }
+  }
+  return splits;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1377,8 +1497,20 @@ int gemm_nt(const GemmNT& p, hipStream_t s) {
   return -4;
 }
 
+template <bool SUM, int FA, int FB, int WN, int WK, int NST> static void launch_tn_wide(const GemmTN& q, int grid, hipStream_t s) {
+  constexpr int smem = NST * (FA * WN + FB * WK) / 4 * MW_ROWS * 128 * 2;
+  static int spread = -1;             // TFX_TN_SPREAD=0: the next slab's DMA pieces as one burst behind the barrier (A/B)
+  if (spread < 0) {
+    const char* e = getenv("TFX_TN_SPREAD"); spread = e ? atoi(e) : 1;
+    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  }
+  if (spread) hipLaunchKernelGGL((gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, true>), dim3(grid), dim3(64 * WN * WK), smem, s, q);
+  else hipLaunchKernelGGL((gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, false>), dim3(grid), dim3(64 * WN * WK), smem, s, q);
+}
+
 int gemm_tn(const GemmTN& p, hipStream_t s) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 1) return -1;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 0) return -1;
   if ((p.lda | p.ldb | p.a_cols | p.b_cols) & 7) return -2;
   static bool attr_set = false;
   const int smem = 2 * 2 * TN_BMK * TN_LD * 2;
@@ -1386,14 +1518,33 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
+  static int tile = -2;               // TFX_TN_TILE: force 0 = 128 x 128 blocks, 1 = 4-wave wide tiles, 2 = 256 x 256 (A/B); unset: by tile count
+  if (tile == -2) { const char* e = getenv("TFX_TN_TILE"); tile = e ? atoi(e) : -1; }
   GemmTN q = p;
-  q.splits = p.splits == 1 ? 1 : (p.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernel's block order)
-  int grid = ((q.N + 127) / 128) * ((q.K + 127) / 128) * q.splits;
+#ifdef TFX_TN_TIMING
+  const bool dma_ok = true;
+#else
   const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
-  if (dma_ok)
-  {
-    if (q.colsum) hipLaunchKernelGGL(gemm_tn_ms_kernel<true>, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
-    else hipLaunchKernelGGL(gemm_tn_ms_kernel<false>, dim3(grid), dim3(256), 2 * MS_NST * MS_ROWS * 128 * 2, s, q);
+#endif
+  const int t42 = ((q.N + 255) / 256) * ((q.K + 127) / 128), t24 = ((q.N + 127) / 128) * ((q.K + 255) / 256);
+  const int t44 = ((q.N + 255) / 256) * ((q.K + 255) / 256), t22 = ((q.N + 127) / 128) * ((q.K + 127) / 128);
+  const bool o24 = q.colsum || t24 <= t42;                        // 4-wave wide form: the orientation with fewer tiles (bias form: 64 A columns per wave)
+  // 256 x 256 tiles once there are enough of them to fill the chip at <= 32 splits; below that (512 x 512: 4 tiles) the 128 x 128 blocks
+  const int kind = !dma_ok ? -1 : tile >= 0 ? tile : (t44 >= 8 ? 2 : 0);
+  const int tiles = kind == 2 ? t44 : kind == 1 ? (o24 ? t24 : t42) : t22;
+  if (q.splits == 0) q.splits = tn_auto_splits(q.M, tiles, kind == 2 ? 32 : 64);
+  q.splits = q.splits == 1 ? 1 : (q.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernels' block order)
+  const int grid = tiles * q.splits;
+  if (kind == 2) {
+    if (q.colsum) launch_tn_wide<true, 2, 4, 4, 2, 4>(q, grid, s);
+    else launch_tn_wide<false, 2, 4, 4, 2, 4>(q, grid, s);
+  } else if (kind == 1) {
+    if (q.colsum) launch_tn_wide<true, 2, 4, 2, 2, 3>(q, grid, s);
+    else if (o24) launch_tn_wide<false, 2, 4, 2, 2, 3>(q, grid, s);
+    else launch_tn_wide<false, 4, 2, 2, 2, 3>(q, grid, s);
+  } else if (kind == 0) {
+    if (q.colsum) launch_tn_wide<true, 2, 2, 2, 2, 4>(q, grid, s);
+    else launch_tn_wide<false, 2, 2, 2, 2, 4>(q, grid, s);
   }
   else {
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), smem, s, q);

@@ -40,7 +40,6 @@ def skip_sources(md: ModelDims):
     return src
 
 
-_TN_SPLIT_PRICE = 0.03      # cost of one more split (fp32 atomics onto cold gradient lines), in units of one full-M pass; tuned on the full step
 
 
 _LAUNCH = capi.STRUCTS['tfx_launch']
@@ -263,19 +262,7 @@ class Plan:
         lst.append(('tfx_gemm_nt', a))
 
     def _tn(self, lst, M, N, K, **kw):
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        # each XCD owns whole row-chunks (gemm.hip); 64 blocks are resident per XCD (2 per CU).  Pick the split count
-        # that minimises (block waves per XCD) x (rows per block) plus a price for the fp32 atomics per split (cold gradient lines: tuned on the full step, not the L2-hot microbenchmark)
-        # (measured on MI355X with tools/bench_gemm.py).
-        best, splits = None, 8
-        for s in (() if tiles >= 512 else (8, 16, 24, 32, 48, 64)):
-            if s > 8 and M // s < 256:
-                break
-            cost = -(-(tiles * s // 8) // 64) * (8.0 / s) + _TN_SPLIT_PRICE * s
-            if best is None or cost < best - 1e-9:
-                best, splits = cost, s
-        if tiles >= 512:
-            splits = 1            # enough tiles to fill the chip: no split, no extra atomics
+        splits = 0                # the library picks the split count from the tile count of the kernel it launches (tfx.h, gemm.hip tn_auto_splits)
         kw.setdefault('k_valid', K)
         algo_n = kw.pop('algo_n', None)
         side = kw.pop('side', False)
