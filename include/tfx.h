@@ -62,8 +62,8 @@ int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
 /* C[rowmap[n]][k] += alpha * sum_m A[m][n] * B[m][k]   (fp32 C, ALWAYS accumulates: split-M partial sums are
  * added with fp32 atomics, the caller zeroes C when it wants a plain product; `accumulate` is ignored).
  * a_cols/b_cols: number of readable columns of A/B (multiples of 8); k_valid: columns of the product that are written.
- * splits: number of M chunks summed through the atomics (rounded up to a multiple of 8: one chunk per XCD at a time); 1 = one block per
- * output tile over all rows; 0 = the library picks it from the tile count of the kernel it launches. */
+ * splits: number of M chunks (of a multiple of 64 rows) summed through the atomics; 1 = one block per output tile over all rows;
+ * 0 = the library picks the count that fills the chip with the tiles of the kernel it launches. */
 typedef struct {
   const tfx_bf16* A; int32_t lda; int32_t a_cols;
   const tfx_bf16* B; int32_t ldb; int32_t b_cols;

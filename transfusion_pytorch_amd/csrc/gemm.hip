@@ -523,6 +523,24 @@ TFX_DEV int tn_out_col(const GemmTN& p, int k) {
   return c < p.k_group ? (k >> 6) * p.k_group + c : -1;
 }
 
+// Block order of the TN kernels (block b runs on XCD b % 8, each with a private L2).  The ntile x splits (tile, row chunk) pairs are numbered
+// chunk-major and cut into 8 contiguous runs, one per XCD: an XCD walks all tiles of a chunk side by side, so every slab of A and B is fetched
+// from HBM once per chunk and re-read by the other tiles from that XCD's L2.  Any split count works (the launcher rounds the grid up to a
+// multiple of 8; surplus blocks leave at once), so it can be chosen to fill the chip: 22 tiles x 11 chunks = 242 blocks on 256 CUs where the
+// multiple-of-8 rule of rounds 1-2 left 176 or two half-length rounds of 352.
+struct TnBlock { int tile, mbeg, mend; };
+TFX_DEV TnBlock tn_block(const GemmTN& p, int ntile) {
+  const int per = gridDim.x >> 3;
+  const int g = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  TnBlock b;
+  const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
+  const int split = g / ntile;
+  b.tile = g - split * ntile;
+  b.mbeg = split < p.splits ? split * chunk : p.M;
+  b.mend = min(p.M, b.mbeg + chunk);
+  return b;
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* As = (bf16*)smem_raw;                         // [2][64*160]
@@ -531,17 +549,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wn = w >> 1, wk = w & 1, hi = l >> 5;
   const int ntn = (p.N + 127) / 128, ntk = (p.K + 127) / 128;
-  // XCD-aware order (block b runs on XCD b % 8, private L2): an XCD owns whole row-chunks ("splits") and walks
-  // all output tiles of a chunk concurrently, so every 64-row slab of A and B is fetched from HBM once per
-  // chunk and re-read by the other tiles from that XCD's L2.  splits is a multiple of 8 (launcher).
   const int ntile = ntn * ntk;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  // splits == 1 (many tiles, few rows: e.g. the AdaLN weight gradient): one block per tile over all rows
-  const int split = p.splits == 1 ? 0 : xcd + 8 * (local / ntile);
-  const int bid = p.splits == 1 ? xcd_remap(blockIdx.x, gridDim.x) : local % ntile;
+  const TnBlock blk = tn_block(p, ntile);
+  const int bid = blk.tile, mbeg = blk.mbeg, mend = blk.mend;
   const int n0 = (bid / ntk) * 128, k0 = (bid % ntk) * 128;
-  const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
-  const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
   if (mbeg >= mend) return;
   const int nsteps = (mend - mbeg + TN_BMK - 1) / TN_BMK;
 
@@ -1196,14 +1207,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 // of (32 FA WN) x (32 FB WK); operands arrive as 32-row slabs of 128-column sub-slabs (swizzled [32][128] layout above) in an NST-slot ring,
 // NST - 1 slabs in flight, one barrier per slab.  Instantiated as
 //   <2,2,2,2,4>  128 x 128, 4 waves, 16 KiB slabs, 64 KiB  -> 2 blocks per CU   (round 2's kernel; few-tile products: 512 x 512)
-//   <2,4,2,2,3> / <4,2,2,2,3>  128 x 256 / 256 x 128, 4 waves, 24 KiB slabs, 72 KiB -> 2 blocks per CU   (TFX_TN_TILE=1, A/B only)
 //   <2,4,4,2,4>  256 x 256, 8 waves, 32 KiB slabs, 128 KiB -> 1 block per CU    (7.8 KiB of L2 -> LDS traffic per MFLOP instead of 15.6)
 // What the counters and stamps said (profiles/r03_c_*): no bank conflicts and 3.5 % LDS issue stalls with either fragment ratio (1.0 or 0.75
-// transposed reads per MFMA) - the loop was neither LDS- nor MFMA-bound; the three tilings ran within 2 % of each other until the DMA issue
-// was spread (SPREAD below), after which the wide tiles lead: 2816 x 512 at M = 65536 713 -> 850 TFLOP/s, 4096 x 1024 830 -> 1100.
+// transposed reads per MFMA) - the loop was neither LDS- nor MFMA-bound; three tilings (also 128 x 256 with 4 waves) ran within 2 % of each
+// other until the DMA issue was spread over the MFMAs (see the slab loop), after which the wide tiles lead: 2816 x 512 at M = 65536
+// 713 -> 810 TFLOP/s, 4096 x 1024 830 -> 1140.
 // Fragments that lie wholly outside N / k_valid skip their MFMAs (wave-uniform), so the ragged last tile of N = 1544 costs its DMA only.
 constexpr int MW_ROWS = 32;
-template <bool SUM, int FA, int FB, int WN, int WK, int NST, bool SPREAD>
+template <bool SUM, int FA, int FB, int WN, int WK, int NST>
 __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p) {
   constexpr int NW = WN * WK;
   constexpr int TILE_N = 32 * FA * WN, TILE_K = 32 * FB * WK;
@@ -1219,12 +1230,9 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
   const int wn = w / WK, wk = w % WK;
   const int ntn = (p.N + TILE_N - 1) / TILE_N, ntk = (p.K + TILE_K - 1) / TILE_K;
   const int ntile = ntn * ntk;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int split = p.splits == 1 ? 0 : xcd + 8 * (local / ntile);
-  const int bid = p.splits == 1 ? xcd_remap(blockIdx.x, gridDim.x) : local % ntile;
+  const TnBlock blk = tn_block(p, ntile);
+  const int bid = blk.tile, mbeg = blk.mbeg, mend = blk.mend;
   const int n0 = (bid / ntk) * TILE_N, k0 = (bid % ntk) * TILE_K;
-  const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
-  const int mbeg = split * chunk, mend = min(p.M, mbeg + chunk);
   if (mbeg >= mend) return;
   const int nst = (mend - mbeg) / MW_ROWS;
 
@@ -1253,7 +1261,7 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
       gp[j] += gstep[j];
     }
   };
-  static_assert(!SPREAD || NPW <= FA * FB, "one DMA piece per MFMA pair");
+  static_assert(NPW <= FA * FB, "one DMA piece per MFMA pair");
 
   bool live_a[FA], live_b[FB];                                          // wave-uniform: the fragment holds at least one written row / column
 #pragma unroll
@@ -1315,7 +1323,6 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
     tw += c1 - c0;
     if (st == 0) TN_STAMP(1)
 #endif
-    if (!SPREAD && MORE) issue(nbuf);
     TN_CLK(c2)
 #ifdef TFX_TN_TIMING
     ti += c2 - c1;
@@ -1336,9 +1343,9 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
         bfr[ks][j] = lds_tr8_swz(sb + (c >> 7) * SUBE, 16 * ks + 8 * hi, 16 * ks + 8 * hi + 4, c & 127);
       }
     }
-    // SPREAD: the next slab's DMA pieces go out one per MFMA pair instead of as a burst behind the barrier.  Phase stamps of the burst form
-    // (tools/tn_timing.py, 2816 x 512): of 1570 clocks per slab and wave, 570 pass in the six `global_load_lds` issues - every wave of the CU
-    // queues its pieces at the address unit at the same moment (64 B/clk, 16 clocks per 1 KiB piece) and feeds no MFMA meanwhile.
+    // The next slab's DMA pieces go out one per MFMA pair, not as a burst behind the barrier.  Phase stamps of the burst form (tools/tn_timing.py,
+    // profiles/r03_c_tn_timing.txt, 2816 x 512): of 1570 clocks per slab and wave, 570 passed in the six `global_load_lds` issues - every wave
+    // of the CU queues its pieces at the address unit at the same moment (64 B/clk, 16 clocks per 1 KiB piece) and feeds no MFMA meanwhile.
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
@@ -1347,7 +1354,7 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
         for (int j = 0; j < FB; j++) {
           if (!CHECK || (live_a[i] && live_b[j])) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
           const int idx = (ks * FA + i) * FB + j;
-          if (SPREAD && MORE && (idx & 1) && (idx >> 1) < NPW) {
+          if (MORE && (idx & 1) && (idx >> 1) < NPW) {
             glds16_asm(gp[idx >> 1], S + nbuf * STAGE + loff[idx >> 1]);
             gp[idx >> 1] += gstep[idx >> 1];
             __builtin_amdgcn_sched_barrier(0);
@@ -1378,23 +1385,34 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
   }
   TN_STAMP(2)
 
+  // Output rows first, atomics after: loads, stores and atomics retire through the one in-order vmcnt, so a row-map load between two groups of
+  // atomics (`s_waitcnt vmcnt(0)` before its use) made every group wait for the previous group's round trip to L2 - 32 serial round trips,
+  // 47-64 k clocks per block = 13-29 % of the kernel in the phase stamps (profiles/r03_c_tn_timing.txt).
+  int out_row[FA][16];
 #pragma unroll
   for (int i = 0; i < FA; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int n = n0 + (wn * FA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (n >= p.N) continue;
-      const int no = p.rowmap ? p.rowmap[n] : n;
+      out_row[i][r] = n >= p.N ? -1 : p.rowmap ? p.rowmap[n] : n;
+    }
+  int out_col[FB];
+#pragma unroll
+  for (int j = 0; j < FB; j++) {
+    const int k = k0 + (wk * FB + j) * 32 + (l & 31);
+    out_col[j] = k < p.k_valid ? tn_out_col(p, k) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < FA; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int no = out_row[i][r];
       if (no < 0) continue;
       if (SUM && do_sum && (l & 31) == 0) atomicAdd(p.colsum + no, accs[SUM ? i : 0][r]);
+      float* crow = p.C + (size_t)no * p.ldc;
 #pragma unroll
-      for (int j = 0; j < FB; j++) {
-        const int k = k0 + (wk * FB + j) * 32 + (l & 31);
-        if (k < p.k_valid) {
-          const int ko = tn_out_col(p, k);
-          if (ko >= 0) atomicAdd(p.C + (size_t)no * p.ldc + ko, acc[i][j][r] * p.alpha);
-        }
-      }
+      for (int j = 0; j < FB; j++)
+        if (out_col[j] >= 0) atomicAdd(crow + out_col[j], acc[i][j][r] * p.alpha);
     }
   TN_STAMP(3)
 #ifdef TFX_TN_TIMING
@@ -1406,21 +1424,20 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
 #undef TN_CLK
 }
 
-// split count of a TN launch with `tiles` output tiles over M rows (tfx.h: splits == 0).  Each XCD owns whole row chunks and holds `resident`
-// blocks (1 or 2 per CU): minimise (block rounds per XCD) x (rows per block) plus a price per split for the fp32 atomics onto cold
-// gradient lines (0.03 of a full-M pass, tuned on the full training step, not on the L2-hot microbenchmark).
-static int tn_auto_splits(int M, int tiles, int resident) {
-  if (tiles >= 8 * resident) return 1;
-  static const int cand[6] = {8, 16, 24, 32, 48, 64};
-  double best = 1e30;
-  int splits = 8;
-  for (int s : cand) {
-    if (s > 8 && M / s < 256) break;
-    const int rounds = (tiles * s / 8 + resident - 1) / resident;
-    const double cost = rounds * (8.0 / s) + 0.03 * s;
-    if (cost < best - 1e-9) { best = cost; splits = s; }
-  }
-  return splits;
+// split count of a TN launch with `tiles` output tiles over M rows (tfx.h: splits == 0): the smallest count that puts `fill` x (resident block
+// slots) blocks on the chip, never more than one round of blocks.  Measured in the training step (profiles/r03_c_tn_splits.txt, one stream):
+// 256 x 256 tiles - 2816 x 512 (22 tiles) 256 / 225 / 220 / 215 us at 154 / 198 / 220 / 242 blocks and 341 us at 264 (a second round);
+// 1544 x 512 and 512 x 1408 flat (144 us) from 216 blocks on; 128 x 128 tiles (512 slots) - 512 x 512 (16 tiles) 63 / 60 / 74 / 66 / 68 us at
+// 208 / 256 / 320 / 384 / 512 blocks.  Past the knee more splits only add fp32 atomics: the kernels run against the power limit, not against
+// idle CUs.  Chunks stay >= 256 rows.
+static int tn_auto_splits(int M, int tiles, int kind) {
+  static double fill2 = -1, fill0 = -1;        // TFX_TN_FILL / TFX_TN_FILL0 (A/B): 256 x 256 tiles (256 slots) / the 4-wave tilings (512 slots)
+  if (fill2 < 0) { const char* e = getenv("TFX_TN_FILL"); fill2 = e ? atof(e) : 0.9; e = getenv("TFX_TN_FILL0"); fill0 = e ? atof(e) : 0.5; }
+  const int slots = kind == 2 ? 256 : 512;
+  const double want = (kind == 2 ? fill2 : fill0) * slots;
+  int s = 1;
+  while (tiles * s < want && tiles * (s + 1) <= slots && s < 64 && M / (s + 1) >= 256) s++;
+  return s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1499,14 +1516,9 @@ int gemm_nt(const GemmNT& p, hipStream_t s) {
 
 template <bool SUM, int FA, int FB, int WN, int WK, int NST> static void launch_tn_wide(const GemmTN& q, int grid, hipStream_t s) {
   constexpr int smem = NST * (FA * WN + FB * WK) / 4 * MW_ROWS * 128 * 2;
-  static int spread = -1;             // TFX_TN_SPREAD=0: the next slab's DMA pieces as one burst behind the barrier (A/B)
-  if (spread < 0) {
-    const char* e = getenv("TFX_TN_SPREAD"); spread = e ? atoi(e) : 1;
-    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  }
-  if (spread) hipLaunchKernelGGL((gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, true>), dim3(grid), dim3(64 * WN * WK), smem, s, q);
-  else hipLaunchKernelGGL((gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST, false>), dim3(grid), dim3(64 * WN * WK), smem, s, q);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  hipLaunchKernelGGL((gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST>), dim3(grid), dim3(64 * WN * WK), smem, s, q);
 }
 
 int gemm_tn(const GemmTN& p, hipStream_t s) {
@@ -1518,7 +1530,7 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  static int tile = -2;               // TFX_TN_TILE: force 0 = 128 x 128 blocks, 1 = 4-wave wide tiles, 2 = 256 x 256 (A/B); unset: by tile count
+  static int tile = -2;               // TFX_TN_TILE: force 0 = 128 x 128 blocks or 2 = 256 x 256 (A/B, tests); unset: by tile count
   if (tile == -2) { const char* e = getenv("TFX_TN_TILE"); tile = e ? atoi(e) : -1; }
   GemmTN q = p;
 #ifdef TFX_TN_TIMING
@@ -1526,22 +1538,15 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
 #else
   const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
 #endif
-  const int t42 = ((q.N + 255) / 256) * ((q.K + 127) / 128), t24 = ((q.N + 127) / 128) * ((q.K + 255) / 256);
   const int t44 = ((q.N + 255) / 256) * ((q.K + 255) / 256), t22 = ((q.N + 127) / 128) * ((q.K + 127) / 128);
-  const bool o24 = q.colsum || t24 <= t42;                        // 4-wave wide form: the orientation with fewer tiles (bias form: 64 A columns per wave)
   // 256 x 256 tiles once there are enough of them to fill the chip at <= 32 splits; below that (512 x 512: 4 tiles) the 128 x 128 blocks
-  const int kind = !dma_ok ? -1 : tile >= 0 ? tile : (t44 >= 8 ? 2 : 0);
-  const int tiles = kind == 2 ? t44 : kind == 1 ? (o24 ? t24 : t42) : t22;
-  if (q.splits == 0) q.splits = tn_auto_splits(q.M, tiles, kind == 2 ? 32 : 64);
-  q.splits = q.splits == 1 ? 1 : (q.splits + 7) / 8 * 8;          // one row-chunk per XCD at a time (see the kernels' block order)
-  const int grid = tiles * q.splits;
+  const int kind = !dma_ok ? -1 : tile == 0 || tile == 2 ? tile : (t44 >= 8 ? 2 : 0);
+  const int tiles = kind == 2 ? t44 : t22;
+  if (q.splits == 0) q.splits = tn_auto_splits(q.M, tiles, kind);
+  const int grid = (tiles * q.splits + 7) / 8 * 8;                // tn_block: 8 equal runs of (chunk, tile) pairs, one per XCD
   if (kind == 2) {
     if (q.colsum) launch_tn_wide<true, 2, 4, 4, 2, 4>(q, grid, s);
     else launch_tn_wide<false, 2, 4, 4, 2, 4>(q, grid, s);
-  } else if (kind == 1) {
-    if (q.colsum) launch_tn_wide<true, 2, 4, 2, 2, 3>(q, grid, s);
-    else if (o24) launch_tn_wide<false, 2, 4, 2, 2, 3>(q, grid, s);
-    else launch_tn_wide<false, 4, 2, 2, 2, 3>(q, grid, s);
   } else if (kind == 0) {
     if (q.colsum) launch_tn_wide<true, 2, 2, 2, 2, 4>(q, grid, s);
     else launch_tn_wide<false, 2, 2, 2, 2, 4>(q, grid, s);
