@@ -122,16 +122,21 @@ TFX_DEV void fast_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n
     const int m = m_w + i * 32 + r;
     mo[i] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
   }
+  // ONE branch around all eight loads: with a branch per load hipcc waits (`s_waitcnt vmcnt(0)`) at every join - eight serial round trips to L2
   f32x4 bias[2][4];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 2; j++)
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int n = n_w + j * 32 + 8 * g + 4 * hi;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      bias[j][g] = z;
-      if constexpr (EPI != EPI_GEGLU_BWD) { if (p.bias) bias[j][g] = *(const f32x4*)(p.bias + min(n, p.N - 4)); }   // uniform branch
+    for (int g = 0; g < 4; g++) bias[j][g] = zero4;
+  if constexpr (EPI != EPI_GEGLU_BWD) {
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
     }
+  }
   // side-data loads are unconditional (addresses clamped into range): a load under a divergent branch makes the
   // compiler fall back to vmcnt(0) at the join, which would drain the stores again
   auto load_in = [&](EpiIn<EPI>& in, int i) {
@@ -244,15 +249,18 @@ TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w
       const int m = m_w + i * 32 + q * 8 + (l >> 3);
       mo[i][q] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
     }
-  f32x4 bias[2][4];
+  f32x4 bias[2][4];                                            // one branch around the eight loads (see fast_epilogue)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 2; j++)
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      bias[j][g] = z;
-      if (p.bias) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
-    }
+    for (int g = 0; g < 4; g++) bias[j][g] = zero4;
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
+  }
   const bool col_ok = n_w + ch * 8 < p.N;
 #ifdef TFX_PP_TIMING
   unsigned long long* stamps = (unsigned long long*)p.aux + (size_t)blockIdx.x * 8;
@@ -270,12 +278,15 @@ TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w
         for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] + bias[j][g][e];
         stage_put4(s, r, j * 32 + 8 * g + 4 * hi, v);
       }
+    bf16x8 v[4];                                               // all four LDS reads ahead of the (branch-guarded) stores: one LDS latency per block, not four
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int row = q * 8 + (l >> 3);
-      const bf16x8 v = *(const bf16x8*)(s + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
-      if (col_ok && mo[i][q] >= 0) *(bf16x8*)((bf16*)p.C + (size_t)mo[i][q] * p.ldc + n_w + ch * 8) = v;
+      v[q] = *(const bf16x8*)(s + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (col_ok && mo[i][q] >= 0) *(bf16x8*)((bf16*)p.C + (size_t)mo[i][q] * p.ldc + n_w + ch * 8) = v[q];
 #ifdef TFX_PP_TIMING
     if (threadIdx.x == 0 && i < 2) stamps[6 + i] = __builtin_readcyclecounter();
 #endif
@@ -301,20 +312,24 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
     for (int q = 0; q < 2; q++) { const int m = m_w + i * 32 + q * 16 + (l >> 2); mo2[i][q] = (EPI == EPI_GEGLU && m < p.M) ? (p.rowmap ? p.rowmap[m] : m) : -1; }
   }
   auto flush64 = [&](const bf16* s, int i, int n_base, int Nout) {
+    bf16x8 v[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int row = q * 8 + (l >> 3);
-      const bf16x8 v = *(const bf16x8*)(s + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
-      if (n_base + ch * 8 < Nout && mo[i][q] >= 0) *(bf16x8*)((bf16*)p.C + (size_t)mo[i][q] * p.ldc + n_base + ch * 8) = v;
+      v[q] = *(const bf16x8*)(s + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (n_base + ch * 8 < Nout && mo[i][q] >= 0) *(bf16x8*)((bf16*)p.C + (size_t)mo[i][q] * p.ldc + n_base + ch * 8) = v[q];
   };
   if constexpr (EPI == EPI_GEGLU) {
-    f32x4 ba[4], bg[4];
+    f32x4 ba[4], bg[4];                                        // one branch around the eight loads (see fast_epilogue)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ba[g] = z; bg[g] = z;
-      if (p.bias) { const int n_a = min(n_w + 8 * g + 4 * hi, p.N - 36); ba[g] = *(const f32x4*)(p.bias + n_a); bg[g] = *(const f32x4*)(p.bias + n_a + 32); }
+    for (int g = 0; g < 4; g++) { ba[g] = zero4; bg[g] = zero4; }
+    if (p.bias) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) { const int n_a = min(n_w + 8 * g + 4 * hi, p.N - 36); ba[g] = *(const f32x4*)(p.bias + n_a); bg[g] = *(const f32x4*)(p.bias + n_a + 32); }
     }
     const int c4 = l & 3;
 #pragma unroll
@@ -329,13 +344,16 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
         stage_put4(s, r, nl, a); stage_put4(s, r, 32 + nl, gt); stage_put4_32(s + 2048, r, nl, h);
       }
       flush64(s, i, n_w, p.N);
+      bf16x8 hv[2];
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         const int row = q * 16 + (l >> 2);
-        const bf16x8 v = *(const bf16x8*)(s + 2048 + row * 32 + ((c4 ^ ((row >> 2) & 3)) << 3));
-        const int feat = (n_w >> 6) * 32 + c4 * 8;
-        if (n_w < p.N && mo2[i][q] >= 0) *(bf16x8*)((bf16*)p.C2 + (size_t)mo2[i][q] * p.ldc2 + feat) = v;
+        hv[q] = *(const bf16x8*)(s + 2048 + row * 32 + ((c4 ^ ((row >> 2) & 3)) << 3));
       }
+      const int feat = (n_w >> 6) * 32 + c4 * 8;
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (n_w < p.N && mo2[i][q] >= 0) *(bf16x8*)((bf16*)p.C2 + (size_t)mo2[i][q] * p.ldc2 + feat) = hv[q];
     }
   } else {   // EPI_GEGLU_BWD
     bf16x4 a4[2][2][4], g4[2][2][4];                           // [buffer][j][g]
