@@ -109,6 +109,17 @@ def cast_tuple(t, length=1):
     return t if isinstance(t, tuple) else ((t,) * length)
 
 
+def _bucket(x: int, min_step: int) -> int:
+    """round a ragged count up to a bucket: steps of a quarter of its power of two (1950 instances -> 2048, 7700 rows -> 8192), never below
+    `min_step` - a ragged corpus then lands on a handful of training plans instead of one per (64, 256) cell (a plan costs ~0.5 s to build and
+    owns every activation of the step; the plan cache holds 8).  Padding instances / rows are referenced by nothing and cost a sliver of the
+    small per-instance and per-row GEMMs."""
+    if x <= 0:
+        return x
+    step = max(min_step, (1 << (x.bit_length() - 1)) // 4)
+    return -(-x // step) * step
+
+
 _TRAIN_PAD = max(1, int(os.environ.get('TFX_TRAIN_PAD', '64')))
 
 
@@ -778,12 +789,12 @@ class Transfusion(nn.Module):
         ps.refresh_shadows(stream)
         # Ragged corpora change the number of modality instances and of latent rows with every batch.  A training plan owns every activation of the
         # step and its launch lists (building one costs far more than a step), so in the plain training case the plan is built for both counts ROUNDED
-        # UP - instances to 64, rows per type to 256 - and shared: padding instances are referenced by no token (their table gradients stay zero),
+        # UP - in steps of a quarter of the count's power of two, at least 64 instances / 256 rows per type (`_bucket`) - and shared: padding instances are referenced by no token (their table gradients stay zero),
         # padding rows scatter nowhere and are kept out of the losses (engine.Plan.set_rows).  TFX_PLAN_BUCKETS=0: exact counts (one plan per pair).
         bucket = (return_loss and not self._ext and not md.pos_types and ema is None and not return_only_pred_flows and not self.has_recon_loss
                   and not md.model_output_clean and os.environ.get('TFX_PLAN_BUCKETS', '1') != '0')
-        Ip = -(-I // 64) * 64 if (bucket and I > 0) else I
-        Rp = {t: -(-r // 256) * 256 for t, r in R.items()} if bucket else R
+        Ip = _bucket(I, 64) if (bucket and I > 0) else I
+        Rp = {t: _bucket(r, 256) for t, r in R.items()} if bucket else R
         plan = self._plan(b, n, Ip, Rp, training=return_loss)
         if md.model_output_clean:
             plan.set_clean_mode('model')                    # interleaved path: the model-space conversion (MP:786-792)
