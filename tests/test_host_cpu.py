@@ -262,3 +262,26 @@ def test_packer_matches_oracle_on_random_ragged_batches():
         flat = tm.tok_inst.reshape(-1)
         for s0, l0 in zip(ss, sl):
             assert (flat[s0:s0 + l0] == flat[s0]).all() and (flat[s0] >= 0 or l0 <= 8) and s0 // n == (s0 + l0 - 1) // n
+
+
+def test_reassigned_parameter_data_is_readopted_into_the_flat_buffer():
+    """`p.data = w` moves a parameter out of the flat master buffer the kernels and the fused optimizer read: the version check copies it back into its
+    slice, re-points the parameter and invalidates the bf16 shadows; `mark_weights_changed()` covers in-place edits through `.data` nothing can see."""
+    torch.manual_seed(0)
+    m = Transfusion(num_text_tokens=32, dim_latent=8, modality_default_shape=(2,), transformer=dict(dim=64, depth=1, dim_head=64, heads=1))
+    st = m.store
+    name, prm = next((n, p) for n, p in st.params.items() if p.dim() == 2)
+    st._shadow_version = st.params_version()                       # "shadows are current"
+    assert prm.data_ptr() == st.ptr(name)
+    w = torch.randn_like(prm.data)
+    prm.data = w                                                   # e.g. a checkpoint loader that assigns instead of copying
+    assert prm.data_ptr() != st.ptr(name)
+    st.params_version()
+    assert prm.data_ptr() == st.ptr(name) and torch.equal(st.view(name), w) and st._shadow_version is None
+    st._shadow_version = st.params_version()
+    prm.data.mul_(0.5)                                             # invisible: no counter, no pointer
+    assert st.params_version() == st._shadow_version
+    m.mark_weights_changed()
+    assert st._shadow_version is None
+    with pytest.raises(ValueError):
+        prm.data = torch.zeros(3, 3); st.params_version()

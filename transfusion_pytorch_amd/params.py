@@ -268,7 +268,22 @@ class ParamStore:
         self._shadow_version = None
 
     def params_version(self):
-        return sum(p._version for p in self.params.values()) + self.fourier_w._version
+        """changes autograd can see: the version counters (optimizers, `load_state_dict`, `p.copy_` ...).  A parameter whose `.data` was RE-ASSIGNED
+        (`p.data = w`) no longer points into the flat master buffer the kernels and the fused optimizer read: it is copied back into its slice and
+        re-pointed here.  In-place writes THROUGH `.data` (`p.data.mul_(0.5)`) bump no counter and move no pointer - nothing can see them; callers
+        that edit weights that way call `Transfusion.mark_weights_changed()`."""
+        ver = self.fourier_w._version
+        for name, prm in self.params.items():
+            if prm.data_ptr() != self.ptr(name):
+                v = self.view(name)
+                if prm.shape != v.shape:
+                    raise ValueError(f'parameter {name} was re-assigned with shape {tuple(prm.shape)}, the model was built for {tuple(v.shape)}')
+                with torch.no_grad():
+                    v.copy_(prm.data)
+                prm.data = v
+                self._shadow_version = None
+            ver += prm._version
+        return ver
 
     def ensure_grad_views(self):
         """(re)attach `.grad` views; zero the segments whose grad was None (fresh accumulation)."""

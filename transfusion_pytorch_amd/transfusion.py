@@ -528,6 +528,12 @@ class Transfusion(nn.Module):
         return fl, rec
 
     # ------------------------------------------------------------------ helpers
+    def mark_weights_changed(self):
+        """tell the model its weights were edited where nothing can see it - in place through `.data` (`p.data.mul_(0.5)`) or by a kernel of the
+        caller's: the bf16 shadows are rebuilt on the next call.  Not needed after optimizers, `load_state_dict`, `p.copy_` / `p.add_` under
+        `no_grad` (version counters) or `p.data = w` (re-adopted into the flat buffer, `ParamStore.params_version`)."""
+        self.store.mark_dirty()
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
