@@ -508,6 +508,49 @@ def test_losses():
     assert (dp[:, dl:] == 0).all()
 
 
+def test_cast_batch_plain_and_transposed_jobs_in_one_launch():
+    """`tfx_cast_batch`: every bf16 shadow of the parameter set in one launch - plain jobs (row map, column padding) and transposed jobs
+    (dst[c][r] = src[map(r)][c]) on sources that start at odd float offsets of one flat buffer (16-byte loads only where a row is aligned)."""
+    import ctypes
+    torch.manual_seed(2)
+    flat = torch.randn(400000, device=DEV)
+    specs = [(3, 200, 70, True, True), (1003, 130, 64, False, True), (20000, 512, 136, True, False), (100001, 64, 200, False, False),
+             (150002, 300, 129, True, True), (250000, 256, 256, False, True)]            # (offset, Rs, Cs, row map?, transposed?)
+    J = capi.STRUCTS['tfx_cast_job']
+    arr = (J * len(specs))()
+    keep, first = [], 0
+    for i, (off, Rs, Cs, use_map, tr) in enumerate(specs):
+        src = flat[off:off + Rs * Cs].view(Rs, Cs)
+        n_r = Rs + 24                                                    # logical rows: some map to nothing / past the source
+        rowmap = torch.randint(-1, Rs + 5, (n_r,), device=DEV, dtype=torch.int32) if use_map else None
+        if tr:
+            Rd, ldd = (Cs + 15) // 8 * 8, (n_r + 7) // 8 * 8             # dst rows = padded Cs, dst columns = padded logical rows
+            nb = ((ldd + 63) // 64) * ((Rd + 63) // 64)
+        else:
+            Rd, ldd = n_r, (Cs + 15) // 8 * 8
+            nb = (Rd * ldd + 2047) // 2048
+        dst = torch.full((Rd, ldd), float('nan'), device=DEV, dtype=BF)
+        for k, v in dict(src=src.data_ptr(), ld_src=Cs, Rs=Rs, Cs=Cs, rowmap=capi.ptr(rowmap), dst=dst.data_ptr(), ld_dst=ldd, Rd=Rd,
+                         Cd=n_r if tr else ldd, transposed=int(tr), first_block=first).items():
+            setattr(arr[i], k, v)
+        first += nb
+        ref = torch.zeros(n_r, Cs, device=DEV)
+        rows = rowmap.long() if use_map else torch.arange(n_r, device=DEV)
+        ok = (rows >= 0) & (rows < Rs)
+        ref[ok] = src[rows[ok]]
+        full = torch.zeros(Rd, ldd, device=DEV)
+        if tr:
+            full[:Cs, :n_r] = ref.T
+        else:
+            full[:, :Cs] = ref
+        keep.append((dst, full, rowmap, tr))
+    tab = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8).to(DEV)
+    capi.check(capi.lib().tfx_cast_batch(tab.data_ptr(), len(specs), first, stream()), 'tfx_cast_batch')
+    for i, (dst, full, _, tr) in enumerate(keep):
+        assert not torch.isnan(dst.float()).any(), f'job {i}: unwritten elements'
+        assert torch.equal(dst, full.to(BF)), f'job {i} ({"transposed" if tr else "plain"})'
+
+
 def test_param_plumbing():
     torch.manual_seed(0)
     Rs, Cs = 200, 70

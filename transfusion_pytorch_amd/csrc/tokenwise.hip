@@ -1680,26 +1680,50 @@ TFX_DEV void cast8_body(const tfx_cast_args& p, long long blk) {
   *(bf16x8*)(p.dst + i) = o;
 }
 TFX_DEV void cast64_t_body(const tfx_cast_args& p, int bx, int by, float (*tile)[65]) {
+  // dst[c][r] = src[map(r)][c] over a 64 (r) x 64 (c) tile.  Loads: every thread owns one 4-column group of four rows (r = rr + 16 k) - the four
+  // row-map entries first, then four 16-byte loads back to back (scalar where a row start is not 16-byte aligned or the tile hangs over Cs);
+  // stores: 16 bytes = 8 consecutive r of one dst row per thread and pass.  (Round 2's form read 4 bytes per lane with the row-map load inside
+  // the loop - two dependent round trips per iteration - and wrote 4 bytes per lane: 2.2 ms for the 604 M parameters of dim 1024 / depth 24.)
   const int r0 = bx * 64, c0 = by * 64;                     // r: dst column index, c: dst row index
   {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int j = ty; j < 64; j += 4) {
-      const int r = r0 + j, c = c0 + tx;
-      float v = 0.f;
-      if (r < p.Cd && c < p.Cs) {
-        const int rs = p.rowmap ? p.rowmap[r] : r;
-        if (rs >= 0 && rs < p.Rs) v = p.src[(size_t)rs * p.ld_src + c];
-      }
-      tile[j][tx] = v;
+    const int cq = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    const int c = c0 + 4 * cq;
+    int rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = r0 + rr + 16 * k;
+      rs[k] = r < p.Cd ? (p.rowmap ? p.rowmap[r] : r) : -1;
+      if (rs[k] >= p.Rs) rs[k] = -1;
     }
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      v[k] = z;
+      if (rs[k] >= 0 && c < p.Cs) {
+        const float* sp = p.src + (size_t)rs[k] * p.ld_src + c;
+        if (c + 4 <= p.Cs && (((uintptr_t)sp) & 15) == 0) v[k] = *(const f32x4*)sp;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (c + e < p.Cs) v[k][e] = sp[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) tile[rr + 16 * k][4 * cq + e] = v[k][e];
   }
   __syncthreads();
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int j = ty; j < 64; j += 8) {
-    const int c = c0 + j, r = r0 + 2 * tx;
-    if (c < p.Rd && r < p.ld_dst) {                        // ld_dst % 8 == 0 -> r + 1 is in range too
-      bf16x2 o; o[0] = f2bf(tile[2 * tx][j]); o[1] = f2bf(tile[2 * tx + 1][j]);
-      *(bf16x2*)(p.dst + (size_t)c * p.ld_dst + r) = o;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int q = threadIdx.x + 256 * k, row = q >> 3, ch = q & 7;
+    const int c = c0 + row, r = r0 + 8 * ch;
+    if (c < p.Rd && r < p.ld_dst) {                          // ld_dst % 8 == 0: the 8 elements stay inside the row
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = f2bf(tile[8 * ch + e][row]);
+      *(bf16x8*)(p.dst + (size_t)c * p.ld_dst + r) = o;
     }
   }
 }
