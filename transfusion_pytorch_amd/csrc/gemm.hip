@@ -356,37 +356,47 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
         if (n_w < p.N && mo2[i][q] >= 0) *(bf16x8*)((bf16*)p.C2 + (size_t)mo2[i][q] * p.ldc2 + feat) = hv[q];
     }
   } else {   // EPI_GEGLU_BWD
-    bf16x4 a4[2][2][4], g4[2][2][4];                           // [buffer][j][g]
-    auto load_aux = [&](int b, int i) {
-      const int m = min(m_w + i * 32 + r, p.M - 1);
-      const bf16* ap = p.aux + (size_t)m * p.ldaux + 4 * hi;
+    // The saved [a|g] of a 32-row block - for the wave's 64 dh columns 128 contiguous bf16 per row - comes in with 16-byte loads, 16 lanes per row
+    // (8 cache lines per instruction), passes through a wave-private LDS image (chunk index XOR (row & 15)) and is read back in fragment shape.
+    // Round 2 loaded it as 8-byte per-lane fragments: 32 rows = 32 cache lines behind every load instruction, 512 line visits per block against 64
+    // (the same address-coalescer walk that made the direct stores slow, see staged_epilogue_bf16).
+    bf16* sag = st + 2048;                                       // [32][128]; the output staging block keeps st[0, 2048)
+    const int cbase = min(n_w >> 5, (p.N >> 5) - 2) * 64;
+    bf16x8 pre[8];
+    auto load_aux = [&](int i) {
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const int blk = min((n_w >> 5) + j, (p.N >> 5) - 1);
-#pragma unroll
-        for (int g = 0; g < 4; g++) { a4[b][j][g] = *(const bf16x4*)(ap + blk * 64 + 8 * g); g4[b][j][g] = *(const bf16x4*)(ap + blk * 64 + 32 + 8 * g); }
+      for (int k = 0; k < 8; k++) {
+        const int q = l + 64 * k, row = q >> 4, cc = q & 15;
+        const int m = min(m_w + i * 32 + row, p.M - 1);
+        pre[k] = *(const bf16x8*)(p.aux + (size_t)m * p.ldaux + cbase + cc * 8);
       }
     };
-    load_aux(0, 0);
+    load_aux(0);
 #pragma unroll
     for (int i = 0; i < NI; i++) {
-      if (i + 1 < NI) load_aux((i + 1) & 1, i + 1);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int q = l + 64 * k, row = q >> 4, cc = q & 15;
+        *(bf16x8*)(sag + row * 128 + ((cc ^ (row & 15)) << 3)) = pre[k];
+      }
+      if (i + 1 < NI) load_aux(i + 1);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
-        bf16* s = st + j * 2048;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
+          const bf16x4 a4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + g) ^ (r & 15)) << 3) + 4 * hi);
+          const bf16x4 g4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + 4 + g) ^ (r & 15)) << 3) + 4 * hi);
           f32x4 da, dg;
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            const float dh = acc[i][j][4 * g + e], a = bf2f(a4[i & 1][j][g][e]), gg = bf2f(g4[i & 1][j][g][e]);
+            const float dh = acc[i][j][4 * g + e], a = bf2f(a4[e]), gg = bf2f(g4[e]);
             float E; const float cdf = gelu_cdf(gg, E);                                   // one exponential serves Phi and phi
             da[e] = dh * gg * cdf;
             dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * E);
           }
-          stage_put4(s, r, 8 * g + 4 * hi, da); stage_put4(s, r, 32 + 8 * g + 4 * hi, dg);
+          stage_put4(st, r, 8 * g + 4 * hi, da); stage_put4(st, r, 32 + 8 * g + 4 * hi, dg);
         }
-        if (n_w + j * 32 < p.N) flush64(s, i, ((n_w >> 5) + j) * 64, 2 * p.N);
+        if (n_w + j * 32 < p.N) flush64(st, i, ((n_w >> 5) + j) * 64, 2 * p.N);
       }
     }
   }
@@ -394,6 +404,7 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
 template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
   bool ok = ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0;
   if constexpr (EPI == EPI_GEGLU) ok = ok && (p.ldc2 & 7) == 0 && (((uintptr_t)p.C2) & 15) == 0;
+  if constexpr (EPI == EPI_GEGLU_BWD) ok = ok && (p.ldaux & 7) == 0 && (((uintptr_t)p.aux) & 15) == 0 && p.N >= 64;
   return ok;
 }
 // epilogue of the LDS-DMA kernels: staged stores where the layout allows, else the direct pipelined form.
