@@ -12,5 +12,5 @@ for i in 1 2 3; do
 done
 for v in "A=1" ${BASE:+"TFX_LIB=$R/transfusion_pytorch_amd/lib/libtfx_$BASE.so"}; do
 (cd /tmp && rm -rf /tmp/pt && env $v TFX_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --ragged-steps 0 --no-sample > /tmp/pt.log 2>&1)
-echo "$v" | cut -c1-20; python tools/prof_summary.py /tmp/pt/p_kernel_trace.csv --steady | grep "total\|gemm_nt_pp_kernel<5>\|gemm_nt_pp_kernel<4>" | cut -c1-120
+echo "$v" | cut -c1-20; python tools/prof_summary.py /tmp/pt/p_kernel_trace.csv --steady | grep "total\|gemm_nt_pp_kernel<5>\|gemm_nt_pp_kernel<3>" | cut -c1-120
 done

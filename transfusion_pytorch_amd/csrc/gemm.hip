@@ -292,6 +292,73 @@ TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w
 #endif
   }
 }
+// C(bf16)[mo][n_w .. n_w+63] = acc + bias + R.  The residual block (32 rows x 64 columns) comes in the way the result goes out: 16-byte
+// accesses, 8 lanes per 128-byte row segment, through the staging layout - written there by chunk, read back in fragment shape (the addresses
+// stage_put4 writes).  Needs what staged_epilogue_bf16 needs plus ldr % 8 == 0 and a 16-byte aligned R.
+template <int NI>
+TFX_DEV void staged_epilogue_resid(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+  int mo[NI][4], mr[NI][4];                                    // output row / residual row of (block i, pass q): tile row q * 8 + (l >> 3)
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int m = m_w + i * 32 + q * 8 + (l >> 3);
+      mo[i][q] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
+      mr[i][q] = p.resid_mapped ? max(mo[i][q], 0) : min(m, p.M - 1);
+    }
+  f32x4 bias[2][4];                                            // one branch around the eight loads (see fast_epilogue)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) bias[j][g] = zero4;
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
+  }
+  const bool col_ok = n_w + ch * 8 < p.N;
+  const int ncol = min(n_w + ch * 8, p.N - 8);
+  bf16* sr = st + 4096;                                        // residual block; the two output areas keep st[0, 4096)
+  bf16x8 pre[4];
+  auto load_r = [&](int i) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) pre[q] = *(const bf16x8*)(p.R + (size_t)mr[i][q] * p.ldr + ncol);
+  };
+  load_r(0);
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = q * 8 + (l >> 3);
+      *(bf16x8*)(sr + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)) = pre[q];
+    }
+    if (i + 1 < NI) load_r(i + 1);
+    bf16* s = st + (i & 1) * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int col = j * 32 + 8 * g + 4 * hi;
+        const bf16x4 rv = *(const bf16x4*)(sr + r * 64 + (((col >> 3) ^ ((r >> 1) & 7)) << 3) + (col & 7));
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] + bias[j][g][e] + bf2f(rv[e]);
+        stage_put4(s, r, col, v);
+      }
+    bf16x8 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = q * 8 + (l >> 3);
+      v[q] = *(const bf16x8*)(s + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (col_ok && mo[i][q] >= 0) *(bf16x8*)((bf16*)p.C + (size_t)mo[i][q] * p.ldc + n_w + ch * 8) = v[q];
+  }
+}
 // 32x32 bf16 block (64-byte rows; chunk XOR ((row >> 2) & 3)) for the GEGLU product h = a * gelu(g)
 TFX_DEV void stage_put4_32(bf16* st, int row, int col, f32x4 v) {
   bf16x4 o; o[0] = f2bf(v[0]); o[1] = f2bf(v[1]); o[2] = f2bf(v[2]); o[3] = f2bf(v[3]);
@@ -405,6 +472,7 @@ template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
   bool ok = ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0;
   if constexpr (EPI == EPI_GEGLU) ok = ok && (p.ldc2 & 7) == 0 && (((uintptr_t)p.C2) & 15) == 0;
   if constexpr (EPI == EPI_GEGLU_BWD) ok = ok && (p.ldaux & 7) == 0 && (((uintptr_t)p.aux) & 15) == 0 && p.N >= 64;
+  if constexpr (EPI == EPI_RESID) ok = ok && (p.ldr & 7) == 0 && (((uintptr_t)p.R) & 15) == 0 && p.N >= 8;
   return ok;
 }
 // epilogue of the LDS-DMA kernels: staged stores where the layout allows, else the direct pipelined form.
@@ -415,6 +483,8 @@ TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w
     if (can_stage<EPI>(p)) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }
   } else if constexpr (EPI == EPI_GEGLU || EPI == EPI_GEGLU_BWD) {
     if (can_stage<EPI>(p)) { staged_epilogue_geglu<EPI, NI>(p, acc, m_w, n_w, st); return; }
+  } else if constexpr (EPI == EPI_RESID) {
+    if (can_stage<EPI>(p)) { staged_epilogue_resid<NI>(p, acc, m_w, n_w, st); return; }
   }
   fast_epilogue<EPI, NI>(p, acc, m_w, n_w);
 }
