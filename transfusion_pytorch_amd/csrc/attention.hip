@@ -159,6 +159,42 @@ TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
 // blocks), and since workgroups go to the XCDs round-robin in linear order, every tile of one (head, sample) lands on the SAME XCD
 // whenever heads * samples is a multiple of 8 (its K / V stay in that XCD's L2).  `order` == 0 is the tile-fastest grid
 // (tiles, heads, samples) of the first version (env TFX_ATTN_ORDER=0, A/B).
+// A wave's 32 x 64 bf16 output block (this lane: row l & 31, columns db * 32 + 8 rg + 4 hi .. + 3) leaves through a wave-private 4 KiB LDS image:
+// 16-byte stores, 8 lanes per 128-byte row = 8 cache lines per instruction.  The direct form - 8 bytes per lane in accumulator shape - puts
+// 32 rows behind every store instruction and visits each line 8 times (the address coalescer walks the lines one by one: the same effect that
+// cost the NT epilogues 7 k clocks per tile, gemm.hip staged_epilogue_bf16).  `st` must be free: the callers pass a tile buffer behind a barrier.
+// Falls back to the direct stores when a row is not 16-byte aligned.
+TFX_DEV void wave_block_store(bf16* st, const bf16x4 (&v)[2][4], bf16* g0, int ld, int rows_valid) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+  if (((ld & 7) | (int)(((uintptr_t)g0 >> 1) & 7)) != 0) {                      // wave-uniform
+    if (r < rows_valid) {
+#pragma unroll
+      for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) *(bf16x4*)(g0 + (size_t)r * ld + db * 32 + 8 * rg + 4 * hi) = v[db][rg];
+    }
+    return;
+  }
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int col = db * 32 + 8 * rg + 4 * hi;
+      *(bf16x4*)(st + r * 64 + (((col >> 3) ^ ((r >> 1) & 7)) << 3) + (col & 7)) = v[db][rg];
+    }
+  bf16x8 t[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = q * 8 + (l >> 3);
+    t[q] = *(const bf16x8*)(st + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = q * 8 + (l >> 3);
+    if (row < rows_valid) *(bf16x8*)(g0 + (size_t)row * ld + ch * 8) = t[q];
+  }
+}
+
 struct BlockId { int tile, h, b; };
 TFX_DEV BlockId decode_block(int order, int ntile, bool heavy_last_tile) {     // (scalars only: no reference to the kernel-argument struct)
   BlockId o;
@@ -473,20 +509,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) 
   asm volatile("s_nop 15\n\ts_nop 15" : "+v"(o[0]), "+v"(o[1]));              // the asm MFMAs' results are read by vector code from here on
   float ls = lsum[0] + lsum[1];
   ls += __shfl_xor(ls, 32, 64);
-  if (qrow < n) {
-    const float g = sigmoidf_(bf2f(p.gate[(tok0 + qrow) * p.ld_gate + h]));
+  {
+    const float g = sigmoidf_(bf2f(p.gate[(tok0 + qc) * p.ld_gate + h]));
     const float sc = g * __builtin_amdgcn_rcpf(ls);
-    bf16* op = p.out + (tok0 + qrow) * p.ld_out + h * DH;
+    bf16x4 ov[2][4];
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        bf16x4 v;
+      for (int rg = 0; rg < 4; rg++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = f2bf(o[db][rg * 4 + e] * sc);
-        *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
-      }
-    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = __log2f(ls) * LN2;
+        for (int e = 0; e < 4; e++) ov[db][rg][e] = f2bf(o[db][rg * 4 + e] * sc);
+    __syncthreads();                                            // every wave is through with the K / V tiles: their LDS becomes the staging area
+    wave_block_store(&Ks[0][0] + w * 2048, ov, p.out + (tok0 + q0 + w * 32) * p.ld_out + h * DH, p.ld_out, n - (q0 + w * 32));
+    if (qrow < n && hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = __log2f(ls) * LN2;
   }
 }
 
@@ -595,17 +630,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
       }
     }
   }
-  if (qrow < n) {
-    bf16* op = p.dq + (tok0 + qrow) * p.ld_dq + h * DH;
+  {
+    bf16x4 ov[2][4];
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        bf16x4 v;
+      for (int rg = 0; rg < 4; rg++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = f2bf(dq[db][rg * 4 + e]);
-        *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
-      }
+        for (int e = 0; e < 4; e++) ov[db][rg][e] = f2bf(dq[db][rg * 4 + e]);
+    __syncthreads();                                            // the K / V tiles are free: staging area of the coalesced stores
+    wave_block_store((w < 2 ? Ks : Vs) + (w & 1) * 2048, ov, p.dq + (tok0 + q0 + w * 32) * p.ld_dq + h * DH, p.ld_dq, n - (q0 + w * 32));
   }
 }
 
@@ -723,19 +757,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
       }
     }
   }
-  if (krow < n) {
-    bf16* okp = p.dk + (tok0 + krow) * p.ld_dk + h * DH;
-    bf16* ovp = p.dv + (tok0 + krow) * p.ld_dv + h * DH;
+  {
+    bf16x4 kv[2][4], vv[2][4];
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        bf16x4 a, c;
+      for (int rg = 0; rg < 4; rg++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) { a[e] = f2bf(dk[db][rg * 4 + e]); c[e] = f2bf(dv[db][rg * 4 + e]); }
-        *(bf16x4*)(okp + db * 32 + 8 * rg + 4 * hi) = a;
-        *(bf16x4*)(ovp + db * 32 + 8 * rg + 4 * hi) = c;
-      }
+        for (int e = 0; e < 4; e++) { kv[db][rg][e] = f2bf(dk[db][rg * 4 + e]); vv[db][rg][e] = f2bf(dv[db][rg * 4 + e]); }
+    __syncthreads();                                            // the Q / dO tiles are free: staging area of the coalesced stores
+    bf16* st = (w < 2 ? Qs : Ds) + (w & 1) * 2048;
+    const int rows = n - (k0 + w * 32);
+    wave_block_store(st, kv, p.dk + (tok0 + k0 + w * 32) * p.ld_dk + h * DH, p.ld_dk, rows);
+    wave_block_store(st, vv, p.dv + (tok0 + k0 + w * 32) * p.ld_dv + h * DH, p.ld_dv, rows);
   }
 }
 
