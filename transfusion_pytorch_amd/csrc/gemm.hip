@@ -1142,7 +1142,8 @@ TFX_DEV bf16x8 lds_tr8_swz(const bf16* tile, int rowA, int rowB, int c0) {
 // 18000 cycles (half a K = 512 tile) = -2.0 ... -3.4 % step time; the delayed blocks' tiles run faster (80 % of the inserted
 // wait is recovered inside the GEMM) and the kernels that FOLLOW (attention -6 %, TN -3 %) run at higher clocks - the GEMM
 // phase is power-limited (tools/clock_probe.hip) and the smoother draw leaves the controller more headroom.  The same delay
-// in the TN kernel measured no effect.
+// in the TN kernel measured no effect.  Round 3, after the epilogues got shorter: 12000 cycles (-0.13 ... -0.25 ms against 18000 on two boxes,
+// flat between 6000 and 15000 on a third; 0 = +0.2 ms).
 TFX_DEV void dephase_first_round(int cycles, int first_round_blocks) {
   if (cycles > 0 && (int)blockIdx.x < first_round_blocks && (blockIdx.x & 1)) {
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -1581,7 +1582,7 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
     const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
     if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
     static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
-    if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 18000; }
+    if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
     hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p, stagger);
     return (int)hipGetLastError();
   }
