@@ -1,0 +1,8 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
+python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "qk_norm or rope" 2>&1 | grep -E "passed|failed" | tail -2
+for v in "TFX_QKB_GRID=256" "TFX_QKB_GRID=512" "TFX_QKB_GRID=128"; do
+(cd /tmp && rm -rf /tmp/pt && env $v TFX_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/pt -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --ragged-steps 0 --no-sample > /tmp/pt.log 2>&1)
+echo "$v"; python tools/prof_summary.py /tmp/pt/p_kernel_trace.csv --steady | grep "total\|qk_norm_rope" | cut -c1-120
+done

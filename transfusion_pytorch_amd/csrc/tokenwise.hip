@@ -1467,10 +1467,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args 
   }
 }
 
-__global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args p) {
-  __shared__ float sg[2][64];
-  if (threadIdx.x < 128) sg[threadIdx.x >> 6][threadIdx.x & 63] = 0.f;
-  __syncthreads();
+__global__ __launch_bounds__(1024) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args p) {
+  __shared__ float sg[16][2][64];                      // per wave: the gamma gradients of q / k, one value per head column
   const int sub = threadIdx.x & 7;      // constant per thread (grid stride is a multiple of 8 threads)
   float pq[8], pk[8];
 #pragma unroll
@@ -1516,12 +1514,26 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_k(tfx_qk_norm_rope_args 
     for (int e = 0; e < 8; e++) o[e] = f2bf(dyn[e] * inv - v[e] * k);
     *(bf16x8*)(p.dqkv + (size_t)t * p.ld_dqkv + col) = o;
   }
+  // the 8 lanes of a wave that own the same 8 columns (lane & 7) are summed with three cross-lane exchanges, the four waves through plain LDS
+  // stores: 16 LDS float atomics per thread with 8 lanes on every address were a ~10 us tail on a 100 us launch (ds_add_f32 with conflicts
+  // runs at hundreds of clocks per instruction - measured for the AttentionResidual backward earlier this round)
 #pragma unroll
-  for (int e = 0; e < 8; e++) { atomicAdd(&sg[0][sub * 8 + e], pq[e]); atomicAdd(&sg[1][sub * 8 + e], pk[e]); }
+  for (int e = 0; e < 8; e++) {
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) { pq[e] += __shfl_xor(pq[e], m, 64); pk[e] += __shfl_xor(pk[e], m, 64); }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) { sg[wv][0][lane * 8 + e] = pq[e]; sg[wv][1][lane * 8 + e] = pk[e]; }
+  }
   __syncthreads();
   if (threadIdx.x < 128) {
-    float s = sg[threadIdx.x >> 6][threadIdx.x & 63];
-    if (s != 0.f) atomicAdd((threadIdx.x < 64 ? p.dgamma_q : p.dgamma_k) + (threadIdx.x & 63), s);
+    const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float s = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; i++) s += sg[i][which][c];
+    if (s != 0.f) atomicAdd((which == 0 ? p.dgamma_q : p.dgamma_k) + c, s);
   }
 }
 
@@ -2086,8 +2098,15 @@ int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* s) {
 int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* s) {
   long long nthreads = (long long)a->T * 2 * a->H * 8;
   if (nthreads >= (1ll << 31)) return -3;
-  long long g = (nthreads + 255) / 256; if (g > MAXB) g = MAXB;
-  hipLaunchKernelGGL(qk_norm_rope_bwd_k, dim3((unsigned)g), dim3(256), 0, ST(s), *a); RET();
+  // 1024-thread blocks, at most one per CU: every block ends in 128 global atomics onto the SAME 128 gamma-gradient addresses, and same-address
+  // atomics retire at about 15 ns apiece - 1024 blocks of 256 threads spent 15 us of a 94 us launch there, 4096 blocks 61 us of 150
+  // (gpurun_out/r03qkb*_call.log).  TFX_QKB_GRID forces a block count (A/B).
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("TFX_QKB_GRID"); forced = e ? atoi(e) : 0; }
+  long long g = (nthreads + 1023) / 1024;
+  const long long cap = forced > 0 ? forced : 256;
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(qk_norm_rope_bwd_k, dim3((unsigned)g), dim3(1024), 0, ST(s), *a); RET();
 }
 int tfx_noise_mix(const tfx_noise_mix_args* a, void* s) {
   long long n = (long long)a->R * a->ld_xt; if (n == 0) return 0;
