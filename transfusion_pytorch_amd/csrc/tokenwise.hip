@@ -2081,7 +2081,9 @@ int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_ar
     // few sources, narrow rows: d w partials in registers, every row of the token in flight at once
     auto fn = attnres_pull_reg_k<1, 8>;
     const int items = a->n_seg > 0 ? a->n_seg : a->T;
-    int grid = (items + 7) / 8; const int cap = var == 5 ? 1024 : resident_blocks(fn, 512, acc);
+    static int forced = -1;                 // TFX_PULL_GRID (A/B): block count of the register form
+    if (forced < 0) { const char* e = getenv("TFX_PULL_GRID"); forced = e ? atoi(e) : 0; }
+    int grid = (items + 7) / 8; const int cap = forced > 0 ? forced : var == 5 ? 1024 : resident_blocks(fn, 512, acc);
     if (grid > cap) grid = cap; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), acc, ST(s), *a, bb, hp); RET();
   }
