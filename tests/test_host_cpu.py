@@ -285,3 +285,14 @@ def test_reassigned_parameter_data_is_readopted_into_the_flat_buffer():
     assert st._shadow_version is None
     with pytest.raises(ValueError):
         prm.data = torch.zeros(3, 3); st.params_version()
+
+
+def test_ragged_count_buckets():
+    """training-plan buckets for ragged instance / latent-row counts: steps of a quarter of the count's power of two, never below the minimum step,
+    never below the count, and few distinct values over a corpus-like spread (a plan costs ~0.5 s to build; the cache holds 8)."""
+    from transfusion_pytorch_amd.transfusion import _bucket
+    assert [_bucket(x, 64) for x in (0, 1, 63, 64, 65, 200, 1024, 1025, 1950, 2048, 2049)] == [0, 64, 64, 64, 128, 256, 1024, 1280, 2048, 2048, 2560]
+    assert [_bucket(x, 256) for x in (5, 256, 257, 7700, 8192, 8193)] == [256, 256, 512, 8192, 8192, 10240]
+    for lo, hi, step in ((1700, 2100, 64), (7000, 8400, 256)):
+        vals = {_bucket(x, step) for x in range(lo, hi)}
+        assert all(b >= x for x in range(lo, hi) for b in [_bucket(x, step)]) and len(vals) <= 3
