@@ -991,6 +991,7 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
 #pragma unroll
           for (int e = 0; e < 8; e++) G.v[i][e] = 0.f;
       }
+      float k2sum = 0.f;                                        // sum_j k2_jl: the - k2 h_l terms of all sources leave as one row pass
       for (int j0 = 0; j0 < ns; j0 += JC) {
         if (j0 > 0) {
 #pragma unroll
@@ -1019,6 +1020,7 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
           const float a = lane_bcast(sv[0], j), inv = lane_bcast(sv[1], j), sj = lane_bcast(sv[2], j);
           const float ds = a * (da - dsum);
           const float k1 = ds * inv, k2 = k1 * sj * inv;
+          k2sum += k2;
           const float* wj = REG ? (dyn + (size_t)j * d) : srcs[j].w;
 #pragma unroll
           for (int i = 0; i < NC; i++) {
@@ -1028,7 +1030,7 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
 #pragma unroll
             for (int e = 0; e < 8; e++) {
               const float we = e < 4 ? w0[e & 3] : w1[e & 3];
-              G.v[i][e] += a * gj.v[i][e] + k1 * we - k2 * h.v[i][e];
+              G.v[i][e] += a * gj.v[i][e] + k1 * we;             // (- k2 h: one pass behind the sources with the summed k2)
               const float ph = k1 * h.v[i][e];
               if constexpr (REG) pw[jj].v[i][e] += ph;
               else atomicAdd(dyn + (size_t)j * d + c * 8 + e, ph);
@@ -1036,6 +1038,10 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
           }
         }
       }
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) G.v[i][e] -= k2sum * h.v[i][e];
 #pragma unroll
       for (int i = 0; i < NC; i++)
 #pragma unroll
@@ -1281,6 +1287,7 @@ __global__ __launch_bounds__(512) void attnres_pull_dma_k(tfx_attnres_pull_args 
       }
       if (has_post) { ring_raw(rr, acquire(), lane, d); widen(yy, rr); }
       float k1_l = 0.f;                                         // lane j: k1 of source j (exported when NJ == 0)
+      float k2sum = 0.f;                                        // sum_j k2_jl: the - k2 h_l terms of all sources leave as one row pass
       auto one_source = [&](int j, Row<NC>& pwj) {
         Row<NC> gj; ring_raw(rr, acquire(), lane, d); widen(gj, rr);
         const float da = row_dot<NC>(gj, h);
@@ -1294,6 +1301,7 @@ __global__ __launch_bounds__(512) void attnres_pull_dma_k(tfx_attnres_pull_args 
         const float a = lane_bcast(sv[0], j), inv = lane_bcast(sv[1], j), sj = lane_bcast(sv[2], j);
         const float ds = a * (da - dsum);
         const float k1 = ds * inv, k2 = k1 * sj * inv;
+        k2sum += k2;
         if (!REG && lane == j) k1_l = k1;
 #pragma unroll
         for (int i = 0; i < NC; i++) {
@@ -1312,7 +1320,7 @@ __global__ __launch_bounds__(512) void attnres_pull_dma_k(tfx_attnres_pull_args 
           }
 #pragma unroll
           for (int e = 0; e < 8; e++) {
-            G.v[i][e] += a * gj.v[i][e] + k1 * w[e] - k2 * h.v[i][e];
+            G.v[i][e] += a * gj.v[i][e] + k1 * w[e];             // (- k2 h: one pass behind the sources with the summed k2)
             if (REG) pwj.v[i][e] += k1 * h.v[i][e];
           }
         }
@@ -1326,6 +1334,10 @@ __global__ __launch_bounds__(512) void attnres_pull_dma_k(tfx_attnres_pull_args 
         for (int j = 0; j < ns; j++) one_source(j, pw[0]);
         if (lane < ns) p.k1[(size_t)t * p.ld_k1 + lane] = f2bf(k1_l);
       }
+#pragma unroll
+      for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) G.v[i][e] -= k2sum * h.v[i][e];
 #pragma unroll
       for (int i = 0; i < NC; i++)
 #pragma unroll
