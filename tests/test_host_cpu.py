@@ -296,3 +296,28 @@ def test_ragged_count_buckets():
     for lo, hi, step in ((1700, 2100, 64), (7000, 8400, 256)):
         vals = {_bucket(x, step) for x in range(lo, hi)}
         assert all(b >= x for x in range(lo, hi) for b in [_bucket(x, step)]) and len(vals) <= 3
+
+
+def test_weight_gradient_gemm_plan_rule():
+    """`tfx_gemm_tn_plan` (host logic of the TN launcher, no device): 256 x 256 tiles from 8 tiles on, 128 x 128 below; the split count is the smallest
+    that puts 0.9 x 256 (0.5 x 512) blocks on the chip in ONE round, chunks of at least 256 rows; explicit counts are honoured; grids are multiples of 8."""
+    lib = capi.lib()
+
+    def plan(M, N, K, splits=0, colsum=0, a_rowmap=0):
+        a = capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, lda=(N + 7) // 8 * 8, a_cols=(N + 7) // 8 * 8, ldb=(K + 7) // 8 * 8, b_cols=(K + 7) // 8 * 8,
+                           ldc=K, k_valid=K, splits=splits, accumulate=1, alpha=1.0, colsum=colsum, a_rowmap=a_rowmap)
+        out = [ctypes.c_int32(-9) for _ in range(4)]
+        assert lib.tfx_gemm_tn_plan(ctypes.byref(a), *[ctypes.byref(o) for o in out]) == 0
+        return tuple(o.value for o in out)                    # kind, tiles, splits, grid
+
+    T = 65536
+    assert plan(T, 2816, 512) == (2, 22, 11, 248)              # 242 blocks on 256 CUs (8 splits = 176, 12 = a second round)
+    assert plan(T, 1544, 512) == (2, 14, 17, 240)
+    assert plan(T, 512, 1408) == (2, 12, 20, 240)
+    assert plan(T, 512, 512) == (0, 16, 16, 256)               # 4 tiles of 256 x 256: the 128 x 128 form at half of its 512 block slots
+    assert plan(T, 24576, 2048) == (2, 768, 1, 768)            # more tiles than slots: no split
+    assert plan(T, 5632, 1024) == (2, 88, 2, 176)              # 3 splits would open a second round
+    assert plan(512, 512, 512)[2] == 2                         # chunks stay >= 256 rows
+    assert plan(T, 1544, 512, splits=8) == (2, 14, 8, 112)     # explicit counts as given
+    assert plan(1000, 200, 136)[0] == -1 and plan(T, 512, 512, a_rowmap=64)[0] == -1      # M % 64 != 0 / gathered rows: the register-staged kernel
+    assert all(plan(T, n, k)[3] % 8 == 0 for n in (264, 520, 1544, 3080) for k in (384, 512, 768, 1024))

@@ -1621,6 +1621,33 @@ template <bool SUM, int FA, int FB, int WN, int WK, int NST> static void launch_
   hipLaunchKernelGGL((gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST>), dim3(grid), dim3(64 * WN * WK), smem, s, q);
 }
 
+// what gemm_tn launches for a shape: kernel form (-1 register-staged fallback, 0 = 128 x 128 / 4 waves, 2 = 256 x 256 / 8 waves), output tiles,
+// row chunks, grid.  Pure host logic (tfx.h tfx_gemm_tn_plan: the CPU tests pin the split rule through it).
+struct TnPlan { int kind, tiles, splits, grid; };
+static TnPlan tn_plan(const GemmTN& q) {
+  static int tile = -2;               // TFX_TN_TILE: force 0 = 128 x 128 blocks or 2 = 256 x 256 (A/B, tests); unset: by tile count
+  if (tile == -2) { const char* e = getenv("TFX_TN_TILE"); tile = e ? atoi(e) : -1; }
+#ifdef TFX_TN_TIMING
+  const bool dma_ok = true;
+#else
+  const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
+#endif
+  const int t44 = ((q.N + 255) / 256) * ((q.K + 255) / 256), t22 = ((q.N + 127) / 128) * ((q.K + 127) / 128);
+  TnPlan pl;
+  // 256 x 256 tiles once there are enough of them to fill the chip at <= 32 splits; below that (512 x 512: 4 tiles) the 128 x 128 blocks
+  pl.kind = !dma_ok ? -1 : tile == 0 || tile == 2 ? tile : (t44 >= 8 ? 2 : 0);
+  pl.tiles = pl.kind == 2 ? t44 : t22;
+  pl.splits = q.splits == 0 ? tn_auto_splits(q.M, pl.tiles, pl.kind) : q.splits;
+  pl.grid = (pl.tiles * pl.splits + 7) / 8 * 8;                   // tn_block: 8 equal runs of (chunk, tile) pairs, one per XCD
+  return pl;
+}
+int gemm_tn_plan(const GemmTN& p, int* kind, int* tiles, int* splits, int* grid) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 0) return -1;
+  const TnPlan pl = tn_plan(p);
+  if (kind) *kind = pl.kind; if (tiles) *tiles = pl.tiles; if (splits) *splits = pl.splits; if (grid) *grid = pl.grid;
+  return 0;
+}
+
 int gemm_tn(const GemmTN& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 0) return -1;
   if ((p.lda | p.ldb | p.a_cols | p.b_cols) & 7) return -2;
@@ -1630,20 +1657,10 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  static int tile = -2;               // TFX_TN_TILE: force 0 = 128 x 128 blocks or 2 = 256 x 256 (A/B, tests); unset: by tile count
-  if (tile == -2) { const char* e = getenv("TFX_TN_TILE"); tile = e ? atoi(e) : -1; }
   GemmTN q = p;
-#ifdef TFX_TN_TIMING
-  const bool dma_ok = true;
-#else
-  const bool dma_ok = use_glds() && q.M % TN_BMK == 0 && !q.a_rowmap && !q.b_rowmap && q.a_cols >= 8 && q.b_cols >= 8;
-#endif
-  const int t44 = ((q.N + 255) / 256) * ((q.K + 255) / 256), t22 = ((q.N + 127) / 128) * ((q.K + 127) / 128);
-  // 256 x 256 tiles once there are enough of them to fill the chip at <= 32 splits; below that (512 x 512: 4 tiles) the 128 x 128 blocks
-  const int kind = !dma_ok ? -1 : tile == 0 || tile == 2 ? tile : (t44 >= 8 ? 2 : 0);
-  const int tiles = kind == 2 ? t44 : t22;
-  if (q.splits == 0) q.splits = tn_auto_splits(q.M, tiles, kind);
-  const int grid = (tiles * q.splits + 7) / 8 * 8;                // tn_block: 8 equal runs of (chunk, tile) pairs, one per XCD
+  const TnPlan pl = tn_plan(q);
+  q.splits = pl.splits;
+  const int kind = pl.kind, grid = pl.grid;
   if (kind == 2) {
     if (q.colsum) launch_tn_wide<true, 2, 4, 4, 2, 4>(q, grid, s);
     else launch_tn_wide<false, 2, 4, 4, 2, 4>(q, grid, s);
