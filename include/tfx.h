@@ -58,6 +58,10 @@ typedef struct {
   const tfx_bf16* aux; int32_t ldaux;
 } tfx_gemm_nt_args;
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
+/* which kernel tfx_gemm_nt would launch for these arguments and on how many blocks, without launching (host logic only, no device needed):
+ * 0 register-staged fallback, 1 LDS-DMA 128 x 128, 2 "mid" (<= one 128 x 128 tile per CU), 3 ping-pong 256 x 256, 4 skinny (M <= 512 ... 1024),
+ * 5 decode (M <= 1024, K split across the waves). */
+int tfx_gemm_nt_plan(const tfx_gemm_nt_args* a, int32_t* kind, int32_t* grid);
 
 /* C[rowmap[n]][k] += alpha * sum_m A[m][n] * B[m][k]   (fp32 C, ALWAYS accumulates: split-M partial sums are
  * added with fp32 atomics, the caller zeroes C when it wants a plain product; `accumulate` is ignored).

@@ -321,3 +321,28 @@ def test_weight_gradient_gemm_plan_rule():
     assert plan(T, 1544, 512, splits=8) == (2, 14, 8, 112)     # explicit counts as given
     assert plan(1000, 200, 136)[0] == -1 and plan(T, 512, 512, a_rowmap=64)[0] == -1      # M % 64 != 0 / gathered rows: the register-staged kernel
     assert all(plan(T, n, k)[3] % 8 == 0 for n in (264, 520, 1544, 3080) for k in (384, 512, 768, 1024))
+
+
+def test_nt_gemm_kernel_selection():
+    """`tfx_gemm_nt_plan` (host logic of the NT launcher, no device): which kernel a shape runs on and its grid."""
+    lib = capi.lib()
+    FALLBACK, GLDS, MID, PP, SKINNY, DECODE = range(6)
+
+    def plan(M, N, K):
+        a = capi.make_args('tfx_gemm_nt_args', M=M, N=N, K=K, lda=K, ldb=K, ldc=N, epi=capi.ENUMS['TFX_EPI_BF16'])
+        kind, grid = ctypes.c_int32(-9), ctypes.c_int32(-9)
+        rc = lib.tfx_gemm_nt_plan(ctypes.byref(a), ctypes.byref(kind), ctypes.byref(grid))
+        return rc, kind.value, grid.value
+
+    T = 65536
+    assert plan(T, 1544, 512) == (0, PP, 256 * 7)              # the training step: 256 x 256 tiles, ragged last N tile included
+    assert plan(T, 512, 512) == (0, PP, 512)                   # exactly two tiles per CU
+    assert plan(T, 256, 512) == (0, GLDS, 512 * 2)             # one 256-column tile per row block: 256 tiles < 512 -> 128 x 128 tiles
+    assert plan(8192, 384, 1024) == (0, MID, 64 * 3)           # latent projection: <= one 128 x 128 tile per CU
+    assert plan(2048, 2048, 24576) == (0, MID, 256)            # AdaLN table backward
+    assert plan(640, 3080, 1024) == (0, SKINNY, 10 * 25)       # mixed decode step: 490 tiles of 64 x 64 do not fit one round
+    assert plan(640, 1024, 1024) == (0, DECODE, 10 * 16)       # ... 160 do
+    assert plan(64, 5632, 1024) == (0, DECODE, 88)
+    assert plan(64, 5632, 128)[1] == SKINNY                    # K < 8 x 32: no K split
+    assert plan(T, 1546, 512)[1] == FALLBACK                   # N % 4 != 0
+    assert plan(T, 512, 500)[0] == -1                          # K % 64 != 0 is refused

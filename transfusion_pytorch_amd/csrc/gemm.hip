@@ -1549,55 +1549,80 @@ static bool use_glds() {             // TFX_GEMM_GLDS=0 forces the register-stag
   return v == 1;
 }
 
-template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
-  const int smem = 2 * (BM * BK + BN * BK) * 2;
+// which NT kernel a shape runs on, and its grid (pure host logic: tfx.h tfx_gemm_nt_plan, pinned by the CPU tests):
+//   5 decode    M <= 1024 rows (decode steps: samples x 1 ... x (modality length + 1) rows - 640 at SURVEY 8(d) config 5), K split across the waves,
+//               as long as the 64 x 64 tiles fit the chip in one round (128 KiB of LDS = one block per CU; 344 tiles at M = 256, N = 5504 measured
+//               19.9 us against 13.7 for the 64 x 128 kernel)
+//   4 skinny    few row blocks: latency-bound, deep DMA ring (gemm_nt_skinny_kernel)
+//   3 ping-pong 256 x 256 tiles whenever they still fill the chip (>= 2 tiles per CU); a ragged last N tile costs less than the 128 x 128 kernel
+//               loses (measured on N = 1544 / 1408).  One tile per block: a persistent walk with cross-tile prefetch measured no faster
+//   2 mid       at most one 128 x 128 tile per CU and K >= 256
+//   1 glds      128 x 128 tiles, LDS-DMA, two stages
+//   0 register-staged fallback: N % 4 != 0 (the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups) or TFX_GEMM_GLDS=0
+enum { NT_FALLBACK = 0, NT_GLDS = 1, NT_MID = 2, NT_PP = 3, NT_SKINNY = 4, NT_DECODE = 5 };
+struct NtPlan { int kind, grid; };
+static NtPlan nt_plan(const GemmNT& p) {
   const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
-  const bool dma = use_glds() && (p.N & 3) == 0;      // the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups
+  const bool dma = use_glds() && (p.N & 3) == 0;
   static int dec64 = -1;              // TFX_NT_DECODE=0: the 64 x 128 skinny kernel for every small M (A/B)
   if (dec64 < 0) { const char* e = getenv("TFX_NT_DECODE"); dec64 = e ? atoi(e) : 1; }
-  const int grid_sd = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-  // decode steps (samples x 1 ... x modality length rows): K split across the waves - as long as the 64 x 64 tiles fit the chip in one round
-  // (128 KiB of LDS = one block per CU; 344 tiles at M = 256, N = 5504 measured 19.9 us against 13.7 for the 64 x 128 kernel below)
-  // (M up to 1024: the mixed forwards of the continuous decode schedule run samples x (modality length + 1) rows - 640 at SURVEY 8(d) config 5)
-  if (dma && p.M <= 1024 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) {
-    static bool attr_sd = false;
-    const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
-    if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }
-    hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI>, dim3(grid_sd), dim3(256), smem_sd, s, p);
-    return (int)hipGetLastError();
-  }
-  const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
-  if (dma && (p.M <= 512 || (p.M <= 1024 && grid_sk <= 256))) {   // few row blocks: latency-bound, deep DMA ring (see gemm_nt_skinny_kernel)
-    static bool attr_sk = false;
-    const int smem_sk = SK_ST * SK_STAGE * 2;
-    if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk); attr_sk = true; }
-    hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(grid_sk), dim3(256), smem_sk, s, p);
-    return (int)hipGetLastError();
-  }
-  // 256x256 ping-pong tiles whenever they still fill the chip (>= 2 tiles per CU); a ragged last N tile costs less than the
-  // 128x128 kernel loses (measured on N = 1544 / 1408).  One tile per block: a persistent walk with cross-tile prefetch measured no faster.
-  if (dma && t256 >= 512) {
-    static bool attr_pp = false;
-    const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
-    if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
-    static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
-    if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
-    hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(t256), dim3(512), smem2, s, p, stagger);
-    return (int)hipGetLastError();
-  }
   static int mid = -1;                // TFX_NT_MID=0: the 2-stage kernel also when a CU gets at most one tile (A/B)
   if (mid < 0) { const char* e = getenv("TFX_NT_MID"); mid = e ? atoi(e) : 1; }
-  if (dma && mid && grid <= 256 && p.K >= 4 * BK) {
-    static bool attr_md = false;
-    const int smem_md = MD_ST * MD_STAGE * 2;
-    if (!attr_md) { (void)hipFuncSetAttribute((const void*)gemm_nt_mid_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_md); attr_md = true; }
-    hipLaunchKernelGGL(gemm_nt_mid_kernel<EPI>, dim3(grid), dim3(256), smem_md, s, p);
-    return (int)hipGetLastError();
+  const int grid_sd = ((p.M + 63) / 64) * ((p.N + 63) / 64);
+  const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
+  if (dma && p.M <= 1024 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) return {NT_DECODE, grid_sd};
+  if (dma && (p.M <= 512 || (p.M <= 1024 && grid_sk <= 256))) return {NT_SKINNY, grid_sk};
+  if (dma && t256 >= 512) return {NT_PP, t256};
+  if (dma && mid && grid <= 256 && p.K >= 4 * BK) return {NT_MID, grid};
+  return {dma ? NT_GLDS : NT_FALLBACK, grid};
+}
+
+template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
+  const NtPlan pl = nt_plan(p);
+  const int smem = 2 * (BM * BK + BN * BK) * 2;
+  switch (pl.kind) {
+    case NT_DECODE: {
+      static bool attr_sd = false;
+      const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
+      if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }
+      hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sd, s, p);
+      break;
+    }
+    case NT_SKINNY: {
+      static bool attr_sk = false;
+      const int smem_sk = SK_ST * SK_STAGE * 2;
+      if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk); attr_sk = true; }
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sk, s, p);
+      break;
+    }
+    case NT_PP: {
+      static bool attr_pp = false;
+      const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
+      if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
+      static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
+      if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
+      hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(pl.grid), dim3(512), smem2, s, p, stagger);
+      break;
+    }
+    case NT_MID: {
+      static bool attr_md = false;
+      const int smem_md = MD_ST * MD_STAGE * 2;
+      if (!attr_md) { (void)hipFuncSetAttribute((const void*)gemm_nt_mid_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_md); attr_md = true; }
+      hipLaunchKernelGGL(gemm_nt_mid_kernel<EPI>, dim3(pl.grid), dim3(256), smem_md, s, p);
+      break;
+    }
+    case NT_GLDS: hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(pl.grid), dim3(256), smem, s, p); break;
+    default: hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(pl.grid), dim3(256), smem, s, p); break;
   }
-  if (dma) hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
-  else hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(grid), dim3(256), smem, s, p);
   return (int)hipGetLastError();
+}
+
+int gemm_nt_plan(const GemmNT& p, int* kind, int* grid) {
+  if (p.K % BK != 0 || (p.A2 && p.K1 % BK != 0) || p.M <= 0 || p.N <= 0) return -1;
+  const NtPlan pl = nt_plan(p);
+  if (kind) *kind = pl.kind; if (grid) *grid = pl.grid;
+  return 0;
 }
 
 int gemm_nt(const GemmNT& p, hipStream_t s) {

@@ -12,6 +12,7 @@ enum { EPI_BF16 = TFX_EPI_BF16, EPI_F32 = TFX_EPI_F32, EPI_SILU = TFX_EPI_SILU, 
        EPI_GEGLU = TFX_EPI_GEGLU, EPI_GEGLU_BWD = TFX_EPI_GEGLU_BWD };
 int gemm_nt(const GemmNT& p, hipStream_t s);
 int gemm_tn(const GemmTN& p, hipStream_t s);
+int gemm_nt_plan(const GemmNT& p, int* kind, int* grid);
 int gemm_tn_plan(const GemmTN& p, int* kind, int* tiles, int* splits, int* grid);
 int attn_fwd(const tfx_attn_args& p, hipStream_t s);
 int attn_bwd(const tfx_attn_args& p, hipStream_t s);

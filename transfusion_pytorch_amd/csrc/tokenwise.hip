@@ -2263,6 +2263,7 @@ int tfx_ema_update(float* ema, const float* online, int64_t n, float decay, void
 }
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* s) { return gemm_nt(*a, ST(s)); }
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* s) { return gemm_tn(*a, ST(s)); }
+int tfx_gemm_nt_plan(const tfx_gemm_nt_args* a, int32_t* kind, int32_t* grid) { return gemm_nt_plan(*a, kind, grid); }
 int tfx_gemm_tn_plan(const tfx_gemm_tn_args* a, int32_t* kind, int32_t* tiles, int32_t* splits, int32_t* grid) { return gemm_tn_plan(*a, kind, tiles, splits, grid); }
 int tfx_attn_fwd(const tfx_attn_args* a, void* s) { return attn_fwd(*a, ST(s)); }
 int tfx_attn_bwd(const tfx_attn_args* a, void* s) { return attn_bwd(*a, ST(s)); }
