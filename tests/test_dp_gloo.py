@@ -275,3 +275,58 @@ def test_external_parameter_gradients_with_missing_modalities_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_world1_gates(rank, world, port, q):
+    """ world size 1 with torch.distributed initialised (`torchrun --nproc-per-node 1`) and the DEFAULT `always_sync`: the backward takes
+    the overlapped path (it only asks whether a process group exists), so the optimizer's exchange section must consume what it sent - wait for
+    the handles, reduce the tail, re-arm - or the next step's backward is refused.  Two steps, driven by a real plan's cut list; then the
+    accumulation contract of `no_sync()` and the public-API (non-coalesced) exchange."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from transfusion_pytorch_amd.optim import FusedAdam
+    m, ps, plan = _cpu_plan()
+    opt = FusedAdam(m, lr=1e-3)
+    opt.overlap_grad_sync(groups=3)
+    red = opt.reducer
+    ok = opt.always_sync is False
+    local = torch.randn(ps.numel, generator=torch.Generator().manual_seed(7))
+    for step in range(2):
+        ps.grad.copy_(local)
+        red.check_fresh()                                       # what transfusion._native_backward does before it replays the list
+        red.begin()
+        for _, first, last in plan.bwd_cuts:
+            red.group_ready(first, last)
+        ok &= red.exchanged
+        opt.sync_grads()                                        # the exchange section of step()
+        ok &= (not red.exchanged) and not red.handles and not red.done
+        ok &= bool(torch.equal(ps.grad, local))                 # world 1: the sum is the rank's own gradient
+    # no_sync: the flag the backward reads; nesting restores it
+    with opt.no_sync():
+        ok &= red.defer
+        with opt.no_sync():
+            ok &= red.defer
+        ok &= red.defer
+    ok &= not red.defer
+    # public API only (TFX_DP_COALESCE=0): one collective per range, every element still exactly once
+    os.environ['TFX_DP_COALESCE'] = '0'
+    ps.grad.copy_(local)
+    red.begin()
+    for _, first, last in plan.bwd_cuts:
+        red.group_ready(first, last)
+    red.finish()
+    ok &= red.launches == 2 * 3 + 2 and bool(torch.equal(ps.grad, local))      # 3 groups x 2 ranges + the tail's 2 ranges (coalesced: 3 + 1)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_world1_default_gates_no_sync_and_public_api_exchange():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    p = ctx.Process(target=_worker_world1_gates, args=(0, 1, port, q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(timeout=60)
+    assert res == (0, True)

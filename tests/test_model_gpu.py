@@ -518,6 +518,66 @@ def test_overlapped_gradient_exchange_equals_plain_step_rccl_world1():
             dist.destroy_process_group()
 
 
+def test_overlapped_exchange_world1_default_gates_and_accumulation_rccl():
+    """ `torchrun --nproc-per-node 1`: torch.distributed is initialised at world size 1 and `always_sync` keeps its
+    default - the backward still takes the overlapped path, so `step()` must wait for its handles and re-arm the reducer: two consecutive steps
+    run.  Then gradient accumulation: micro-batches under `opt.no_sync()` only accumulate, the last backward exchanges - the step equals the
+    plain exchange's two-backward step; without `no_sync` the second backward is refused.  Also the public-API fallback (TFX_DP_COALESCE=0)."""
+    import torch.distributed as dist
+    from transfusion_pytorch_amd.optim import FusedAdam
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29542')
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        cfg, sd, batch, times, noise = build_case('small2')
+        def fresh(overlap):
+            model = build_native(cfg, sd).train()
+            model._noise_override = {t: v.cuda() for t, v in noise.items()}
+            opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
+            if overlap:
+                opt.overlap_grad_sync(groups=3)
+            return model, opt
+        # two steps with the default gates (the second one used to raise "second backward() before optimizer.step()")
+        model, opt = fresh(True)
+        for _ in range(2):
+            loss = model(batch, times=times); loss.backward(); opt.step(); opt.zero_grad()
+        torch.cuda.synchronize()
+        assert not opt.reducer.exchanged and not opt.reducer.handles
+        # accumulation of two micro-batches
+        res = []
+        for overlap in (False, True):
+            model, opt = fresh(overlap)
+            with opt.no_sync():
+                model(batch, times=times).backward()
+            loss = model(batch, times=times); loss.backward()
+            if overlap:
+                assert opt.reducer.exchanged and opt.reducer.launches == 2                  # depth 4 in groups of 2 layers: only the LAST backward sent them
+            g = model.store.grad.clone()
+            opt.step(); torch.cuda.synchronize()
+            res.append((g, model.store.flat.clone()))
+        assert rel(res[1][0], res[0][0]) <= 2e-3 and rel(res[1][1], res[0][1]) <= 1e-5
+        model, opt = fresh(True)
+        model(batch, times=times).backward()
+        with pytest.raises(RuntimeError, match='no_sync'):
+            model(batch, times=times).backward()
+        # public-API exchange (no private coalescing manager): two launches per group, same sums
+        os.environ['TFX_DP_COALESCE'] = '0'
+        try:
+            model, opt = fresh(True)
+            loss = model(batch, times=times); loss.backward()
+            assert opt.reducer.launches == 4
+            g = model.store.grad.clone(); opt.step(); torch.cuda.synchronize()
+        finally:
+            del os.environ['TFX_DP_COALESCE']
+        model, opt = fresh(False)
+        loss = model(batch, times=times); loss.backward()
+        assert rel(g, model.store.grad) <= 2e-3
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def test_no_fallback_on_cpu():
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.capi import TfxError

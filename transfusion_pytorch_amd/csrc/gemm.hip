@@ -635,8 +635,8 @@ TFX_DEV TnBlock tn_block(const GemmTN& p, int ntile) {
   const int chunk = ((p.M + p.splits - 1) / p.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
   const int split = g / ntile;
   b.tile = g - split * ntile;
-  b.mbeg = split < p.splits ? split * chunk : p.M;
-  b.mend = min(p.M, b.mbeg + chunk);
+  b.mbeg = split < p.splits ? min(split * chunk, p.M) : p.M;      // chunks are rounded up to 64 rows: trailing splits can start past M (M = 2112, 8 splits: chunk 320)
+  b.mend = min(p.M, b.mbeg + chunk);                              // -> empty range, the kernels return before forming an address
   return b;
 }
 

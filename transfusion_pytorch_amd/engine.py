@@ -214,7 +214,7 @@ class Plan:
                 # final embedding rows go back out to the user's decoder; `gemb` receives d loss / d (those embedding rows) before the backward
                 self.lat[t] = dict(tok=z(r, d), gemb=z(r, d))
                 continue
-            self.lat[t] = dict(x=e(r, dl, dtype=torch.float32), eps=e(r, dl, dtype=torch.float32), xt=z(r, dlp),
+            self.lat[t] = dict(x=e(r, dl, dtype=torch.float32), eps=z(r, dl, dtype=torch.float32), xt=z(r, dlp),
                                flow=e(r, dl, dtype=torch.float32), pred=e(r, dl, dtype=torch.float32), dpred=z(r, dlp))
         for t in self.ext_add:
             self.lat[t]['add'] = z(R[t], d)      # additive token rows: the axial positional embedding (T:1384-1403, T:3173-3176), bf16

@@ -6,6 +6,9 @@ reduction -> one fused clip+Adam kernel.  No host sync: the clip coefficient is 
 """
 from __future__ import annotations
 
+import contextlib
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -64,14 +67,26 @@ class GradReducer:
             h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             if async_op:
                 self.handles.append(h)
-        else:
+        elif self._coalesce():
             with dist._coalescing_manager(group=self.group, async_ops=async_op) as cm:
                 for a, b in ranges:
                     dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group)
             if async_op:
                 self.handles.append(cm)
+        else:
+            # public API only: one all-reduce per range (two collective launches per layer group instead of one).  Selected by TFX_DP_COALESCE=0,
+            # or by itself when this torch build has no `_coalescing_manager` (a private name) - a torch-side change costs an env var, not a run
+            for a, b in ranges:
+                h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                if async_op:
+                    self.handles.append(h)
+            self.launches += len(ranges) - 1
         self.done += ranges
         self.launches += 1
+
+    @staticmethod
+    def _coalesce() -> bool:
+        return os.environ.get('TFX_DP_COALESCE', '1') != '0' and hasattr(dist, '_coalescing_manager')
 
     def _unstage(self, ranges, buf):
         g, off = self.model.store.grad, 0
@@ -86,6 +101,7 @@ class GradReducer:
         self.launches = 0
 
     exchanged = False        # a backward has sent layer groups out and no optimizer step has consumed them yet
+    defer = False            # inside `FusedAdam.no_sync()`: this backward only accumulates (no cut, no collective) - a later one exchanges
 
     def group_ready(self, lo: int, hi: int):
         """called between two segments of the backward list: layers lo..hi are final (and, at the first cut, nothing else is)"""
@@ -96,8 +112,8 @@ class GradReducer:
         """one backward per optimizer step (like DDP without `no_sync`): a second backward would accumulate into ranges that are already summed
         over the ranks (counting the first micro-batch `world` times) and race with the collectives in flight"""
         if self.exchanged:
-            raise RuntimeError('overlap_grad_sync: a second backward() before optimizer.step() - gradient accumulation needs the un-overlapped exchange '
-                               '(FusedAdam without overlap_grad_sync: one all-reduce in step())')
+            raise RuntimeError('overlap_grad_sync: a second backward() before optimizer.step() after the layer groups went out - run the micro-batches '
+                               'that only accumulate under `with opt.no_sync():` (the LAST backward of the step, outside it, exchanges the sums)')
 
     def finish(self):
         """after the backward: exchange whatever no cut covered, then make the current stream wait for every collective"""
@@ -139,6 +155,22 @@ class FusedAdam:
         self.ext_params = list(model.external_parameters()) if hasattr(model, 'external_parameters') else []
         self.ext_opt = torch.optim.Adam(self.ext_params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay) if self.ext_params else None
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """gradient accumulation (reference practice: `accelerator.accumulate(model)`, train_text_only.py:40, 117 = DDP's `no_sync()` around every
+        micro-batch but the last): a backward inside this context only ADDS into the flat gradient buffer - with the overlapped exchange no layer
+        group leaves (the buffer still changes), with the plain exchange nothing differs (its one all-reduce runs in `step()`).  The last
+        micro-batch's backward, outside the context, sends the accumulated groups out as they become final."""
+        red = self.reducer
+        if red is None:
+            yield
+            return
+        prev, red.defer = red.defer, True
+        try:
+            yield
+        finally:
+            red.defer = prev
+
     def overlap_grad_sync(self, groups: int = 4, exchange_dtype=None):
         """exchange the gradients in `groups` layer groups DURING the backward (GradReducer) instead of one all-reduce after it;
         `exchange_dtype=torch.bfloat16` halves the bytes on the links (the sum is formed in bf16; master gradients stay fp32)"""
@@ -155,12 +187,15 @@ class FusedAdam:
     def sync_grads(self):
         """the ONE collective of a data-parallel step: all-reduce(sum) of the flat gradient buffer (RCCL over xGMI)."""
         world = self._world()
-        if world > 1 or (self.always_sync and dist.is_initialized()):
+        pending = self.reducer is not None and bool(self.reducer.done or self.reducer.exchanged)
+        # (`pending`: the backward took the overlapped path - it does whenever torch.distributed is initialised, also at world size 1, e.g.
+        #  `torchrun --nproc-per-node 1` - so its handles must be waited for and the reducer re-armed here whatever the world size)
+        if world > 1 or pending or (self.always_sync and dist.is_initialized()):
             timed = self.time_exchange and self.model.store.grad is not None and self.model.store.grad.is_cuda
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if self.reducer is not None and self.reducer.done:
+            if pending:
                 self.reducer.finish()                  # the groups went out during the backward: tail + wait
                 self.reducer.begin()
             else:

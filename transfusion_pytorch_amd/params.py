@@ -214,7 +214,11 @@ class ParamStore:
                 if name.endswith('bias') and not name.endswith('to_ada_ln_zero.bias'):
                     view._fan_in_bound = 1. / math.sqrt(fan_in[name[:-len('bias')]])
                 init_param_(name, view)
-            for name, shape in self.specs:
+            # registration (hence `named_parameters()` / positional optimizer state) follows the same MODULE order: only the flat-buffer OFFSETS
+            # put the AttentionResidual parameters at the tail - a param-group list or a positional `torch.optim` state_dict built in the
+            # reference's module order keeps meaning the same tensors
+            for name in order:
+                shape = shapes[name]
                 o = self.offsets[name][0]
                 view = self.flat[o:o + int(np.prod(shape))].view(shape)
                 prm = nn.Parameter(view, requires_grad=True)
@@ -228,6 +232,7 @@ class ParamStore:
         self._shadow_version = None
         self._maps = {}
         self._jobs, self._job_table = [], None
+        self._exp_ptrs = None
         self.device = torch.device('cpu')
 
     # ------------------------------------------------------------------ flat <-> views
@@ -273,8 +278,14 @@ class ParamStore:
         re-pointed here.  In-place writes THROUGH `.data` (`p.data.mul_(0.5)`) bump no counter and move no pointer - nothing can see them; callers
         that edit weights that way call `Transfusion.mark_weights_changed()`."""
         ver = self.fourier_w._version
-        for name, prm in self.params.items():
-            if prm.data_ptr() != self.ptr(name):
+        # (this runs on every forward: one data_ptr() and one version read per parameter against a cached list of expected addresses - the
+        #  list is rebuilt when the flat buffer moves - instead of a name lookup + offset arithmetic per parameter)
+        base = self.flat.data_ptr()
+        exp = self._exp_ptrs
+        if exp is None or exp[0] != base:
+            exp = self._exp_ptrs = (base, [(name, prm, base + 4 * self.offsets[name][0]) for name, prm in self.params.items()])
+        for name, prm, want in exp[1]:
+            if prm.data_ptr() != want:
                 v = self.view(name)
                 if prm.shape != v.shape:
                     raise ValueError(f'parameter {name} was re-assigned with shape {tuple(prm.shape)}, the model was built for {tuple(v.shape)}')

@@ -849,7 +849,7 @@ class Transfusion(nn.Module):
                 if self._noise_override is not None:
                     lt['eps'][:R[t]].copy_(self._noise_override[t])
                 else:
-                    lt['eps'].normal_()                                                     # MP:654
+                    lt['eps'][:R[t]].normal_()                                              # MP:654 (the REAL rows only: the RNG stream a seed consumes does not depend on the plan's bucket padding)
             # without a loss there is no noising (MP:658-660): noise_mix with eps = NULL copies x
             plan.set_noise(t, lt['eps'].data_ptr() if return_loss else None)
 
@@ -1476,8 +1476,10 @@ class Transfusion(nn.Module):
         if self.md.model_output_clean and plan.clean_mode == 'model' and len(plan.clean_bwd):
             Plan.run(plan.clean_bwd, stream)                # gradient paths through q = W proj (engine._clean_model_space)
         red = getattr(self, '_grad_reducer', None)
-        if red is None or not plan.bwd_cuts or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            Plan.run(plan.bwd, stream)
+        if red is None or red.defer or not plan.bwd_cuts or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            if red is not None and red.defer:
+                red.check_fresh()                               # (accumulating AFTER a backward that already exchanged would add into summed ranges)
+            Plan.run(plan.bwd, stream)                          # `opt.no_sync()`: accumulate only - the step's last backward exchanges the sums
             return
         # data parallel with overlap: replay the list group by group; a finished group's gradient ranges go out while the rest runs
         red.check_fresh()                                   # one backward per optimizer step (the groups of the previous one are already summed over the ranks)
