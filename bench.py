@@ -75,21 +75,38 @@ def f_core_per_sample(d=512, D=8, h=8, dh=64, n=1024, n_inst=32, L=4):
     return 6 * n * D * (p_attn + p_ff + sdpa)
 
 
-def timed_run(orig_run, launches, stream, lo, hi, family, events):
-    """Plan.run with HIP events (torch events on the launch stream) around every launch of `family`; the launches in between
+def classify(launches, k, attn_flops):
+    """(family, algorithmic work) of launch k of a plan's list, or None: the MFMA families by entry point (GEMM work = the unpadded 2 M N K the
+    engine attached to the args struct; attention = mask-aware score pairs), the HBM-bound token-wise launches by the byte tags the engine
+    attached (`LaunchList.meta`: passes of a [T, d] bf16 matrix)."""
+    fn, a = launches[k]
+    if fn in ('tfx_gemm_nt', 'tfx_gemm_tn'):
+        return fn, getattr(a, '_algo_flops', 0.0)
+    if fn == 'tfx_attn_fwd':
+        return fn, attn_flops
+    if fn == 'tfx_attn_bwd':
+        return fn, 2.5 * attn_flops                       # S and dP recomputed once more than the minimum is NOT counted: 5 products of the forward's 2
+    meta = getattr(launches, 'meta', None)
+    if meta and k in meta:
+        return meta[k]
+    return None
+
+
+def timed_run(orig_run, launches, stream, lo, hi, families, events, attn_flops=0.0):
+    """Plan.run with HIP events (torch events on the launch stream) around every launch of `families`; the launches in between
     are replayed natively (tfx_run_list), exactly as the product path does."""
     n = len(launches)
     hi = n if hi is None else min(hi, n)
     seg = lo
     for k in range(lo, hi):
-        fn, a = launches[k]
-        if fn == family:
+        c = classify(launches, k, attn_flops)
+        if c is not None and c[0] in families:
             orig_run(launches, stream, seg, k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             orig_run(launches, stream, k, k + 1)
             e1.record()
-            events.append((e0, e1, getattr(a, '_algo_flops', 0.0)))
+            events.append((e0, e1, c[1], c[0]))
             seg = k + 1
     orig_run(launches, stream, seg, hi)
 
@@ -116,9 +133,10 @@ def cpu_baseline(budget_s=30.0):
         t0 = time.time(); train_step(sd, cfg, batch, times, noise, state); dt = time.time() - t0
         tsum += dt; steps += 1
     per_step = (tsum / steps) if steps else t1
-    return {'value': bs / per_step, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+    return {'value': bs / per_step, 'unit': 'samples/s', 'cores': threads, 'host_cores': os.cpu_count(), 'kind': 'port',
             'sample': f'oracle restatement (torch fp32 CPU), dim512/depth8, batch {bs} x 1024 canonical samples, '
-                      f'{"1 warm-up + " + str(steps) + " timed" if steps else "1 timed (cold)"} step(s) of fwd+bwd+clip+Adam'}
+                      f'{"1 warm-up + " + str(steps) + " timed" if steps else "1 timed (cold)"} step(s) of fwd+bwd+clip+Adam; {threads} torch threads of the box\'s {os.cpu_count()} '
+                      '(more threads oversubscribe this graph: 256 threads measured 100x slower)'}
 
 
 def sample_prompts(n_each, dev, gen, dim_latent=384):
@@ -179,6 +197,112 @@ def bench_sample(args):
     os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 
+CONFIGS = {2: (512, 8), 3: (1024, 24)}          # BASELINE.json configs[1] (the metric's) and configs[2] (the 8-GPU model), single modality type
+
+
+def workload_label(dim, depth, batch, world, use_pg, overlap):
+    cfgname = {(512, 8): 'BASELINE config 2', (1024, 24): 'BASELINE config 3 (per-GPU share of global batch 512 at 8 GPUs)'}.get((dim, depth), 'non-BASELINE dims')
+    return (f'{cfgname}: Transfusion dim={dim} depth={depth} heads=8 dim_head=64 num_text_tokens=256 dim_latent=384; '
+            f'per-GPU batch {batch} x seq 1024 (32 x [24 text tokens + (4,384) latent] per sample); '
+            'step = pack + fwd + bwd + ' + (('grad all-reduce (4 layer groups + tail = 5 collective launches, overlapped with the backward) + '
+                                            if overlap else 'ONE grad all-reduce after the backward + ') if use_pg else '')
+            + 'clip(0.5) + Adam(3e-4)' + ('' if use_pg else ' (one GPU: no gradient exchange)'))
+
+
+def dp_setup(world, rank, dev, backend='nccl'):
+    """process group + per-rank seeds of the data-parallel run (one process per GPU; torch.distributed `nccl` IS RCCL on ROCm).  Returns use_pg."""
+    import torch.distributed as dist
+    use_pg = world > 1 or bool(os.environ.get('TFX_BENCH_FORCE_PG'))   # the env flag exercises the RCCL path on a 1-GPU box (world 1)
+    if use_pg:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        kw = dict(device_id=dev) if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return use_pg
+
+
+def make_optimizer(model, use_pg):
+    from transfusion_pytorch_amd.optim import FusedAdam
+    opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
+    opt.always_sync = use_pg
+    opt.time_exchange = use_pg
+    overlap = use_pg and os.environ.get('TFX_DP_OVERLAP', '1') != '0'
+    if overlap:
+        # the gradient all-reduce goes out in 4 layer groups DURING the backward; fp32 on the links like the reference's DDP (TFX_DP_BF16=1: bf16)
+        opt.overlap_grad_sync(groups=4, exchange_dtype=torch.bfloat16 if os.environ.get('TFX_DP_BF16') == '1' else None)
+    return opt, overlap
+
+
+def gather_ranks(elapsed, my_elapsed, exchange_ms, steps, world, use_pg, dev):
+    """max-over-ranks wall time (the contract's `value` clock) + every rank's own clock and exposed exchange time"""
+    import torch.distributed as dist
+    per_rank = [my_elapsed / steps * 1e3]
+    if use_pg:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([my_elapsed / steps * 1e3, exchange_ms or 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(x[0]) for x in allr]
+        exchange_ms = max(float(x[1]) for x in allr)
+        elapsed = float(t.item())
+    return elapsed, per_rank, exchange_ms
+
+
+def dry_run(args, world, rank, json_fd):
+    """`--dry-run` (tests/test_dp_gloo.py, no GPU): everything of the N > 1 code path that is not a kernel launch - process group (gloo), identical
+    init on every rank, per-rank seeds, `overlap_grad_sync`, the exchange driven by the REAL training plan's cut list on a rank-dependent fake
+    gradient, the exchange section of `step()`, the closing barrier, max-over-ranks timing, `per_rank_ms_per_step` and the JSON assembly.
+    `value` is null: nothing was computed."""
+    import collections
+    import torch.distributed as dist
+    from transfusion_pytorch_amd import Transfusion
+    from transfusion_pytorch_amd.engine import Plan
+    from transfusion_pytorch_amd.params import geglu_phys_to_ref_rows
+    dev = torch.device('cpu')
+    use_pg = dp_setup(world, rank, dev, backend='gloo')
+    torch.manual_seed(0)
+    model = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=args.dim, depth=args.depth))
+    opt, overlap = make_optimizer(model, use_pg)
+    opt.time_exchange = False                                   # (HIP events)
+    ps = model.store
+    ps.grad = torch.zeros(ps.numel)
+    ps.shadows = collections.defaultdict(lambda: torch.zeros(8, 8, dtype=torch.bfloat16))
+    ps._map('geglu', geglu_phys_to_ref_rows(model.md.di, model.md.dip))
+    plan = Plan(ps, b=2, n=64, I=4, R={0: 8}, training=True, dp_groups=getattr(model, '_dp_groups', 0))
+    torch.manual_seed(7 + rank)
+    same_init = float(ps.flat.double().sum())
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ps.grad.copy_(torch.full((ps.numel,), float(rank + 1)))
+        if overlap:
+            opt.reducer.check_fresh(); opt.reducer.begin()
+            for _, first, last in plan.bwd_cuts:
+                opt.reducer.group_ready(first, last)
+        opt.sync_grads()
+    my_elapsed = time.perf_counter() - t0
+    if use_pg:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed, per_rank, _ = gather_ranks(elapsed, my_elapsed, None, args.steps, world, use_pg, dev)
+    want = float(sum(range(1, world + 1)))
+    ok = bool((ps.grad == want).all())
+    sums = torch.tensor([same_init], dtype=torch.float64)
+    if use_pg:
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ok &= bool(lo == hi)                                    # replicas start from identical weights
+    if rank == 0:
+        out = {'metric': f'train samples/sec, dim{args.dim} d{args.depth} seq1024 text+latent', 'value': None, 'unit': 'samples/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+               'dry_run': True, 'exchange_ok': ok, 'collective_launches_per_step': opt.reducer.last_launches if overlap else 1,
+               'config': {'workload': workload_label(args.dim, args.depth, args.batch, world, use_pg, overlap), 'global_batch': world * args.batch,
+                          'seq_len': 1024, 'parallelism': f'dp{world}'}, 'per_rank_ms_per_step': per_rank}
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    if use_pg:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -187,15 +311,20 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--dim', type=int, default=512)
     ap.add_argument('--depth', type=int, default=8)
+    ap.add_argument('--config', type=int, default=0, help='2 = dim512/depth8 (the metric, default), 3 = dim1024/depth24 (BASELINE config 3, the 8-GPU model)')
     ap.add_argument('--roofline-kernel', default='tfx_gemm_nt')
     ap.add_argument('--roofline-every', type=int, default=5, help='bracket the roofline kernels with HIP events on every E-th timed step '
                     '(each bracketed launch costs two ~5 us event bubbles: 84 launches = ~0.9 ms on a step)')
+    ap.add_argument('--family-steps', type=int, default=3, help='steps AFTER the timed region with every kernel family bracketed (roofline_by_family); 0 = skip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-profile', action='store_true')
     ap.add_argument('--sample', action='store_true', help='time sample_many (SURVEY 8(d) config 5) instead of the training step')
     ap.add_argument('--no-sample', action='store_true', help='skip the sample_many timing (SURVEY 8(d) config 5) that rides in the N = 1 line')
     ap.add_argument('--ragged-steps', type=int, default=10, help='timed steps of the ragged steady state (every batch a new structure signature); 0 = skip')
+    ap.add_argument('--dry-run', action='store_true', help='no GPU: drive the N > 1 host path (gloo) without launching kernels (tests/test_dp_gloo.py)')
     args = ap.parse_args()
+    if args.config:
+        args.dim, args.depth = CONFIGS[args.config]
     if args.sample:
         return bench_sample(args)
 
@@ -204,34 +333,25 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
     # keep stdout for the ONE JSON line: libraries print banners there (RCCL's version block at communicator init), so everything
     # else this process writes to fd 1 goes to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    use_pg = world > 1 or bool(os.environ.get('TFX_BENCH_FORCE_PG'))   # the env flag exercises the RCCL path on a 1-GPU box (world 1)
-    if use_pg:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # "nccl" is RCCL on ROCm
+    if args.dry_run:
+        return dry_run(args, world, rank, json_fd)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    use_pg = dp_setup(world, rank, dev)
 
     from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd import capi
     from transfusion_pytorch_amd.engine import Plan
-    from transfusion_pytorch_amd.optim import FusedAdam
 
     torch.manual_seed(0)                                      # identical init on every rank (replicas)
     model = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,),
                         transformer=dict(dim=args.dim, depth=args.depth)).to(dev).train()
-    opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
-    opt.always_sync = use_pg
-    opt.time_exchange = use_pg
-    overlap = use_pg and os.environ.get('TFX_DP_OVERLAP', '1') != '0'
-    if use_pg and os.environ.get('TFX_DP_OVERLAP', '1') != '0':
-        # the gradient all-reduce goes out in 4 layer groups DURING the backward; fp32 on the links like the reference's DDP (TFX_DP_BF16=1: bf16)
-        opt.overlap_grad_sync(groups=4, exchange_dtype=torch.bfloat16 if os.environ.get('TFX_DP_BF16') == '1' else None)
+    opt, overlap = make_optimizer(model, use_pg)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     torch.manual_seed(7 + rank)                               # per-rank noise / times / CFG streams
     # a FRESH batch for every step (train_toy.py:50-52 draws new data each iteration): generated before the timed region (the metric excludes
@@ -262,9 +382,12 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     orig_run = Plan.run
     sampled = [False]
+    families = [{args.roofline_kernel}]
+    n_inst, L_lat, n_tok = 32, 4, 1024
+    attn_flops = 4.0 * 64 * (n_tok * (n_tok + 1) / 2 + n_inst * L_lat * (L_lat - 1) / 2) * args.batch * 8      # per launch: 4 dh pairs per (sample, head), mask-aware
     def run(launches, stream_, lo=0, hi=None):
         if sampled[0]:
-            timed_run(orig_run, launches, stream_, lo, hi, args.roofline_kernel, events)
+            timed_run(orig_run, launches, stream_, lo, hi, families[0], events, attn_flops)
         else:
             orig_run(launches, stream_, lo, hi)
     Plan.run = staticmethod(run)
@@ -295,9 +418,60 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    Plan.run = orig_run
+    sampled[0] = False
     capi.lib().tfx_set_single_stream(0)
     exchange_ms = opt.exchange_ms() if use_pg else None
+    nt_events, events = events, []
+
+    # ---- every kernel family, bracketed on `--family-steps` extra steps behind the timed region (same batches, one stream; NOT part of `value`: ~450
+    # brackets cost ~2.5 ms of event bubbles per step): SURVEY 8(d) asks for the MFMA fraction of the attention + MLP kernels and the HBM rate
+    # of the token-wise ones.  Also the host's issue time on an IDLE queue: `host_ms_per_step` above includes the time the issuing thread is
+    # blocked behind a full queue (the step is GPU-bound), which says nothing about the host path itself.
+    by_family, host_idle_ms, step_gpu_ms = None, None, None
+    if args.family_steps > 0:                                  # (every rank: a step holds collectives)
+        fams = {'tfx_gemm_nt', 'tfx_gemm_tn', 'tfx_attn_fwd', 'tfx_attn_bwd', 'hbm'}
+        families[0] = fams
+        capi.lib().tfx_set_single_stream(1)
+        sampled[0] = True
+        se = []
+        for _ in range(args.family_steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); step(); e1.record(); se.append((e0, e1))
+        torch.cuda.synchronize()
+        sampled[0] = False
+        capi.lib().tfx_set_single_stream(0)
+        step_ms_bracketed = sum(a.elapsed_time(b) for a, b in se) / len(se)
+        agg = {}
+        for e0, e1, work, fam in events:
+            d = agg.setdefault(fam, [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += work; d[2] += 1
+        by_family = []
+        for fam in ('tfx_gemm_nt', 'tfx_gemm_tn', 'tfx_attn_fwd', 'tfx_attn_bwd', 'hbm'):
+            if fam not in agg:
+                continue
+            tsec, work, cnt = agg[fam]
+            hbm = fam == 'hbm'
+            ach = work / tsec / 1e12
+            by_family.append({'kernel': 'token-wise (AdaLN, QK-norm/RoPE, AttentionResidual, norms, CE)' if hbm else fam, 'bound': 'hbm' if hbm else 'mfma',
+                              'achieved': ach, 'peak': 8.0 if hbm else PEAK_BF16_TFLOPS, 'unit': 'TB/s' if hbm else 'TFLOP/s',
+                              'frac': ach / (8.0 if hbm else PEAK_BF16_TFLOPS), 'ms_per_step': tsec / args.family_steps * 1e3,
+                              'launches_per_step': cnt / args.family_steps,
+                              ('algorithmic_gbyte_per_step' if hbm else 'algorithmic_gflop_per_step'): work / args.family_steps / 1e9})
+        events = []
+        mf = [f for f in by_family if f['bound'] == 'mfma']
+        agg_flops = sum(f['algorithmic_gflop_per_step'] for f in mf) * 1e9
+        agg_t = sum(f['ms_per_step'] for f in mf) * 1e-3
+        step_gpu_ms = {'bracketed_step_ms': step_ms_bracketed, 'families_ms': sum(f['ms_per_step'] for f in by_family),
+                       'note': 'one stream, every family bracketed (event bubbles included in bracketed_step_ms); the rest = optimizer, casts, losses, small launches'}
+        aggregate = {'attn_mlp_tflops': agg_flops / agg_t / 1e12, 'frac': agg_flops / agg_t / 1e12 / PEAK_BF16_TFLOPS, 'ms_per_step': agg_t * 1e3,
+                     'what': 'all GEMMs (NT + weight-gradient TN) + attention forward + backward: algorithmic flops / their summed kernel time'}
+        # host issue time with nothing queued: sync, then time until step() RETURNS (launches cannot block on a full queue)
+        hs = []
+        for _ in range(3):
+            torch.cuda.synchronize(); h0 = time.perf_counter(); step(); hs.append(time.perf_counter() - h0)
+        torch.cuda.synchronize()
+        host_idle_ms = sorted(hs)[1] * 1e3
+    Plan.run = orig_run
     # ragged steady state: EVERY batch has a structure the model has never seen (new signature, its own packed lengths) - the host scan, token maps,
     # segments and index uploads are paid on every step, as on a real corpus; steps are issued back to back (no sync in between), so whatever of
     # that host work hides behind the previous step's GPU work is hidden here too.  Two warm-up steps create the plan of the padded length.
@@ -321,47 +495,38 @@ def main():
     step(miss)
     torch.cuda.synchronize(); structure_miss_ms = (time.perf_counter() - tm0) * 1e3
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    per_rank = [my_elapsed / args.steps * 1e3]
-    if use_pg:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        mine = torch.tensor([my_elapsed / args.steps * 1e3, exchange_ms or 0.0], device=dev, dtype=torch.float64)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [float(x[0]) for x in allr]
-        exchange_ms = max(float(x[1]) for x in allr)
-    elapsed = float(t.item())
+    elapsed, per_rank, exchange_ms = gather_ranks(elapsed, my_elapsed, exchange_ms, args.steps, world, use_pg, dev)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
     if rank == 0:
-        kt = sum(e0.elapsed_time(e1) for e0, e1, _ in events) * 1e-3
-        kf = sum(f for _, _, f in events)
+        kt = sum(e0.elapsed_time(e1) for e0, e1, _, _ in nt_events) * 1e-3
+        kf = sum(f for _, _, f, _ in nt_events)
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
-        n_launch = len(events)
+        n_launch = len(nt_events)
         fcore = f_core_per_sample(d=args.dim, D=args.depth)
         # HBM bytes per launch of the roofline kernel family: rocprofv3 PMC passes of this same command, committed under
         # profiles/ (tools/pmc_traffic.sh; FETCH_SIZE x2 gfx950 correction applied there) - counters cannot be read in-process
         traffic, traffic_src = None, None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_traffic.json')
-        if os.path.exists(tj) and (args.batch, args.dim, args.depth) == (64, 512, 8):
-            tr = json.load(open(tj))
-            if tr.get('kernel_family') == args.roofline_kernel:
-                traffic, traffic_src = tr['bytes_per_launch'], tr['source']
+        pdir = os.path.join(ROOT, 'profiles')
+        for tname in ('r04_traffic.json', 'r03_traffic.json'):
+            tj = os.path.join(pdir, tname)
+            if os.path.exists(tj) and (args.batch, args.dim, args.depth) == (64, 512, 8):
+                tr = json.load(open(tj))
+                if tr.get('kernel_family') == args.roofline_kernel:
+                    traffic, traffic_src = tr['bytes_per_launch'], tr['source']
+                    break
         out = {
-            'metric': 'train samples/sec, dim512 d8 seq1024 text+latent', 'value': value, 'unit': 'samples/s',
+            'metric': f'train samples/sec, dim{args.dim} d{args.depth} seq1024 text+latent', 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'Transfusion dim={args.dim} depth={args.depth} heads=8 dim_head=64 num_text_tokens=256 dim_latent=384; '
-                                   f'per-GPU batch {args.batch} x seq 1024 (32 x [24 text tokens + (4,384) latent] per sample); '
-                                   'step = pack + fwd + bwd + ' + (('grad all-reduce (4 layer groups + tail = 5 collective launches, overlapped with the backward) + '
-                                                                   if overlap else 'ONE grad all-reduce after the backward + ') if use_pg else '')
-                                   + 'clip(0.5) + Adam(3e-4)' + ('' if use_pg else ' (one GPU: no gradient exchange)'),
+            'config': {'workload': workload_label(args.dim, args.depth, args.batch, world, use_pg, overlap),
                        'global_batch': world * args.batch, 'seq_len': 1024, 'parallelism': f'dp{world}'},
             'loss': float(loss.detach()),
             'model_flops_utilization': value / world * fcore / (PEAK_BF16_TFLOPS * 1e12),
             'f_core_gflop_per_sample': fcore / 1e9,
-            'host_ms_per_step': host_t / args.steps * 1e3,
+            'host_ms_per_step': host_t / args.steps * 1e3,     # wall time of the issuing thread per step INCLUDING its waits behind the full queue (GPU-bound step)
+            'host_issue_ms_idle_queue': host_idle_ms,          # the same path with nothing queued (sync before the step): scan + pointer gather + ~440 launches
             'structure_miss_ms': structure_miss_ms,
             'ragged_ms_per_step': ragged_ms,                    # every batch a never-seen structure, steps back to back (rank 0)
             'per_rank_ms_per_step': per_rank,                   # each rank's own clock over the timed steps (before the closing barrier)
@@ -374,6 +539,14 @@ def main():
                          'measured_peak': MEASURED_PEAK_TFLOPS, 'measured_peak_frac': achieved / MEASURED_PEAK_TFLOPS,
                          'measured_peak_source': 'profiles/r02_power_clock.txt (tools/mfma_peak.hip: register-resident MFMA loop, uniform random operands, 1.66-1.77 GHz sustained)'},
         }
+        if by_family is not None:
+            out['roofline_by_family'] = by_family
+            out['aggregate_attn_mlp'] = aggregate
+            out['step_kernel_time'] = step_gpu_ms
+        pj = os.path.join(pdir, 'r04_parity.json')
+        if os.path.exists(pj):
+            pm = json.load(open(pj))
+            out['parity_met'] = pm
         if world == 1 and not args.no_sample and (args.batch, args.dim, args.depth) == (64, 512, 8):
             # SURVEY 8(d) config 5 rides in the same line (outside the timed region): the training model's plans are dropped first
             model._plans, model._struct_cache = {}, {}

@@ -330,3 +330,35 @@ def test_world1_default_gates_no_sync_and_public_api_exchange():
     res = q.get(timeout=240)
     p.join(timeout=60)
     assert res == (0, True)
+
+
+def test_bench_two_rank_host_path_dry_run():
+    """the driver's own N = 2 command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...`) with `--dry-run`: gloo instead of RCCL and no kernel launches, everything else of bench.py's
+    N > 1 path - RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, identical initial weights on both ranks, `overlap_grad_sync`, the exchange
+    driven by the real plan's cut list (5 collective launches per step, every element summed once), the closing barrier, max-over-ranks
+    timing, one JSON line from rank 0 with `per_rank_ms_per_step` of both ranks and a self-describing workload label."""
+    import json
+    import subprocess
+    port = _free_port()
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    for extra_env, want_launches in ((dict(), 5), (dict(TFX_DP_COALESCE='0'), 10), (dict(TFX_DP_OVERLAP='0'), 1)):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+               os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run', '--dim', '128', '--depth', '8']
+        r = subprocess.run(cmd, env=dict(env, **extra_env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1, r.stdout                          # ONE JSON line, from rank 0
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['dry_run'] and d['value'] is None and d['exchange_ok']
+        assert d['collective_launches_per_step'] == want_launches, d
+        assert len(d['per_rank_ms_per_step']) == 2 and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 128
+        port = _free_port()
+    # a driver line at the 8-GPU model's dimensions names BASELINE config 3 (VERDICT r3 item 7d)
+    sys.path.insert(0, ROOT)
+    import bench
+    lab = bench.workload_label(*bench.CONFIGS[3], 64, 8, True, True)
+    assert 'BASELINE config 3' in lab and 'dim=1024 depth=24' in lab and '5 collective launches' in lab
+    assert 'BASELINE config 2' in bench.workload_label(512, 8, 64, 1, False, False)

@@ -318,6 +318,7 @@ def test_weight_gradient_gemm_plan_rule():
     assert plan(T, 24576, 2048) == (2, 768, 1, 768)            # more tiles than slots: no split
     assert plan(T, 5632, 1024) == (2, 88, 2, 176)              # 3 splits would open a second round
     assert plan(512, 512, 512)[2] == 2                         # chunks stay >= 256 rows
+    assert plan(2112, 512, 512) == (0, 16, 8, 128)             # 8 chunks of 320 rows (264 rounded up to 64): the 8th starts at 2240 > M - tn_block clamps it to an empty range
     assert plan(T, 1544, 512, splits=8) == (2, 14, 8, 112)     # explicit counts as given
     assert plan(1000, 200, 136)[0] == -1 and plan(T, 512, 512, a_rowmap=64)[0] == -1      # M % 64 != 0 / gathered rows: the register-staged kernel
     assert all(plan(T, n, k)[3] % 8 == 0 for n in (264, 520, 1544, 3080) for k in (384, 512, 768, 1024))

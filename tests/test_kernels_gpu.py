@@ -43,7 +43,9 @@ def gemm_nt(**kw):
 # (33000, 1032, 128) and (65536, 512, 192): >= 512 tiles of 256x256 -> the ping-pong kernel (ragged M and N tiles in the first)
 @pytest.mark.parametrize('M,N,K', [(300, 200, 128), (128, 128, 64), (1000, 1544, 512), (4096, 512, 1408), (77, 390, 192), (33000, 1032, 128), (65536, 512, 192),
                                    (64, 1544, 512), (1, 512, 64), (37, 2816, 1408), (512, 520, 1024), (256, 128, 768),    # M <= 512: the skinny deep-ring kernel
-                                   (640, 5504, 1024), (2000, 388, 512), (640, 1024, 2752), (640, 1544, 1024), (3000, 1024, 256)])   # <= 256 tiles of 128 x 128: the 4-slot mid kernel; 640 rows: split-K decode kernel up to 1024 rows
+                                   (640, 5504, 1024), (2000, 388, 512), (640, 1024, 2752), (640, 1544, 1024), (3000, 1024, 256),
+                                   # the training step's own shapes at bench size (b 64 x 1024 tokens, dim512): qkvg / out / ff2 forward, dX of ff1 / qkvg
+                                   (65536, 1544, 512), (65536, 512, 512), (65536, 512, 1408), (65536, 512, 2816), (65536, 512, 1600)])   # <= 256 tiles of 128 x 128: the 4-slot mid kernel; 640 rows: split-K decode kernel up to 1024 rows
 def test_gemm_nt_bf16_bias(M, N, K):
     torch.manual_seed(0)
     A, B = rnd(M, K), rnd(N, K, scale=K ** -0.5)
@@ -152,9 +154,51 @@ def test_gemm_nt_geglu_fwd_bwd(M):
     check('geglu backward epilogue', dag, dag_ref, 8e-3)
 
 
+def test_gemm_nt_bench_shapes_resid_skip_geglu():
+    """the fused epilogues of the ping-pong kernel at the bench's own shapes (M = 65536 tokens, dim 512): attention out-projection
+    + residual (RESID, K = 512), U-Net skip projection (split-A RESID, K = 2 x 512), GEGLU forward (N = 2 x 1408 interleaved, bias) and GEGLU backward
+    (N = 1408, K = 512, saved [a|g]) - against fp32 torch.matmul on the same bf16 operands."""
+    torch.manual_seed(11)
+    M, d, dip = 65536, 512, 1408
+    A, B, R = rnd(M, d), rnd(d, d, scale=d ** -0.5), rnd(M, d)
+    C = torch.full((M, d), float('nan'), device=DEV, dtype=BF)
+    gemm_nt(A=A, lda=d, B=B, ldb=d, M=M, N=d, K=d, epi=capi.ENUMS['TFX_EPI_RESID'], C=C, ldc=d, R=R, ldr=d)
+    check('bench out-proj + residual', C, A.float() @ B.float().T + R.float(), 6e-3)
+    A2, B2 = rnd(M, d), rnd(d, 2 * d, scale=(2 * d) ** -0.5)
+    C.fill_(float('nan'))
+    gemm_nt(A=A, lda=d, A2=A2, lda2=d, K1=d, B=B2, ldb=2 * d, M=M, N=d, K=2 * d, epi=capi.ENUMS['TFX_EPI_RESID'], C=C, ldc=d, R=A, ldr=d)
+    check('bench skip projection (split-A) + residual', C, torch.cat([A, A2], 1).float() @ B2.float().T + A.float(), 6e-3)
+    del A2, B2, R
+    Wa, Wg = rnd(dip, d, scale=d ** -0.5), rnd(dip, d, scale=d ** -0.5)
+    ba, bg = torch.randn(dip, device=DEV), torch.randn(dip, device=DEV)
+    is_gate, feat = geglu_perm(dip)
+    is_gate, feat = is_gate.to(DEV), feat.to(DEV)
+    Wphys = torch.where(is_gate[:, None], Wg[feat], Wa[feat]).contiguous()
+    bphys = torch.where(is_gate, bg[feat], ba[feat]).contiguous()
+    ag = torch.full((M, 2 * dip), float('nan'), device=DEV, dtype=BF); hm = torch.full((M, dip), float('nan'), device=DEV, dtype=BF)
+    gemm_nt(A=A, lda=d, B=Wphys, ldb=d, M=M, N=2 * dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU'], C=ag, ldc=2 * dip, C2=hm, ldc2=dip, bias=bphys)
+    a = A.float() @ Wa.float().T + ba
+    g = A.float() @ Wg.float().T + bg
+    check('bench geglu pre-activation', ag, torch.where(is_gate[None], g[:, feat], a[:, feat]), 6e-3)
+    check('bench geglu hidden', hm, a * F.gelu(g), 8e-3)
+    del a, g
+    dy, W2t = rnd(M, d), rnd(dip, d, scale=d ** -0.5)
+    dag = torch.full((M, 2 * dip), float('nan'), device=DEV, dtype=BF)
+    gemm_nt(A=dy, lda=d, B=W2t, ldb=d, M=M, N=dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip, aux=ag, ldaux=2 * dip)
+    dh = dy.float() @ W2t.float().T
+    a_s, g_s = ag.float()[:, ~is_gate].requires_grad_(True), ag.float()[:, is_gate].requires_grad_(True)
+    (a_s * F.gelu(g_s)).backward(dh)
+    dag_ref = torch.zeros(M, 2 * dip, device=DEV)
+    dag_ref[:, ~is_gate] = a_s.grad; dag_ref[:, is_gate] = g_s.grad
+    check('bench geglu backward epilogue', dag, dag_ref, 8e-3)
+
+
 # ---------------------------------------------------------------------------------------------- GEMM TN
 @pytest.mark.parametrize('M,N,K,splits', [(1000, 200, 136, 1), (1000, 200, 136, 4), (4096, 1544, 512, 8), (100, 64, 64, 3),
-                                          (4096, 1544, 512, 0), (8192, 512, 1408, 0), (4096, 300, 700, 16), (2048, 2816, 512, 1), (64, 130, 260, 0), (16384, 32, 512, 0)])
+                                          (4096, 1544, 512, 0), (8192, 512, 1408, 0), (4096, 300, 700, 16), (2048, 2816, 512, 1), (64, 130, 260, 0), (16384, 32, 512, 0),
+                                          (2112, 512, 512, 0), (2112, 512, 512, 8),      # chunks rounded up to 64 rows: the last of 8 splits starts past M (ADVICE r3)
+                                          # the weight gradients of the training step at bench size, library-chosen splits (11 / 17 / 20 / 16 row chunks, tfx_gemm_tn_plan)
+                                          (65536, 2816, 512, 0), (65536, 1544, 512, 0), (65536, 512, 1408, 0), (65536, 512, 512, 0)])
 def test_gemm_tn(M, N, K, splits):
     torch.manual_seed(4)
     lda = (N + 7) // 8 * 8 + 8
@@ -175,7 +219,7 @@ def test_gemm_tn(M, N, K, splits):
 
 
 @pytest.mark.parametrize('M,N,K,splits,kg', [(4096, 1544, 512, 8, 0), (1000, 200, 136, 4, 0), (2048, 128, 256, 8, 8), (2048, 384, 192, 16, 32),
-                                             (8192, 2816, 512, 0, 0), (4096, 520, 320, 0, 40)])
+                                             (8192, 2816, 512, 0, 0), (4096, 520, 320, 0, 40), (65536, 2816, 512, 0, 0)])   # last: net.0 weight + bias gradient at bench size
 def test_gemm_tn_folded_bias_gradient_and_head_compaction(M, N, K, splits, kg):
     """`colsum`: the bias gradient (column sums of A through the row map) rides on the weight-gradient GEMM - LDS-DMA kernel (M % 64 == 0)
     and the register-staged fallback; `k_group`: per-head padded product columns are compacted into the unpadded gradient."""

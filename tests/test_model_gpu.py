@@ -2,7 +2,7 @@
 the UNMODIFIED reference produced (tests/golden/*.pt, fp32 CPU) and - for the small cases - the live oracle.
 
 Tolerances (bf16 vs fp32; the reference's own bf16-autocast floor is rel-Frobenius 4.9e-3 on logits):
-  loss / text loss / flow losses : |delta| <= 2e-3 * max(1, |ref|)          (measured 7e-6 ... 4e-5: the north star's 1e-3 is met on the losses)
+  loss / text loss / flow losses : |delta| <= 1e-3 * max(1, |ref|) = LOSS_TOL (measured 7e-6 ... 5e-4: the north star's 1e-3 is the gate)
   logits, final embed            : rel-Frobenius <= 1e-2 = LOGIT_TOL           (measured 5.9e-3 at dim512/depth8: bf16 activations cannot reach 1e-3 here -
                                    the reference's own bf16-autocast run is at 4.9e-3)
   greedy token (argmax)          : identical wherever the reference's top-2 margin exceeds 0.05; >= 97.5% overall
@@ -27,6 +27,7 @@ from oracle.transfusion_oracle import forward_train     # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 LOGIT_TOL, GRAD_TOL, GRAD_MEAN_TOL, GRAD_HEAD_TOL = 1e-2, 4e-2, 1.2e-2, 8e-2
+LOSS_TOL = 1e-3          # the north star's tolerance, met on every loss (round 3 held them to 2e-3; worst measured 9.8e-4: the text loss of the CFG-dropped batch)
 
 
 def build_native(cfg, sd):
@@ -59,11 +60,26 @@ def run_native(name):
     return cfg, model, dict(loss=float(loss), text=float(bd.text), flow=[float(f) for f in bd.flow], logits=logits, embed=embed, grads=grads)
 
 
-def compare_losses(out, g):
+PARITY_LOG = {}          # measured parity figures of this run -> gpurun_out/parity_measured.json (copied to profiles/ and quoted by bench.py `parity_met`)
+
+
+def _log_parity(name, **kw):
+    import json
+    PARITY_LOG.setdefault(name, {}).update({k: float(v) for k, v in kw.items()})
+    out = os.path.join(os.path.dirname(GOLDEN), '..', 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_measured.json'), 'w') as f:
+            json.dump(PARITY_LOG, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def compare_losses(out, g, tol=LOSS_TOL):
     for nm, a, r in [('loss', out['loss'], float(g['loss'])), ('text', out['text'], float(g['text_loss']))] + \
                     [(f'flow{i}', a, float(r)) for i, (a, r) in enumerate(zip(out['flow'], g['flow_losses']))]:
         print(f'  {nm}: native {a:.6f} reference {r:.6f} delta {a - r:+.2e}')
-        assert abs(a - r) <= 2e-3 * max(1., abs(r)), nm
+        assert abs(a - r) <= tol * max(1., abs(r)), nm
 
 
 @pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'head8', 'canon512', 'cfg4_768', 'cfg3_1024'])
@@ -84,6 +100,7 @@ def test_training_step_matches_reference_golden(name):
     safe = margin > 0.05
     agree_safe = (am_n == am_r)[safe].float().mean().item()
     print(f'  logits rel-fro {e_log:.3e}  embed rel-fro {e_emb:.3e}  argmax agreement {agree:.4f} (margin>0.05: {agree_safe:.4f}, {safe.float().mean():.3f} of positions)')
+    _log_parity(name, loss_rel=abs(out['loss'] - float(g['loss'])) / max(1., abs(float(g['loss']))), logits_rel=e_log, embed_rel=e_emb, argmax_unfiltered=agree, argmax_margin_gt_0p05=agree_safe)
     assert e_log <= LOGIT_TOL and e_emb <= LOGIT_TOL
     assert agree_safe == 1.0 and agree >= 0.975
     worst, num, den = (None, 0.), 0., 0.
@@ -105,6 +122,42 @@ def test_training_step_matches_reference_golden(name):
             worst = (k, e)
         assert e <= tol, f'gradient {k}: rel err {e:.3e}'
     print(f'  gradients: norm-weighted mean rel err {num / den:.3e}; worst {worst[0]} {worst[1]:.3e}')
+    _log_parity(name, grad_mean_rel=num / den, grad_worst_rel=worst[1])
+    assert num / den <= GRAD_MEAN_TOL
+
+
+def test_canon512_at_bench_batch_matches_golden_rows():
+    """the bench's own geometry - b = 64 samples x 1024 tokens at dim512 / depth 8, i.e. the GEMM tilings, TN split counts
+    and segment grids the timed step runs on - against the REFERENCE golden of `canon512` (b = 2).  The batch is the golden's two samples 32 times
+    over (same times, same noise): samples only see themselves, the losses are token means, so loss, every sample's logits and every gradient
+    must equal the golden's."""
+    g = torch.load(os.path.join(GOLDEN, 'canon512.pt'), weights_only=False)
+    cfg, sd, batch, times, noise = build_case('canon512')
+    rep = 32
+    model = build_native(cfg, sd).train()
+    model._noise_override = {t: v.repeat(rep, 1).cuda() for t, v in noise.items()}
+    loss, bd = model(batch * rep, times=times.repeat(rep, 1), return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = model._live[0]
+    assert (plan.b, plan.n) == (64, 1024)
+    out = dict(loss=float(loss), text=float(bd.text), flow=[float(f) for f in bd.flow])
+    compare_losses(out, g)
+    nt, rs = model._live_n_true, g['row_step']
+    logits = plan.logits.view(64, 1024, -1)[:, :nt:rs, :cfg.vocab].float().cpu()
+    worst = max(rel(logits[i], g['logits'][i % 2]) for i in range(64))
+    agree = (logits.argmax(-1) == g['logits'].argmax(-1).repeat(rep, 1)).float().mean().item()
+    spread = max(rel(logits[i], logits[i % 2]) for i in range(2, 64))          # copies of a sample: identical up to nothing (same kernels, same tiles modulo position)
+    print(f'  b=64: worst per-sample logits rel-fro {worst:.3e}, argmax agreement {agree:.4f}, copy-to-copy spread {spread:.2e}')
+    assert worst <= LOGIT_TOL and agree >= 0.975 and spread <= 1e-3
+    num = den = 0.
+    for k, gn in g['grad_norms'].items():
+        go = model.store.params[k].grad.detach().float().cpu() if k in model.store.params else dict(model.named_parameters())[k].grad.float().cpu()
+        e = rel(go, g['grads'][k]) if 'grads' in g else abs(go.double().norm().item() - gn) / (gn + 1e-30)
+        assert e <= GRAD_TOL, f'gradient {k}: rel err {e:.3e}'
+        num += e * gn; den += gn
+    print(f'  b=64 gradients: norm-weighted mean rel err {num / den:.3e}')
+    _log_parity('canon512_b64', loss_rel=abs(out['loss'] - float(g['loss'])) / max(1., abs(float(g['loss']))), logits_rel=worst, argmax_unfiltered=agree, grad_mean_rel=num / den)
     assert num / den <= GRAD_MEAN_TOL
 
 

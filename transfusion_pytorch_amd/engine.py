@@ -80,6 +80,7 @@ class LaunchList(list):
     model_output_clean launch) is re-packed on every replay."""
     _image = None
     _graphs = None
+    meta = None              # {list index: (family, algorithmic work)} - bookkeeping for bench.py's per-family roofline (HBM-bound launches: bytes)
 
     def graph(self, lo: int, hi: int):
         """hipGraph of launches[lo:hi] (created on first use).  Only for lists whose kernel arguments are fixed pointers / sizes between
@@ -276,6 +277,13 @@ class Plan:
     def _raw(self, lst, fn, *args):
         lst.append((fn, args))
 
+    def _hbm(self, lst, passes, extra_bytes=0):
+        """tag the launch just appended as HBM-bound with its ALGORITHMIC traffic: `passes` sweeps of a [T, d] bf16 matrix (+ extra bytes).
+        Read by bench.py (`roofline_by_family`); no effect on the replay."""
+        if lst.meta is None:
+            lst.meta = {}
+        lst.meta[len(lst) - 1] = ('hbm', passes * self.T * self.md.dim * 2 + extra_bytes)
+
     def _tab(self, i, w):
         """pointer to (layer i, wrapper w) slice of the AdaLN tables / their grads: gamma | beta | z."""
         off = ((i * 2 + w) * 3 * self.md.dim) * 4
@@ -323,6 +331,7 @@ class Plan:
                 self._nt(L, A=lt['add'], lda=d, B=S['eye'], ldb=d, M=r, N=d, K=d, epi=E['TFX_EPI_RESID'], C=self.hid[0], ldc=d,
                          R=self.hid[0], ldr=d, resid_mapped=1, rowmap=self.row_tok[t])
         self._k(L, 'tfx_embed_fwd', 'tfx_embed_args', T=T, d=d, text_ids=self.text_ids, tok_inst=self.tok_inst, table=S['embed'], x=self.hid[0])
+        self._hbm(L, 1)
         self.fwd_cond = (len(L), len(L))      # [begin, end) of the time-conditioning launches: inst_time -> per-instance AdaLN tables
         if I > 0:
             self._k(L, 'tfx_fourier', 'tfx_fourier_args', I=I, half=d // 2, times=self.inst_time, w=ps.fourier_w, out=self.fe, ld=md.kf)
@@ -354,6 +363,7 @@ class Plan:
                 assert fused_pre[i].x == a_pre_attn.x and fused_pre[i].u == a_pre_attn.u
             else:
                 L.append(('tfx_adaln_pre_fwd', a_pre_attn))
+                self._hbm(L, 2, 8 * T)                                  # x in, u out, mean / rstd out
             self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[lkv], ldc=ldq)
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             # decode plans: the KV-cache append (k~ | v rows at `cache_pos`, T:1005-1016) rides in the same launch - a decode step is launch-bound
@@ -362,6 +372,8 @@ class Plan:
                     gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
                     cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck)
             self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
+            L.meta = L.meta or {}
+            L.meta[len(L) - 1] = ('hbm', 2 * 2 * T * hd * 2)                # q, k in; q~, k~ out
             self._k(L, 'tfx_attn_fwd' if (self.cache is None or self.tile_attn) else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
             self._nt(L, algo_k=md.hd, A=self.og[li], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[li], ldc=d)
             a_post = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[li], out=self.xb[li], tok_inst=self.tok_inst,
@@ -371,6 +383,7 @@ class Plan:
             if fuse:                          # both sides in one launch
                 self._keep = getattr(self, '_keep', []) + [a_post, a_pre]
                 self._raw(L, capi.lib().tfx_adaln_post_pre_fwd, ctypes.addressof(a_post), ctypes.addressof(a_pre))
+                self._hbm(L, 4, 8 * T)                                  # x, y in; out, u out
             else:
                 L.append(('tfx_adaln_post_fwd', a_post))
                 L.append(('tfx_adaln_pre_fwd', a_pre))
@@ -394,10 +407,14 @@ class Plan:
                     fused_pre[i + 1] = nxt
                 self._keep = getattr(self, '_keep', []) + [a_postf, a_ar, nxt]
                 self._raw(L, capi.lib().tfx_layer_end_fwd, ctypes.addressof(a_postf), ctypes.addressof(a_ar), ctypes.addressof(nxt) if nxt is not None else None)
+                # x, y in; hidden i+1 out; hiddens 0..i in (the new one comes from registers); result out (+ its rounding residual and the depth softmax
+                # for the pull-form backward); next wrapper's input out
+                self._hbm(L, 3 + (i + 1) + 1 + (1 if self.pull else 0) + (1 if nxt is not None else 0), (16 * (i + 2) * T if self.pull else 0) + 8 * T)
             else:
                 L.append(('tfx_adaln_post_fwd', a_postf))
                 L.append(('tfx_attnres_fwd', a_ar))
         self._k(L, 'tfx_rmsnorm_fwd', 'tfx_rmsnorm_args', T=T, d=d, x=self.xres[D], y=self.embed, gamma=pp('transformer.norm.gamma'))
+        self._hbm(L, 2)
         self.fwd_embed_end = len(L)          # launches up to here produce `embed` (return_embed / decode paths stop here)
         self._nt(L, A=self.embed, lda=d, B=S['logits'], ldb=d, M=T, N=md.vp, K=d, algo_n=md.vocab, epi=E['TFX_EPI_F32'], C=self.logits, ldc=md.vp)   # zero pad rows: N % 4 == 0 keeps the LDS-DMA kernel
         self.fwd_logits_end = len(L)
@@ -425,6 +442,8 @@ class Plan:
         self._ce_args = capi.make_args('tfx_ce_args', T=T, V=md.vocab, logits=self.logits, ld=md.vp, labels=self.labels, grad_scale=0.0,
                                        dlogits=self.dlogits, ld_d=md.vp, acc=self.acc)
         L.append(('tfx_ce_fwd_bwd', self._ce_args))
+        L.meta = L.meta or {}
+        L.meta[len(L) - 1] = ('hbm', T * md.vp * (4 + 2))                    # fp32 logits in, bf16 d logits out
         self._mse_args = {}
         for t, r in native.items():
             dl = md.dim_latents[t]; dlp = pad_to(dl, 64); lt = self.lat[t]
@@ -589,6 +608,7 @@ class Plan:
                      C=gp(f'model_to_latent_projs.{t}.weight'), ldc=d)
         self._k(L, 'tfx_rmsnorm_bwd', 'tfx_rmsnorm_args', T=T, d=d, x=self.xres[D], gamma=pp('transformer.norm.gamma'), dy=self.dembed,
                 dx=self.gfin, dgamma=gp('transformer.norm.gamma'))
+        self._hbm(L, 3)
         src = skip_sources(md)
         pushed = set(src.values())
         g = self.gfin
@@ -630,6 +650,7 @@ class Plan:
             self._seg_args.append(a)
             self._keep = getattr(self, '_keep', []) + [a, post]
             self._raw(L, lib.tfx_attnres_pull_bwd, ctypes.addressof(a), ctypes.addressof(post) if post is not None else None)
+            self._hbm(L, ns + 6 if post is not None else ns + 4, 12 * ns * T)     # n_src gradient rows + h, out, err in, dh out (+ g, y in, dy out of the wrapper side); saved softmax state
             if export:
                 self._tn(L, T, ns, d, A=self.k1buf, lda=32, a_cols=32, B=self.hid[l], ldb=d, b_cols=d, C=self.wtab[1, j0], ldc=d)
         for i in range(D - 1, -1, -1):
@@ -678,6 +699,7 @@ class Plan:
                 # input side of the feed-forward wrapper + output side of the attention wrapper: the residual-gradient row is written once, not read back
                 self._keep = getattr(self, '_keep', []) + [a_pref, a_posta]
                 self._raw(L, lib.tfx_adaln_pre_post_bwd, ctypes.addressof(a_pref), ctypes.addressof(a_posta))
+                self._hbm(L, 6)                                         # du, x in, residual gradient in / out, y in, dy out
             else:
                 L.append(('tfx_adaln_pre_bwd', a_pref))
                 L.append(('tfx_adaln_post_bwd', a_posta))
@@ -688,12 +710,15 @@ class Plan:
                     gamma_k=gam('k'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5,
                     dqk=self.dqk, ld_dqk=2 * hd, dqkv=dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
             self._rope_args.append(L[-1][1])
+            L.meta = L.meta or {}
+            L.meta[len(L) - 1] = ('hbm', 3 * 2 * T * hd * 2)                # q, k (raw) in; d q~, d k~ in; d q, d k out
             self._nt(L, algo_k=md.nq, A=dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             # (pull form: the gradient a U-Net skip hands to this layer's input joins here, so that G ends up as the TOTAL gradient of xres[i])
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, tok_inst=self.tok_inst, table=ta, ld_table=nt3,
                     gamma_text=pp(f'{p}.1.layernorm_gamma'), mean=_p(self.stats, 0, i), rstd=_p(self.stats, 1, i), du=self.du, dx=G,
                     dtable=dta, dgamma_text=gp(f'{p}.1.layernorm_gamma'), seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0,
                     dx_add=self.dskip[i] if (pull and i in pushed) else None)
+            self._hbm(L, 4 + (1 if (pull and i in pushed) else 0))          # du, x in; residual gradient in / out (+ the U-Net skip's share)
             self._seg_args.append(L[-1][1])
             # weight gradients of the attention wrapper (dy_a, d[q|k|v|gates] and G = dH[i+1] are final) on the side stream
             sync('tfx_fork', 2 * i + 1)

@@ -98,7 +98,9 @@ class GradReducer:
     def begin(self):
         self.handles, self.done, self.staged = [], [], []
         self.exchanged = False
-        self.launches = 0
+        self.last_launches, self.launches = self.launches, 0
+
+    last_launches = 0        # collective launches of the previous (finished) step
 
     exchanged = False        # a backward has sent layer groups out and no optimizer step has consumed them yet
     defer = False            # inside `FusedAdam.no_sync()`: this backward only accumulates (no cut, no collective) - a later one exchanges
