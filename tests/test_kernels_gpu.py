@@ -193,6 +193,46 @@ def test_gemm_nt_bench_shapes_resid_skip_geglu():
     check('bench geglu backward epilogue', dag, dag_ref, 8e-3)
 
 
+def test_geglu_table_range_ends():
+    """round 4: the ping-pong kernel's GEGLU epilogues look gelu / its derivative up in a 32 KiB LDS table (forward: second-order Taylor on a 2^-7 grid over
+    [-8, 8); backward: indexed by the bits of the saved bf16 gate for 2^-13 <= |g| < 8).  Gate pre-activations pinned (through the bias) far outside,
+    at the ends of and deep inside those ranges - saturated, clamped and tiny - against fp32 torch."""
+    torch.manual_seed(12)
+    M, d, dip = 66000, 128, 128
+    u = rnd(M, d)
+    Wa, Wg = rnd(dip, d, scale=d ** -0.5), rnd(dip, d, scale=1e-3 * d ** -0.5)
+    ba = torch.randn(dip, device=DEV)
+    pins = torch.tensor([-40., -9., -8.01, -7.99, -3., -1e-2, -2e-4, -1e-5, 0., 3e-6, 1.3e-4, 6e-3, 0.5, 2.5, 7.97, 8.03, 11., 60.], device=DEV)
+    bg = pins[torch.arange(dip, device=DEV) % pins.numel()].contiguous()
+    is_gate, feat = geglu_perm(dip)
+    is_gate, feat = is_gate.to(DEV), feat.to(DEV)
+    Wphys = torch.where(is_gate[:, None], Wg[feat], Wa[feat]).contiguous()
+    bphys = torch.where(is_gate, bg[feat], ba[feat]).contiguous()
+    ag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF); hm = torch.zeros(M, dip, device=DEV, dtype=BF)
+    gemm_nt(A=u, lda=d, B=Wphys, ldb=d, M=M, N=2 * dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU'], C=ag, ldc=2 * dip, C2=hm, ldc2=dip, bias=bphys)
+    a = u.float() @ Wa.float().T + ba
+    g = u.float() @ Wg.float().T + bg
+    href = a * F.gelu(g)
+    for c in range(pins.numel()):                                # per pinned column: elementwise, relative to the column's own scale
+        cols = torch.arange(c, dip, pins.numel(), device=DEV)
+        e = (hm[:, cols].float() - href[:, cols]).abs().max().item()
+        sc = href[:, cols].abs().max().item()
+        assert e <= 8e-3 * sc + 1e-30, f'forward, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'
+    dy, W2t = rnd(M, d), rnd(dip, d, scale=d ** -0.5)
+    dag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF)
+    gemm_nt(A=dy, lda=d, B=W2t, ldb=d, M=M, N=dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip, aux=ag, ldaux=2 * dip)
+    dh = dy.float() @ W2t.float().T
+    a_s, g_s = ag.float()[:, ~is_gate].requires_grad_(True), ag.float()[:, is_gate].requires_grad_(True)
+    (a_s * F.gelu(g_s)).backward(dh)
+    da, dg = dag.float()[:, ~is_gate], dag.float()[:, is_gate]
+    for c in range(pins.numel()):
+        cols = torch.arange(c, dip, pins.numel(), device=DEV)
+        for nm, got, ref in (('da', da, a_s.grad), ('dg', dg, g_s.grad)):
+            e = (got[:, cols] - ref[:, cols]).abs().max().item()
+            sc = ref[:, cols].abs().max().item()
+            assert e <= 8e-3 * sc + 1e-30, f'backward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'
+
+
 # ---------------------------------------------------------------------------------------------- GEMM TN
 @pytest.mark.parametrize('M,N,K,splits', [(1000, 200, 136, 1), (1000, 200, 136, 4), (4096, 1544, 512, 8), (100, 64, 64, 3),
                                           (4096, 1544, 512, 0), (8192, 512, 1408, 0), (4096, 300, 700, 16), (2048, 2816, 512, 1), (64, 130, 260, 0), (16384, 32, 512, 0),

@@ -10,6 +10,9 @@
 #include "tfx_common.h"
 #include "tfx_kernels.h"
 #include <type_traits>
+#include <cmath>
+#include <cstring>
+#include <vector>
 
 namespace tfx {
 
@@ -367,8 +370,33 @@ TFX_DEV void stage_put4_32(bf16* st, int row, int col, f32x4 v) {
 // GEGLU forward / backward with staged stores.  Forward: per 32-row block one [a|g] block (32x64) and one h block (32x32).
 // Backward: per 32-row block two [da|dg] blocks (one per 32 dh columns).  The saved-activation loads of the backward stay
 // per-lane 8-byte loads, issued one block ahead of their use (see fast_epilogue).
+// GELU table of the backward epilogue (ping-pong kernel).  The saved gate pre-activation g is a bf16 VALUE: gelu(g) = g Phi(g) and gelu'(g) = Phi(g) +
+// g phi(g) are functions of 16 bits, so the epilogue looks them up instead of evaluating an exponential, a reciprocal and a degree-5 polynomial per
+// element (~14 VALU issue slots of ~25 per element: at 128 elements per lane the GEGLU-backward epilogue took as long as the K = 512 loop it
+// follows - the kernel ran at 2.6 TB/s / 12 % of the MFMA roof, bound by neither).  4096 entries x {gelu, gelu'} fp32 = 32 KiB - exactly what the
+// 128 KiB operand ring leaves of the CU's 160 KiB - indexed by sign | (biased exponent - 114) | mantissa, i.e. every bf16 with 2^-13 <= |g| < 8;
+// smaller magnitudes clamp to the +-2^-13 entry (|error| <= 1.2e-4 x |g| on gelu, 2e-4 on gelu': below the bf16 output rounding), larger
+// ones to +-7.97 (Phi = 0 / 1 to 1e-15).  Entries are computed in double precision on the host: inside the range the result is the correctly
+// rounded function of the saved g, closer to the reference's erf than the polynomial it replaces.
+constexpr int GTAB_LO = 114 << 7, GTAB_HI = (130 << 7) - 1, GTAB_N = 4096;
+TFX_DEV f32x2_t gtab_lookup(const float* gtab, uint32_t bits16) {
+  const uint32_t mag = min(max(bits16 & 0x7fffu, (uint32_t)GTAB_LO), (uint32_t)GTAB_HI);
+  const uint32_t idx = mag - GTAB_LO + ((bits16 >> 15) << 11);
+  return *(const f32x2_t*)(gtab + 2 * idx);
+}
+// Forward: g is an fp32 accumulator, so the table is a uniform GRID over g (step 2^-7 on [-8, 8): 2048 entries x {gelu, h gelu', h^2 gelu''/2, pad} = 32 KiB)
+// and gelu(g) is its second-order Taylor polynomial around the nearest node: |error| <= (2^-8)^3 |d3 gelu| / 6 < 1e-8, also relative to gelu near 0
+// (node 0 carries 0.5 g + 0.399 g^2 exactly); beyond +-8 the clamped end nodes extrapolate linearly to g / to 0.  6 index + 3 arithmetic VALU slots
+// against ~16 incl. v_exp / v_rcp for the polynomial erf.
+TFX_DEV float gelu_grid(const float* gtab, float g) {
+  const float x = g * 128.f;
+  const float xr = __builtin_amdgcn_fmed3f(__builtin_rintf(x), -1024.f, 1023.f);
+  const float d = x - xr;
+  const f32x4 c = *(const f32x4*)(gtab + 4 * ((int)xr + 1024));
+  return fmaf(fmaf(c[2], d, c[1]), d, c[0]);
+}
 template <int EPI, int NI>
-TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st, const float* gtab = nullptr, bool use_tab = false) {
   const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
   int mo[NI][4], mo2[NI][2];                                   // rows of the 8-lane-per-row / 4-lane-per-row flush passes
 #pragma unroll
@@ -407,7 +435,14 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
         const int nl = 8 * g + 4 * hi;
         f32x4 a, gt, h;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e] + ba[g][e]; gt[e] = acc[i][1][4 * g + e] + bg[g][e]; h[e] = a[e] * gelu_erf(gt[e]); }
+        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e] + ba[g][e]; gt[e] = acc[i][1][4 * g + e] + bg[g][e]; }
+        if (use_tab) {                                           // (block-uniform) table form, see gelu_grid
+#pragma unroll
+          for (int e = 0; e < 4; e++) h[e] = a[e] * gelu_grid(gtab, gt[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) h[e] = a[e] * gelu_erf(gt[e]);
+        }
         stage_put4(s, r, nl, a); stage_put4(s, r, 32 + nl, gt); stage_put4_32(s + 2048, r, nl, h);
       }
       flush64(s, i, n_w, p.N);
@@ -454,12 +489,25 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
           const bf16x4 a4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + g) ^ (r & 15)) << 3) + 4 * hi);
           const bf16x4 g4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + 4 + g) ^ (r & 15)) << 3) + 4 * hi);
           f32x4 da, dg;
+          if (use_tab) {                                                                  // (block-uniform) table form, see gtab_lookup
+            const u32x2 gb = __builtin_bit_cast(u32x2, g4);
+            f32x2_t t[4];
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const float dh = acc[i][j][4 * g + e], a = bf2f(a4[e]), gg = bf2f(g4[e]);
-            float E; const float cdf = gelu_cdf(gg, E);                                   // one exponential serves Phi and phi
-            da[e] = dh * gg * cdf;
-            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * E);
+            for (int e = 0; e < 4; e++) t[e] = gtab_lookup(gtab, (e & 1) ? (gb[e >> 1] >> 16) : (gb[e >> 1] & 0xffffu));
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const float dh = acc[i][j][4 * g + e];
+              da[e] = dh * t[e][0];
+              dg[e] = dh * bf2f(a4[e]) * t[e][1];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const float dh = acc[i][j][4 * g + e], a = bf2f(a4[e]), gg = bf2f(g4[e]);
+              float E; const float cdf = gelu_cdf(gg, E);                                   // one exponential serves Phi and phi
+              da[e] = dh * gg * cdf;
+              dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * E);
+            }
           }
           stage_put4(st, r, 8 * g + 4 * hi, da); stage_put4(st, r, 32 + 8 * g + 4 * hi, dg);
         }
@@ -478,11 +526,11 @@ template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
 // epilogue of the LDS-DMA kernels: staged stores where the layout allows, else the direct pipelined form.
 // `st` = this wave's private LDS staging area (>= 12 KiB), valid once every wave has left the K loop.
 template <int EPI, int NI>
-TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st, const float* gtab = nullptr, bool use_tab = false) {
   if constexpr (EPI == EPI_BF16) {
     if (can_stage<EPI>(p)) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }
   } else if constexpr (EPI == EPI_GEGLU || EPI == EPI_GEGLU_BWD) {
-    if (can_stage<EPI>(p)) { staged_epilogue_geglu<EPI, NI>(p, acc, m_w, n_w, st); return; }
+    if (can_stage<EPI>(p)) { staged_epilogue_geglu<EPI, NI>(p, acc, m_w, n_w, st, gtab, use_tab); return; }
   } else if constexpr (EPI == EPI_RESID) {
     if (can_stage<EPI>(p)) { staged_epilogue_resid<NI>(p, acc, m_w, n_w, st); return; }
   }
@@ -1153,7 +1201,7 @@ TFX_DEV void dephase_first_round(int cycles, int first_round_blocks) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagger) {
+__global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagger, const float* gtab) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* lds = (bf16*)smem_raw;                                    // [2 K-tiles][A0, A1, B0, B1][128 rows x 64]
   constexpr int HALF = 128 * BK;
@@ -1227,6 +1275,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 #endif
   PP_STAMP(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
+  // GEGLU forward / backward: the 32 KiB GELU table (gelu_grid / gtab_lookup) goes into the LDS the operand ring leaves free, 4 KiB per wave, issued AHEAD of the first
+  // K-tile - the DMAs retire in order, so the prologue's wait for K-tile 0 covers the table as well
+  const float* gtab_lds = (const float*)(smem_raw + 8 * HALF * 2);  // (only dereferenced when the launch reserved it: gtab != nullptr)
+  if constexpr (EPI == EPI_GEGLU_BWD || EPI == EPI_GEGLU) {
+    if (gtab) {                                                   // kernel argument: block-uniform
+#pragma unroll
+      for (int j = 0; j < 4; j++) glds16_asm((const bf16*)gtab + (size_t)(w * 4 + j) * 512 + l * 8, (const bf16*)gtab_lds + (w * 4 + j) * 512);
+    }
+  }
   // DMA schedule, 2 pieces per wave and phase, issued inside the MFMA blocks:  p1: A1(kt+1)  p2: B1(kt+1)  p3: A0(kt+2)  p4: B0(kt+2)
   // (every slot is re-filled >= 2 phases after its last read: A1 read p3, B1 read p2, A0/B0 read p1 of the K-tile before).
   // One wait per K-tile: vmcnt(2) before p4's first barrier leaves only A0(kt+2) outstanding, i.e. certifies all of K-tile kt+1
@@ -1294,7 +1351,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 #undef PP_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();
   PP_STAMP(2)
-  nt_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 8192);   // all of LDS is free after the last barrier: 16 KiB per wave
+  nt_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 8192, gtab_lds, (EPI == EPI_GEGLU_BWD || EPI == EPI_GEGLU) && gtab != nullptr);   // all of the ring is free after the last barrier: 16 KiB per wave
   PP_STAMP(3)
 #ifdef TFX_PP_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1560,6 +1617,46 @@ static bool use_glds() {             // TFX_GEMM_GLDS=0 forces the register-stag
 //   1 glds      128 x 128 tiles, LDS-DMA, two stages
 //   0 register-staged fallback: N % 4 != 0 (the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups) or TFX_GEMM_GLDS=0
 enum { NT_FALLBACK = 0, NT_GLDS = 1, NT_MID = 2, NT_PP = 3, NT_SKINNY = 4, NT_DECODE = 5 };
+
+// device copy of the GELU table of the GEGLU-backward epilogue (gtab_lookup): built once per process and device in double precision.
+// TFX_GELU_TABLE = bit mask (1 forward, 2 backward; default 3), 0 keeps the polynomial form (A/B, tests).  Returns nullptr when disabled or when the allocation fails (the epilogue then
+// evaluates the polynomial: same results to ~1e-7).
+static const float* gelu_table(int kind) {           // kind 1: backward, indexed by the bits of the saved bf16 g (gtab_lookup); kind 0: forward grid (gelu_grid)
+  static const float* tab[2][16] = {{nullptr}};
+  static bool tried[2][16] = {{false}};
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("TFX_GELU_TABLE"); enabled = e ? atoi(e) : 3; }     // bit 0: forward, bit 1: backward
+  if (!((enabled >> kind) & 1)) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!tried[kind][dev]) {
+    tried[kind][dev] = true;
+    std::vector<float> h(2 * GTAB_N);
+    auto Phi = [](double g) { return 0.5 * erfc(-g * 0.70710678118654752440); };
+    auto phi = [](double g) { return 0.39894228040143267794 * exp(-0.5 * g * g); };
+    if (kind == 1) {
+      for (int i = 0; i < GTAB_N; i++) {
+        const uint32_t bits = ((uint32_t)(i >> 11) << 15) | (uint32_t)(GTAB_LO + (i & 2047));
+        const uint32_t f32 = bits << 16;
+        float gf; memcpy(&gf, &f32, 4);
+        const double g = gf;
+        h[2 * i] = (float)(g * Phi(g)); h[2 * i + 1] = (float)(Phi(g) + g * phi(g));
+      }
+    } else {
+      const double st = 1.0 / 128.0;
+      for (int i = 0; i < 2048; i++) {
+        const double g = (i - 1024) * st;
+        h[4 * i] = (float)(g * Phi(g));                                   // gelu
+        h[4 * i + 1] = (float)((Phi(g) + g * phi(g)) * st);               // h x first derivative
+        h[4 * i + 2] = (float)(0.5 * phi(g) * (2.0 - g * g) * st * st);   // h^2 x half the second derivative (= phi (2 - g^2))
+        h[4 * i + 3] = 0.f;
+      }
+    }
+    float* d = nullptr;
+    if (hipMalloc(&d, h.size() * 4) == hipSuccess && hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess) tab[kind][dev] = d;
+  }
+  return tab[kind][dev];
+}
 struct NtPlan { int kind, grid; };
 static NtPlan nt_plan(const GemmNT& p) {
   const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -1598,11 +1695,12 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
     }
     case NT_PP: {
       static bool attr_pp = false;
-      const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2;
-      if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2); attr_pp = true; }
+      const float* gtab = EPI == EPI_GEGLU_BWD ? gelu_table(1) : EPI == EPI_GEGLU ? gelu_table(0) : nullptr;
+      const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2 + (gtab ? GTAB_N * 8 : 0);       // GEGLU forward / backward: + the 32 KiB GELU table = all 160 KiB of the CU
+      if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8); attr_pp = true; }
       static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
       if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
-      hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(pl.grid), dim3(512), smem2, s, p, stagger);
+      hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(pl.grid), dim3(512), smem2, s, p, stagger, gtab);
       break;
     }
     case NT_MID: {
