@@ -111,6 +111,7 @@ typedef struct {
   tfx_bf16* dgate; int32_t ld_dgate;         /* grad wrt gate logits */
   tfx_bf16 *dq, *dk, *dv; int32_t ld_dq, ld_dk, ld_dv;
   int32_t order;              /* set by the library (block order of the launch); callers leave it 0 */
+  const float* sc_plan;       /* optional, forward and backward: the layer's soft-cap plan (tfx_qk_norm_rope_args.sc_plan); NULL = decide from the scores */
 } tfx_attn_args;
 int tfx_attn_fwd(const tfx_attn_args* a, void* stream);
 int tfx_attn_bwd(const tfx_attn_args* a, void* stream);   /* prep + dK/dV kernel + dQ kernel */
@@ -172,6 +173,13 @@ typedef struct {
    * `qkv`) are also written to cache row cache_pos[t] ([k~ | v], ld_cache elements per row; cache_pos < 0 = skip).  A decode step is launch-bound
    * (~4.5 us per kernel whatever its size): this removes two launches per layer */
   tfx_bf16* cache; int32_t ld_cache; const int32_t* cache_pos;
+  /* forward, optional: the layer's soft-cap plan for the attention kernels (`tfx_attn_args.sc_plan`), 8 floats written by block 0.  QK-RMSNorm bounds
+   * the scores, |q~ . k~| <= B = norm_scale^2 q_scale max|1 + gamma_q| max|1 + gamma_k| (x 1.02 for the bf16 rounding of q~, k~), so the degree of the
+   * polynomial that replaces cap tanh(s / cap) is a property of the LAYER, not of the data: the attention kernels need not look at their scores to pick
+   * it.  plan = {mode, p1, p3, p5, d1, d3, d5, B}: mode 0 (B / cap <= 0.2) cubic, mode 1 (<= 0.35) quintic - Chebyshev-economised on [-B, B],
+   * s2 = s (p1 + p3 s^2 + p5 s^4) in the log2 domain and d tanh / dx = d1 + d3 s^2 + d5 s^4 its exact derivative; mode 2: the kernels decide
+   * per wave from the scores as without a plan.  `softcap` must be the attention's. */
+  float* sc_plan; float softcap;
 } tfx_qk_norm_rope_args;
 int tfx_qk_norm_rope_fwd(const tfx_qk_norm_rope_args* a, void* stream);
 int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* stream);

@@ -363,6 +363,68 @@ def test_attention_fwd_bwd(b, h, n, qs, ks):
         assert (sim > 0.45).any(), 'this case must reach the exact-tanh branch'
 
 
+@pytest.mark.parametrize('gscale,want_mode', [(0.04, 0), (0.22, 1), (1.0, 2)])
+def test_attention_softcap_plan_from_qk_norm_bound(gscale, want_mode):
+    """round 4: the soft-cap polynomial's degree is a property of the LAYER - QK-RMSNorm bounds |q~ . k~| by
+    B = 8 max|1 + gamma_q| max|1 + gamma_k| - so tfx_qk_norm_rope_fwd writes a plan (mode, Chebyshev-economised coefficients, derivative
+    coefficients, B) and the attention kernels drop the per-score |s| maximum, the wave vote and the degree branch.  Checks: the mode thresholds,
+    B really bounds the scores of ADVERSARIAL inputs (keys aligned with queries, so the scores reach the bound), forward and backward with the plan
+    equal the fp32 reference as closely as without it."""
+    torch.manual_seed(21)
+    b, h, n = 2, 2, 384
+    T, HD = b * n, h * 64
+    ld = 3 * HD + 8
+    qkv = rnd(T, ld, scale=1.0)
+    # adversarial: every 7th key vector parallel to its own query AFTER the gains (so that q~ . k~ reaches norm_scale^2 q_scale max.. for some pairs)
+    gq = (torch.rand(64, device=DEV) * 2 - 1) * gscale; gk = (torch.rand(64, device=DEV) * 2 - 1) * gscale
+    gq[3] = gscale; gk[3] = gscale                                 # the maxima sit on the same coordinate ...
+    qkv[::7, :HD] = 0; qkv[::7, 3:HD:64] = 2.0                     # ... and these tokens' q and k are that coordinate's unit vector
+    qkv[::7, HD:2 * HD] = 0; qkv[::7, HD + 3:2 * HD:64] = 2.0
+    pos = torch.zeros(T, device=DEV, dtype=torch.int32)           # no rotation: aligned pairs stay aligned
+    cos_t, sin_t = torch.ones(8, 32, device=DEV), torch.zeros(8, 32, device=DEV)
+    qk = torch.zeros(T, 2 * HD, device=DEV, dtype=BF)
+    plan = torch.full((8,), float('nan'), device=DEV)
+    a = capi.make_args('tfx_qk_norm_rope_args', T=T, H=h, qkv=qkv, ld_qkv=ld, qk=qk, ld_qk=2 * HD, gamma_q=gq, gamma_k=gk,
+                       rot_pos=pos, cos_tab=cos_t, sin_tab=sin_t, q_scale=0.125, sc_plan=plan, softcap=50.0)
+    capi.call('tfx_qk_norm_rope_fwd', a, stream())
+    torch.cuda.synchronize()
+    pl = plan.cpu()
+    B = 1.02 * 8 * (1 + gscale) ** 2
+    assert int(pl[0]) == want_mode and abs(float(pl[7]) - B) <= 1e-4 * B, (pl, B)
+
+    def heads(x):
+        return x.float().reshape(b, n, h, 64).transpose(1, 2)
+    smax = torch.einsum('bhid,bhjd->bhij', heads(qk[:, :HD]), heads(qk[:, HD:])).abs().max().item()
+    print(f'  bound B = {float(pl[7]):.3f}, largest |score| = {smax:.3f}, mode {int(pl[0])}')
+    assert smax <= float(pl[7]) and smax >= 0.9 * 8 * (1 + gscale) ** 2       # the bound holds and is nearly attained
+    kv_end, q_start = make_kv_end(b, n)
+    kv_end, q_start = kv_end.to(DEV), q_start.to(DEV)
+    vg = rnd(T, HD + 8)
+    dout = rnd(T, HD)
+    res = []
+    for use_plan in (False, True):
+        out = torch.zeros(T, HD, device=DEV, dtype=BF); lse = torch.zeros(b, h, n, device=DEV)
+        do_eff = torch.zeros(T, HD, device=DEV, dtype=BF); delta = torch.zeros(b, h, n, device=DEV)
+        dqk = torch.zeros(T, 2 * HD, device=DEV, dtype=BF); dvg = torch.zeros(T, HD + 8, device=DEV, dtype=BF)
+        aa = capi.make_args('tfx_attn_args', q=qk, k=qk[:, HD:], v=vg, ld_q=2 * HD, ld_k=2 * HD, ld_v=HD + 8, gate=vg[:, HD:], ld_gate=HD + 8,
+                            kv_end=kv_end, q_start=q_start, out=out, ld_out=HD, lse=lse, b=b, h=h, n=n, softcap=50.0, dout=dout, ld_dout=HD,
+                            do_eff=do_eff, ld_do=HD, delta=delta, dgate=dvg[:, HD:], ld_dgate=HD + 8, dq=dqk, dk=dqk[:, HD:], dv=dvg, ld_dq=2 * HD,
+                            ld_dk=2 * HD, ld_dv=HD + 8, sc_plan=plan if use_plan else None)
+        capi.call('tfx_attn_fwd', aa, stream()); capi.call('tfx_attn_bwd', aa, stream())
+        torch.cuda.synchronize()
+        res.append((out.clone(), dqk.clone(), dvg.clone()))
+    q = heads(qk[:, :HD]).requires_grad_(True); k = heads(qk[:, HD:]).requires_grad_(True)
+    v = heads(vg[:, :HD]).requires_grad_(True); g = vg[:, HD:HD + h].float().reshape(b, n, h).transpose(1, 2).requires_grad_(True)
+    ref = attn_ref(q, k, v, g, kv_end.long(), 50.0)
+    ref.backward(heads(dout))
+    errs = []
+    for out, dqk, dvg in res:
+        errs.append((relerr(heads(out), ref), relerr(heads(dqk[:, :HD]), q.grad), relerr(heads(dqk[:, HD:]), k.grad), relerr(heads(dvg[:, :HD]), v.grad)))
+    print('  rel err (out, dq, dk, dv) without plan:', ['%.2e' % e for e in errs[0]], ' with plan:', ['%.2e' % e for e in errs[1]])
+    for e0, e1, tol in zip(errs[0], errs[1], (8e-3, 2e-2, 2e-2, 2e-2)):
+        assert e1 <= tol and e1 <= 1.25 * e0 + 1e-4
+
+
 @pytest.mark.parametrize('entry', ['tfx_attn_fwd', 'tfx_decode_attn'])     # the forward kernel with cache addressing / the decode entry (<= 2 rows per sample: one block per (sample, head), no matrix cores)
 @pytest.mark.parametrize('b,h,lq,n_kv', [(3, 2, 1, 300), (2, 4, 4, 200), (5, 1, 6, 64), (2, 8, 16, 1100), (64, 8, 1, 333), (7, 3, 2, 77), (128, 8, 5, 330), (3, 2, 8, 100), (2, 2, 3, 9), (2, 2, 7, 40)])
 def test_attention_fwd_against_kv_cache(b, h, lq, n_kv, entry):

@@ -82,20 +82,48 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // of the wave exceeds the bound the whole wave takes the exact exp2/rcp form (wave-uniform branch, no divergence).
 // Because |s2| <= cap*log2e (72 for cap 50), exp2(s2) can never overflow or vanish in fp32/bf16: the softmax uses the
 // FIXED reference 0 instead of a running maximum, which removes the max/rescale work of online softmax entirely.
-struct SoftCap { float k1, k3, k5, k7, k9, icap, cap2, smax, smid, slo, g2; };
-TFX_DEV SoftCap make_softcap(float cap) {
+struct SoftCap { float cap, g2; int mode; float p1, p3, p5, d1, d3, d5; };
+struct SoftCapLegacy { float k1, k3, k5, k7, k9, icap, cap2, smax, smid, slo; };
+// `plan` (tfx.h tfx_qk_norm_rope_args.sc_plan): the layer's polynomial, chosen from the QK-RMSNorm bound on the scores - modes 0 / 1 need no look at
+// the scores (no running |s| maximum, no wave vote, no degree branch); NULL or mode 2 = the data-dependent choice of softcap16's second half
+TFX_DEV SoftCap make_softcap(float cap, const float* plan = nullptr) {
   SoftCap c;
+  c.cap = cap; c.mode = 2; c.p1 = c.p3 = c.p5 = c.d1 = c.d3 = c.d5 = 0.f;
+  if (plan) {                                                  // kernel argument: uniform; scalar loads
+    c.mode = (int)plan[0]; c.p1 = plan[1]; c.p3 = plan[2]; c.p5 = plan[3]; c.d1 = plan[4]; c.d3 = plan[5]; c.d5 = plan[6];
+  }
+  const float cap2 = cap * LOG2E;
+  c.g2 = 1.f / (cap2 * cap2);
+  return c;
+}
+// The constants of the data-dependent form are derived where that form runs, behind an opaque copy of `cap`: VALU instructions take one scalar
+// operand, so hipcc keeps loop-invariant coefficients in VECTOR registers for the whole kernel - ten of them pushed the pipelined forward from
+// 168 to 176 allocated registers (two waves per SIMD instead of three) once the plan's coefficients joined them.
+TFX_DEV SoftCapLegacy make_softcap_legacy(float cap) {
+  asm volatile("" : "+s"(cap));
+  SoftCapLegacy c;
   const float ic = 1.f / cap, i2 = ic * ic;
   c.k1 = LOG2E; c.k3 = -LOG2E * i2 * 0.33333334f; c.k5 = LOG2E * i2 * i2 * 0.13333334f;
   c.k7 = -LOG2E * i2 * i2 * i2 * 0.053968254f; c.k9 = LOG2E * i2 * i2 * i2 * i2 * 0.021869488f;
-  c.icap = ic; c.cap2 = cap * LOG2E; c.smax = 0.45f * cap; c.smid = 0.28f * cap; c.slo = 0.12f * cap; c.g2 = 1.f / (c.cap2 * c.cap2);
+  c.icap = ic; c.cap2 = cap * LOG2E; c.smax = 0.45f * cap; c.smid = 0.28f * cap; c.slo = 0.12f * cap;
   return c;
 }
 TFX_DEV float tanh_exact(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * (2.f * LOG2E))); }
 TFX_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 TFX_DEV f32x2 bc2(float v) { f32x2 r = {v, v}; return r; }
 // in place: s <- cap*log2e*tanh(s/cap) for one 32x32 accumulator block
-TFX_DEV void softcap16(f32x16& s, const SoftCap& c) {
+TFX_DEV void softcap16(f32x16& s, const SoftCap& cp) {
+  if (cp.mode == 0) {                                           // (scalar branch) the layer's cubic
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = s[r] * fmaf(s[r] * s[r], cp.p3, cp.p1);
+    return;
+  }
+  if (cp.mode == 1) {                                          // the layer's quintic
+#pragma unroll
+    for (int r = 0; r < 16; r++) { const float u = s[r] * s[r]; s[r] = s[r] * fmaf(u, fmaf(u, cp.p5, cp.p3), cp.p1); }
+    return;
+  }
+  const SoftCapLegacy c = make_softcap_legacy(cp.cap);
   float amax = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; r++) amax = fmaxf(amax, fabsf(s[r]));
@@ -205,7 +233,7 @@ TFX_DEV BlockId decode_block(int order, int ntile, bool heavy_last_tile) {     /
 }
 
 #ifndef TFX_ATTN_FWD_WAVES
-#define TFX_ATTN_FWD_WAVES 3          // waves per SIMD the forward is compiled for (166 VGPRs fit three; 32 KiB of LDS per block)
+#define TFX_ATTN_FWD_WAVES 2          // waves per SIMD the plain-loop forward (TFX_ATTN_PIPE=0, not the product kernel) is compiled for: three spill since the soft-cap plan
 #endif
 __global__ __launch_bounds__(256, TFX_ATTN_FWD_WAVES) void attn_fwd_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(1024))) bf16 Ks[2][64 * 64];      // double-buffered LDS-DMA tiles (see swz_f)
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(256, TFX_ATTN_FWD_WAVES) void attn_fwd_kernel(tfx_a
 #pragma unroll
   for (int r = 0; r < 16; r++) zero16[r] = 0.f;
   asm volatile("" : "+v"(zero16));              // keep ONE zero accumulator live instead of 32 v_mov per tile
-  const SoftCap sc_ = make_softcap(p.softcap);
+  const SoftCap sc_ = make_softcap(p.softcap, p.sc_plan);
   const int kve_min = wave_min_i(kve);
 
   // The Q fragments / kv_end loads above are compiler-visible VMEM.  They must be CONSUMED (not just waited for in asm) before the
@@ -441,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) 
   bf16x8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks);
-  const SoftCap sc_ = make_softcap(p.softcap);
+  const SoftCap sc_ = make_softcap(p.softcap, p.sc_plan);
   const int kve_min = wave_min_i(kve);
   asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));     // consume the compiler-visible loads before the counted DMA waits
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -583,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
-  const SoftCap sc_ = make_softcap(p.softcap);
+  const SoftCap sc_ = make_softcap(p.softcap, p.sc_plan);
   f32x16 zero16;
 #pragma unroll
   for (int r = 0; r < 16; r++) zero16[r] = 0.f;
@@ -607,12 +635,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
         s = MFMA(lds_rowfrag(Ks, kb * 32, ks), qf[ks], s);
         dp = MFMA(lds_rowfrag(Vs, kb * 32, ks), dof[ks], dp);
       }
-      softcap16(s, sc_);                                             // s = s2 = cap*log2e*tanh(s/cap)
+      if (sc_.mode == 0) {                                           // the layer's cubic and ITS derivative, both from u = s^2 (4 ops instead of 5.6)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float dth = fmaf(s[r] * s[r], -sc_.g2, 1.f);           // 1 - tanh^2
-        dp[r] = (dp[r] - dlt) * dth;
-        s[r] = __builtin_amdgcn_exp2f(s[r] - lse2);                   // P^T
+        for (int r = 0; r < 16; r++) {
+          const float u = s[r] * s[r];
+          dp[r] = (dp[r] - dlt) * fmaf(u, sc_.d3, sc_.d1);
+          s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], fmaf(u, sc_.p3, sc_.p1), -lse2));       // P^T
+        }
+      } else if (sc_.mode == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float u = s[r] * s[r];
+          dp[r] = (dp[r] - dlt) * fmaf(u, fmaf(u, sc_.d5, sc_.d3), sc_.d1);
+          s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], fmaf(u, fmaf(u, sc_.p5, sc_.p3), sc_.p1), -lse2));
+        }
+      } else {
+        softcap16(s, sc_);                                           // s = s2 = cap*log2e*tanh(s/cap)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float dth = fmaf(s[r] * s[r], -sc_.g2, 1.f);         // 1 - tanh^2
+          dp[r] = (dp[r] - dlt) * dth;
+          s[r] = __builtin_amdgcn_exp2f(s[r] - lse2);                 // P^T
+        }
       }
       if (need_mask) {                                               // one scalar branch per 32-key block (boundary tiles only)
         const int key0 = j * 64 + kb * 32 + 4 * hi;
@@ -646,8 +690,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
 // dK/dV kernel: from s = soft-capped scores (log2 domain) and dp = dP of one 32-query x 32-key block: pr = P (masked when MASK), s <- dS_raw.
 // Streams register pairs (the kernel sits at the 256-VGPR limit); the mask test is hoisted into the template parameter so that interior
 // tiles carry no compare / select at all.
-template <bool MASK>
-TFX_DEV void dkv_scores(f32x16& s, const f32x16& dp, f32x16& pr, const float* s_lse, const float* s_dlt, const int* s_kve, int ql0, int krow, float g2) {
+// MODE 0 / 1: s holds the RAW scores - the layer's cubic / quintic (tfx.h soft-cap plan) and its derivative are formed here from u = s^2;
+// MODE 2: s was soft-capped by softcap16 (degree by the wave's scores), the derivative is 1 - (s2 / cap2)^2.
+template <bool MASK, int MODE>
+TFX_DEV void dkv_scores(f32x16& s, const f32x16& dp, f32x16& pr, const float* s_lse, const float* s_dlt, const int* s_kve, int ql0, int krow, float g2,
+                        const SoftCap& c) {
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) {
     const int ql = ql0 + 8 * rg;
@@ -656,15 +703,21 @@ TFX_DEV void dkv_scores(f32x16& s, const f32x16& dp, f32x16& pr, const float* s_
 #pragma unroll
     for (int e = 0; e < 4; e += 2) {
       const int r = rg * 4 + e;
-      const f32x2 a2 = {s[r], s[r + 1]};
+      f32x2 a2 = {s[r], s[r + 1]};
       const f32x2 l2 = {ls4[e], ls4[e + 1]}, d2 = {dl4[e], dl4[e + 1]};
+      f32x2 dthp = {0.f, 0.f};
+      if constexpr (MODE != 2) {
+        const f32x2 u = a2 * a2;
+        if constexpr (MODE == 0) { dthp = pk_fma(u, bc2(c.d3), bc2(c.d1)); a2 = a2 * pk_fma(u, bc2(c.p3), bc2(c.p1)); }
+        else { dthp = pk_fma(u, pk_fma(u, bc2(c.d5), bc2(c.d3)), bc2(c.d1)); a2 = a2 * pk_fma(u, pk_fma(u, bc2(c.p5), bc2(c.p3)), bc2(c.p1)); }
+      }
       const f32x2 arg = a2 - l2;
       f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
       if (MASK) {
         pv[0] = krow < kv4[e] ? pv[0] : 0.f;
         pv[1] = krow < kv4[e + 1] ? pv[1] : 0.f;
       }
-      const f32x2 dth = pk_fma(a2 * a2, bc2(-g2), bc2(1.f));           // 1 - tanh^2
+      const f32x2 dth = MODE != 2 ? dthp : pk_fma(a2 * a2, bc2(-g2), bc2(1.f));           // the polynomial's derivative / 1 - tanh^2
       const f32x2 dpp = {dp[r], dp[r + 1]};
       const f32x2 ds = pv * (dpp - d2) * dth;                          // dS_raw[q][key]
       pr[r] = pv[0]; pr[r + 1] = pv[1];
@@ -704,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-  const SoftCap sc_ = make_softcap(p.softcap);
+  const SoftCap sc_ = make_softcap(p.softcap, p.sc_plan);
   const int kw_last = k0 + w * 32 + 31;                    // last key of this wave's 32-key block
 
   TileRegs qr, dr;
@@ -738,13 +791,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
         s = MFMA(lds_rowfrag(Qs, qb2 * 32, ks), kf[ks], s);       // S[q][key]
         dp = MFMA(lds_rowfrag(Ds, qb2 * 32, ks), vf[ks], dp);     // dP[q][key]
       }
-      softcap16(s, sc_);                                             // s = s2 = cap*log2e*tanh(s/cap)
+      if (sc_.mode == 2) softcap16(s, sc_);                          // s = s2 = cap*log2e*tanh(s/cap); modes 0 / 1: inside dkv_scores
       // kv_end is non-decreasing over the real queries: the 32-query block is fully visible to this wave's keys
       // iff its first query sees the wave's last key and the block holds no rows past the end (wave-uniform)
       const bool need_mask = __builtin_amdgcn_readfirstlane((int)(kw_last >= s_kve[qb2 * 32] || jt * 64 + qb2 * 32 + 31 >= n)) != 0;
       f32x16 pr;
-      if (need_mask) dkv_scores<true>(s, dp, pr, s_lse, s_dlt, s_kve, qb2 * 32 + 4 * hi, krow, sc_.g2);      // one scalar branch per 32-query block
-      else dkv_scores<false>(s, dp, pr, s_lse, s_dlt, s_kve, qb2 * 32 + 4 * hi, krow, sc_.g2);
+      const int ql0 = qb2 * 32 + 4 * hi;
+      if (sc_.mode == 0) {                                           // scalar branches: one variant runs per 32-query block
+        if (need_mask) dkv_scores<true, 0>(s, dp, pr, s_lse, s_dlt, s_kve, ql0, krow, sc_.g2, sc_);
+        else dkv_scores<false, 0>(s, dp, pr, s_lse, s_dlt, s_kve, ql0, krow, sc_.g2, sc_);
+      } else if (sc_.mode == 1) {
+        if (need_mask) dkv_scores<true, 1>(s, dp, pr, s_lse, s_dlt, s_kve, ql0, krow, sc_.g2, sc_);
+        else dkv_scores<false, 1>(s, dp, pr, s_lse, s_dlt, s_kve, ql0, krow, sc_.g2, sc_);
+      } else {
+        if (need_mask) dkv_scores<true, 2>(s, dp, pr, s_lse, s_dlt, s_kve, ql0, krow, sc_.g2, sc_);
+        else dkv_scores<false, 2>(s, dp, pr, s_lse, s_dlt, s_kve, ql0, krow, sc_.g2, sc_);
+      }
 #pragma unroll
       for (int tt = 0; tt < 2; tt++) {
         const bf16x8 pf = pack8(pr, tt), dsf = pack8(s, tt);

@@ -223,6 +223,9 @@ class Plan:
         self.vel = LaunchList()                         # optional launches: velocity-consistency MSE against an EMA teacher's flows (T:3394-3418)
         self.rec = LaunchList()                         # optional launches: reconstruction loss on the same predictions (MP:177-200, T:2840-2853)
         self.cos_tab = self.sin_tab = None
+        # per layer: the soft-cap plan tfx_qk_norm_rope_fwd derives from the layer's QK-RMSNorm gains (tfx.h) and its attention kernels - forward
+        # and, later, backward - read: polynomial degree and coefficients from the BOUND on the scores, no look at the data.  TFX_SC_PLAN=0: decide from the scores
+        self.sc_plan = z(D, 8, dtype=torch.float32) if os.environ.get('TFX_SC_PLAN', '1') != '0' else None
         self.fwd, self.bwd = LaunchList(), LaunchList()
         self.noise_args = {}
         self.loaded_structure = None
@@ -370,7 +373,8 @@ class Plan:
             ck = dict(cache=self.cache[i], ld_cache=2 * hd, cache_pos=self.cache_pos) if self.cache is not None else {}
             self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[lkv], ld_qkv=ldq, qk=self.qkr[lkv], ld_qk=2 * hd,
                     gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
-                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck)
+                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck,
+                    **(dict(sc_plan=self.sc_plan[i], softcap=50.0) if self.sc_plan is not None else {}))
             self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
             L.meta = L.meta or {}
             L.meta[len(L) - 1] = ('hbm', 2 * 2 * T * hd * 2)                # q, k in; q~, k~ out
@@ -506,6 +510,8 @@ class Plan:
         kw = dict(q=self.qkr[lkv], k=_p(self.qkr, lkv) + 2 * hd, v=_p(self.qkvg, lkv) + 2 * 2 * hd, ld_q=2 * hd, ld_k=2 * hd, ld_v=ldq,
                   gate=_p(self.qkvg, lkv) + 2 * 3 * hd, ld_gate=ldq, kv_end=self.kv_end, q_start=self.q_start, out=self.og[li], ld_out=hd,
                   lse=self.lse[li], b=self.b, h=md.heads, n=self.n, softcap=50.0)
+        if self.sc_plan is not None:
+            kw['sc_plan'] = self.sc_plan[i]
         if self.cache is not None:
             ck = self.cache[i]
             kw.update(k=ck.data_ptr(), v=ck.data_ptr() + 2 * hd, ld_k=2 * hd, ld_v=2 * hd, n_kv=int(ck.shape[1]))
