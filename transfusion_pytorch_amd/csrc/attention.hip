@@ -695,33 +695,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
 template <bool MASK, int MODE>
 TFX_DEV void dkv_scores(f32x16& s, const f32x16& dp, f32x16& pr, const float* s_lse, const float* s_dlt, const int* s_kve, int ql0, int krow, float g2,
                         const SoftCap& c) {
+  // single-instruction fp32 forms throughout (round 4): the packed v_pk_* forms this function used since round 1 issue in 6.5 clocks per wave
+  // against 2 x 2.7 for the pair of scalar instructions they replace (tools/valu_probe.hip)
 #pragma unroll
   for (int rg = 0; rg < 4; rg++) {
     const int ql = ql0 + 8 * rg;
     const f32x4 ls4 = *(const f32x4*)(s_lse + ql), dl4 = *(const f32x4*)(s_dlt + ql);
     const int* kv4 = s_kve + ql;
 #pragma unroll
-    for (int e = 0; e < 4; e += 2) {
+    for (int e = 0; e < 4; e++) {
       const int r = rg * 4 + e;
-      f32x2 a2 = {s[r], s[r + 1]};
-      const f32x2 l2 = {ls4[e], ls4[e + 1]}, d2 = {dl4[e], dl4[e + 1]};
-      f32x2 dthp = {0.f, 0.f};
-      if constexpr (MODE != 2) {
-        const f32x2 u = a2 * a2;
-        if constexpr (MODE == 0) { dthp = pk_fma(u, bc2(c.d3), bc2(c.d1)); a2 = a2 * pk_fma(u, bc2(c.p3), bc2(c.p1)); }
-        else { dthp = pk_fma(u, pk_fma(u, bc2(c.d5), bc2(c.d3)), bc2(c.d1)); a2 = a2 * pk_fma(u, pk_fma(u, bc2(c.p5), bc2(c.p3)), bc2(c.p1)); }
+      const float a = s[r];
+      float arg, dth;
+      if constexpr (MODE == 0) {
+        const float u = a * a;
+        dth = fmaf(u, c.d3, c.d1);
+        arg = fmaf(a, fmaf(u, c.p3, c.p1), -ls4[e]);
+      } else if constexpr (MODE == 1) {
+        const float u = a * a;
+        dth = fmaf(u, fmaf(u, c.d5, c.d3), c.d1);
+        arg = fmaf(a, fmaf(u, fmaf(u, c.p5, c.p3), c.p1), -ls4[e]);
+      } else {
+        dth = fmaf(a * a, -g2, 1.f);                                   // 1 - tanh^2 from the soft-capped score
+        arg = a - ls4[e];
       }
-      const f32x2 arg = a2 - l2;
-      f32x2 pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-      if (MASK) {
-        pv[0] = krow < kv4[e] ? pv[0] : 0.f;
-        pv[1] = krow < kv4[e + 1] ? pv[1] : 0.f;
-      }
-      const f32x2 dth = MODE != 2 ? dthp : pk_fma(a2 * a2, bc2(-g2), bc2(1.f));           // the polynomial's derivative / 1 - tanh^2
-      const f32x2 dpp = {dp[r], dp[r + 1]};
-      const f32x2 ds = pv * (dpp - d2) * dth;                          // dS_raw[q][key]
-      pr[r] = pv[0]; pr[r + 1] = pv[1];
-      s[r] = ds[0]; s[r + 1] = ds[1];
+      float pv = __builtin_amdgcn_exp2f(arg);
+      if (MASK) pv = krow < kv4[e] ? pv : 0.f;
+      pr[r] = pv;
+      s[r] = pv * ((dp[r] - dl4[e]) * dth);                             // dS_raw[q][key]
     }
   }
 }
