@@ -15,7 +15,7 @@ fi
 OBJS=""
 for s in gemm attention tokenwise decode collective runner; do
   [ -f $W/pkg/csrc/$s.hip ] || continue
-  FF=""; [ $s = attention ] && [ "$REV" = WORK ] && FF="-fno-slp-vectorize"
+  FF=""; [ $s = attention ] && FF="-fno-slp-vectorize"      # (every revision: the product build always passes it, build.py FILE_FLAGS)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result $FF "$@" -c $W/pkg/csrc/$s.hip -o $W/$s.o &
   OBJS="$OBJS $W/$s.o"
 done

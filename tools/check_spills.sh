@@ -4,7 +4,8 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 for f in gemm attention tokenwise; do
-  (cd $R/transfusion_pytorch_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -I../../include -c $f.hip -o $T/$f.o -save-temps=obj 2>/dev/null)
+  FF=""; [ $f = attention ] && FF="-fno-slp-vectorize"      # build.py FILE_FLAGS
+  (cd $R/transfusion_pytorch_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC $FF -I../../include -c $f.hip -o $T/$f.o -save-temps=obj 2>/dev/null)
 done
 python3 - $T <<'PY'
 import re, sys, glob
