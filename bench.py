@@ -106,7 +106,9 @@ def timed_run(orig_run, launches, stream, lo, hi, families, events, attn_flops=0
             e0.record()
             orig_run(launches, stream, k, k + 1)
             e1.record()
-            events.append((e0, e1, c[1], c[0]))
+            fn_, a_ = launches[k]
+            shape = (getattr(a_, 'M', 0), getattr(a_, 'N', 0), getattr(a_, 'K', 0), getattr(a_, 'epi', -1)) if c[0] in ('tfx_gemm_nt', 'tfx_gemm_tn') else None
+            events.append((e0, e1, c[1], c[0], shape))
             seg = k + 1
     orig_run(launches, stream, seg, hi)
 
@@ -442,7 +444,7 @@ def main():
         capi.lib().tfx_set_single_stream(0)
         step_ms_bracketed = sum(a.elapsed_time(b) for a, b in se) / len(se)
         agg = {}
-        for e0, e1, work, fam in events:
+        for e0, e1, work, fam, _ in events:
             d = agg.setdefault(fam, [0.0, 0.0, 0])
             d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += work; d[2] += 1
         by_family = []
@@ -457,6 +459,15 @@ def main():
                               'frac': ach / (8.0 if hbm else PEAK_BF16_TFLOPS), 'ms_per_step': tsec / args.family_steps * 1e3,
                               'launches_per_step': cnt / args.family_steps,
                               ('algorithmic_gbyte_per_step' if hbm else 'algorithmic_gflop_per_step'): work / args.family_steps / 1e9})
+        if os.environ.get('TFX_BENCH_SHAPES'):                   # per GEMM shape (M, N, K, epilogue): launches / step, us / launch, TFLOP/s -> stderr
+            bys = {}
+            for e0, e1, work, fam, shape in events:
+                if shape is not None:
+                    d = bys.setdefault((fam,) + shape, [0.0, 0.0, 0])
+                    d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += work; d[2] += 1
+            for key, (tsec, work, cnt) in sorted(bys.items(), key=lambda kv: -kv[1][0]):
+                print(f'[shape] {key[0][4:]:8s} M={key[1]:6d} N={key[2]:5d} K={key[3]:5d} epi={key[4]:2d}  x{cnt / args.family_steps:5.1f}/step  {tsec / cnt * 1e6:7.1f} us  '
+                      f'{work / tsec / 1e12:7.1f} TF/s  {tsec / args.family_steps * 1e3:6.3f} ms/step', file=sys.stderr)
         events = []
         mf = [f for f in by_family if f['bound'] == 'mfma']
         agg_flops = sum(f['algorithmic_gflop_per_step'] for f in mf) * 1e9
@@ -500,8 +511,8 @@ def main():
     value = world * args.batch * args.steps / elapsed
 
     if rank == 0:
-        kt = sum(e0.elapsed_time(e1) for e0, e1, _, _ in nt_events) * 1e-3
-        kf = sum(f for _, _, f, _ in nt_events)
+        kt = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in nt_events) * 1e-3
+        kf = sum(f for _, _, f, _, _ in nt_events)
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
         n_launch = len(nt_events)
         fcore = f_core_per_sample(d=args.dim, D=args.depth)

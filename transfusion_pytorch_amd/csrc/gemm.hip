@@ -1268,7 +1268,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 
 #ifdef TFX_PP_TIMING
   // debug build: wave 0 / lane 0 of every block stamps s_memtime into (uint64*)aux[blockIdx * 8 + i] (EPI_BF16 does not use aux)
-  unsigned long long* stamps = (unsigned long long*)p.aux + (size_t)blockIdx.x * 8;
+  // (EPI_BF16 / GEGLU do not use `aux`; GEGLU backward does - its stamps travel through the unused `R`)
+  unsigned long long* stamps = (unsigned long long*)(EPI == EPI_GEGLU_BWD ? (const void*)p.R : (const void*)p.aux) + (size_t)blockIdx.x * 8;
 #define PP_STAMP(i) { if (t == 0) stamps[i] = __builtin_readcyclecounter(); }
 #else
 #define PP_STAMP(i)
