@@ -103,10 +103,19 @@ def test_sample_one_through_forward_cached_equals_uncached_and_batched_decoder()
             la, lo = pa.tolist(), po.tolist()
             k = next((i for i, (x, y) in enumerate(zip(la, lo)) if x != y), None)
             if k is not None:          # a divergence must sit on a near-tie of the un-cached full forward over the agreed history
+                # ... and on a near-tie of the OTHER path's history too: behind a decoded modality the two histories differ by that modality's own
+                # bf16 noise (held to `tol` above), so the logits they are compared through differ as well - the divergence is legitimate when the
+                # two candidate tokens are within the near-tie margin PLUS what the histories' difference moves those two logits
                 hist = list(a[:ia]) + [pa[:k]]
+                hist_o = list(other[:ia]) + [po[:k]]
                 with torch.no_grad():
-                    lg = m([hist], return_loss=False, times=torch.ones(1, 2))[0, -1]
-                assert float(lg.topk(2).values.diff().abs()) < 0.05, (k, la, lo)
+                    lg = m([hist], return_loss=False, times=torch.ones(1, 2))[0, -1].clone()
+                    lg_o = m([hist_o], return_loss=False, times=torch.ones(1, 2))[0, -1].clone()
+                ta, to = la[k], lo[k]
+                gap = float((lg[ta] - lg[to]).abs())
+                moved = float((lg[[ta, to]] - lg_o[[ta, to]]).abs().max())
+                print(f'  divergence at part {ia} pos {k}: tokens {ta} / {to}, margin {gap:.4f}, histories move these logits by {moved:.4f}')
+                assert gap < 0.05 + 2 * moved, (k, la, lo, gap, moved)
                 break
             assert len(la) == len(lo)
 

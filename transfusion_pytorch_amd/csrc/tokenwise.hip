@@ -935,9 +935,13 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
   for (int i = threadIdx.x; i < ns * (int)(sizeof(tfx_attnres_src) / 8); i += blockDim.x)
     ((unsigned long long*)srcs)[i] = ((const unsigned long long*)p.src)[i];
   __syncthreads();
+  // w rows in LDS, register form: a lane reads its 8 columns c 8 .. c 8 + 7 as two 16-byte halves - stored as [half][c][4] so that consecutive lanes are
+  // 16 bytes apart in each ds_read_b128 (the natural [c][8] image puts lanes 32 bytes apart: 2-way bank conflicts on every read, 30 % of the
+  // kernel's LDS cycles in profiles/r03_f_pmc_sq_attn_tokenwise.txt)
   for (int i = threadIdx.x; i < ns * d; i += blockDim.x) {
     const int j = i / d, c = i - j * d;
-    dyn[i] = REG ? srcs[j].w[c] : 0.f;
+    if (REG) dyn[(size_t)j * d + ((c >> 2) & 1) * (d >> 1) + (c >> 3) * 4 + (c & 3)] = srcs[j].w[c];
+    else dyn[i] = 0.f;
   }
   __syncthreads();
   Row<NC> pl, pb;
@@ -1026,7 +1030,7 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
           for (int i = 0; i < NC; i++) {
             const int c = lane + 64 * i;
             if (c * 8 >= d) continue;
-            const f32x4 w0 = *(const f32x4*)(wj + c * 8), w1 = *(const f32x4*)(wj + c * 8 + 4);
+            const f32x4 w0 = *(const f32x4*)(wj + (REG ? c * 4 : c * 8)), w1 = *(const f32x4*)(wj + (REG ? (d >> 1) + c * 4 : c * 8 + 4));
 #pragma unroll
             for (int e = 0; e < 8; e++) {
               const float we = e < 4 ? w0[e & 3] : w1[e & 3];
