@@ -36,7 +36,7 @@ typedef uint16_t tfx_bf16;
 #endif
 
 /* ---- GEMM ------------------------------------------------------------------------------------ */
-enum { TFX_EPI_BF16 = 0, TFX_EPI_F32 = 1, TFX_EPI_SILU = 2, TFX_EPI_RESID = 3, TFX_EPI_GEGLU = 4, TFX_EPI_GEGLU_BWD = 5 };
+enum { TFX_EPI_BF16 = 0, TFX_EPI_F32 = 1, TFX_EPI_SILU = 2, TFX_EPI_RESID = 3, TFX_EPI_GEGLU = 4, TFX_EPI_GEGLU_BWD = 5, TFX_EPI_QKV_NORM_ROPE = 6 };
 
 /* C[M,N] = A[M,K] . B[N,K]^T (+ epilogue).  K % 64 == 0; lda/ldb % 8 == 0; all bases 16-byte aligned.
  * Optional second A source A2 for k >= K1 (skip-proj concat without the cat copy, T:1214-1219).
@@ -56,6 +56,16 @@ typedef struct {
   const int32_t* rowmap;
   const int32_t* a_rowmap;
   const tfx_bf16* aux; int32_t ldaux;
+  /* TFX_EPI_QKV_NORM_ROPE (round 4; SURVEY K4, reference T:946-965): the fused [q | k | v | gates] projection.  C (bf16, ldc) receives the raw
+   * projection as with TFX_EPI_BF16 (the backward of the norm reads it); C2 (bf16, ldc2 >= 2 qk_heads 64) receives q~ | k~ = QK-RMSNorm + RoPE
+   * (+ the q scale) of the first 2 qk_heads 64 columns - exactly what tfx_qk_norm_rope_fwd computes from C, bit for bit, without the launch and
+   * without reading q, k back.  The qk_* fields mirror tfx_qk_norm_rope_args (gammas [64], rot_pos [M], cos / sin tables [P, 32], scales, optional
+   * soft-cap plan).  Shapes the 256 x 256 kernel does not take run as the plain projection followed by tfx_qk_norm_rope_fwd inside the call. */
+  int32_t qk_heads;
+  const float* qk_gamma_q; const float* qk_gamma_k;
+  const int32_t* qk_rot_pos; const float* qk_cos; const float* qk_sin;
+  float qk_q_scale, qk_norm_scale;
+  float* qk_plan; float qk_softcap;
 } tfx_gemm_nt_args;
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
 /* which kernel tfx_gemm_nt would launch for these arguments and on how many blocks, without launching (host logic only, no device needed):

@@ -1,5 +1,6 @@
 """Per-kernel parity: every HIP kernel (through the C ABI) vs a plain PyTorch fp32 reference of the same op.
 Tolerances: bf16 outputs rel-Frobenius <= 1e-2 (bf16 eps = 3.9e-3); fp32 outputs of bf16 MFMA GEMMs <= 5e-3."""
+import ctypes
 import math
 
 import pytest
@@ -589,6 +590,43 @@ def test_qk_norm_rope(T, H):
     check('qk_norm_rope fwd', qk.reshape(T, 2, H, 64), out, 6e-3)
     check('qk_norm_rope dx', dqkv[:, :2 * HD].reshape(T, 2, H, 64), x.grad, 1.2e-2)
     check('qk_norm_rope dgamma_q', dgq, gqr.grad, 1e-2); check('qk_norm_rope dgamma_k', dgk, gkr.grad, 1e-2)
+
+
+@pytest.mark.parametrize('T,H', [(66000, 8), (65536, 8), (1000, 2)])     # two shapes of the 256 x 256 kernel (ragged last row tile / the bench's own) and one it does not take
+def test_gemm_nt_fused_qk_norm_rope_epilogue_is_bit_identical(T, H):
+    """round 4, SURVEY K4 (T:946-965): TFX_EPI_QKV_NORM_ROPE - the [q | k | v | gates] projection whose epilogue also norms and rotates q, k - against
+    the plain projection followed by tfx_qk_norm_rope_fwd: the raw projection, q~ | k~ and the soft-cap plan must be IDENTICAL bit for bit (the
+    fused epilogue runs the token-wise kernel's arithmetic on the same bf16-rounded values)."""
+    torch.manual_seed(31)
+    d, HD = 512, H * 64
+    N = 3 * HD + H; ldq = (N + 63) // 64 * 64
+    u, W = rnd(T, d), rnd(N, d, scale=d ** -0.5)
+    gq = torch.randn(64, device=DEV) * 0.2; gk = torch.randn(64, device=DEV) * 0.2
+    pos = torch.randint(0, 1000, (T,), device=DEV, dtype=torch.int32)
+    freqs = 1. / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(1024).float()[:, None] * freqs[None]
+    cos_t, sin_t = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    # reference: two launches
+    C0 = torch.full((T, ldq), float('nan'), device=DEV, dtype=BF); qk0 = torch.full((T, 2 * HD), float('nan'), device=DEV, dtype=BF)
+    plan0 = torch.full((8,), float('nan'), device=DEV)
+    gemm_nt(A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_BF16'], C=C0, ldc=ldq)
+    a = capi.make_args('tfx_qk_norm_rope_args', T=T, H=H, qkv=C0, ld_qkv=ldq, qk=qk0, ld_qk=2 * HD, gamma_q=gq, gamma_k=gk, rot_pos=pos, cos_tab=cos_t,
+                       sin_tab=sin_t, q_scale=0.125, norm_scale=8.0, sc_plan=plan0, softcap=50.0)
+    capi.call('tfx_qk_norm_rope_fwd', a, stream())
+    # fused
+    C1 = torch.full((T, ldq), float('nan'), device=DEV, dtype=BF); qk1 = torch.full((T, 2 * HD), float('nan'), device=DEV, dtype=BF)
+    plan1 = torch.full((8,), float('nan'), device=DEV)
+    gemm_nt(A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_QKV_NORM_ROPE'], C=C1, ldc=ldq, C2=qk1, ldc2=2 * HD, qk_heads=H,
+            qk_gamma_q=gq, qk_gamma_k=gk, qk_rot_pos=pos, qk_cos=cos_t, qk_sin=sin_t, qk_q_scale=0.125, qk_norm_scale=8.0, qk_plan=plan1, qk_softcap=50.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(qk1.float()).all() and torch.isfinite(C1[:, :N].float()).all()
+    assert torch.equal(C1[:, :N], C0[:, :N]), 'raw projection'
+    assert torch.equal(qk1, qk0), f'q~ | k~ differ in {(qk1 != qk0).sum().item()} elements'
+    assert torch.equal(plan1, plan0)
+    kind, grid = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    pa = capi.make_args('tfx_gemm_nt_args', A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_BF16'], C=C0, ldc=ldq)
+    capi.lib().tfx_gemm_nt_plan(ctypes.byref(pa), ctypes.byref(kind), ctypes.byref(grid))
+    assert (kind.value == 3) == (T > 60000)                        # the large shapes really took the ping-pong kernel (fused), the small one the two launches
 
 
 def test_embed_noise_fourier():

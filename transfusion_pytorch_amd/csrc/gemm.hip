@@ -516,6 +516,101 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
     }
   }
 }
+// Fused QK-RMSNorm + RoPE behind the [q | k | v | gates] projection (TFX_EPI_QKV_NORM_ROPE; SURVEY K4, reference T:946-965).  A wave's 64 columns are ONE
+// head, and the staged store already brings the tile back from LDS in the token-wise kernel's own shape - 8 lanes per row, 8 contiguous columns
+// (4 rotary pairs) each - so the wave norms and rotates what it has just read back, with qk_norm_rope_fwd_k's arithmetic on the same bf16-rounded
+// values (bit-identical output), and stores q~ / k~ next to the raw projection.  Side data: the rotary position of a row (requested two half-blocks
+// ahead), its cos / sin row (one half-block ahead, always BEFORE the stores of the current half: loads and stores retire through one in-order
+// counter, a load behind a store waits for the store's round trip).  v and gate tiles take the plain path.
+// GUARD = false: the wave's 32 NI x 64 block lies wholly inside the matrix - no per-store predicate, hence no branches around the stores: hipcc's
+// wait-count pass merges the two sides of such a branch pessimistically and ends up draining the queue (vmcnt(0)) in the middle of the pipeline.
+template <int NI, bool GUARD>
+TFX_DEV void staged_epilogue_qknr_(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+  const int hd = p.qk_heads * 64;
+  const int which = n_w >= hd;
+  const bool col_ok = n_w + ch * 8 < p.N;
+  constexpr int NS = 2 * NI;                                       // half-blocks of 16 rows: step s = block s >> 1, row groups q = 2 (s & 1), 2 (s & 1) + 1
+  auto row_of = [&](int s, int k) { return m_w + (s >> 1) * 32 + (2 * (s & 1) + k) * 8 + (l >> 3); };
+  f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+  float rs = 0.f;
+  int pos_a[2] = {0, 0}, pos_b[2] = {0, 0};                        // positions of step s + 1 / s + 2
+  f32x4 cs_n[2], sn_n[2];                                          // cos / sin rows of step s + 1
+  auto load_pos = [&](int s, int (&pos)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) pos[k] = p.qk_rot_pos[min(row_of(s, k), p.M - 1)];
+  };
+  auto load_cs = [&](const int (&pos)[2], f32x4 (&cs)[2], f32x4 (&sn)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      cs[k] = *(const f32x4*)(p.qk_cos + (size_t)pos[k] * 32 + ch * 4);
+      sn[k] = *(const f32x4*)(p.qk_sin + (size_t)pos[k] * 32 + ch * 4);
+    }
+  };
+  {
+    const float* gm = (which ? p.qk_gamma_k : p.qk_gamma_q) + ch * 8;
+    g0 = *(const f32x4*)gm; g1 = *(const f32x4*)(gm + 4);
+    rs = (p.qk_norm_scale > 0.f ? p.qk_norm_scale : 8.f);
+    load_pos(0, pos_a);
+    load_cs(pos_a, cs_n, sn_n);                                    // step 0's rows
+    load_pos(1, pos_a);                                            // step 1's positions
+    if (NS > 2) load_pos(2, pos_b);
+    asm volatile("" ::: "memory");
+  }
+  bf16x8 v[4];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int i = s >> 1, qh = s & 1;
+    f32x4 cs[2] = {cs_n[0], cs_n[1]}, sn[2] = {sn_n[0], sn_n[1]};
+    {
+      if (s + 1 < NS) load_cs(pos_a, cs_n, sn_n);                  // next half-block's rows, ahead of this half's stores
+      pos_a[0] = pos_b[0]; pos_a[1] = pos_b[1];
+      if (s + 3 < NS) load_pos(s + 3, pos_b);
+      // compiler fence: hipcc otherwise sinks these loads to their first use, BEHIND this half's stores - and the wait for a load then
+      // drains every older store (one in-order counter): a store round trip per half-block (seen in the ISA: vmcnt waits right behind the loads)
+      asm volatile("" ::: "memory");
+    }
+    if (qh == 0) {                                                 // stage the 32-row block, read it back row-major, store the raw projection
+      bf16* sbuf = st + (i & 1) * 2048;
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          f32x4 a4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) a4[e] = acc[i][j][4 * g + e];
+          stage_put4(sbuf, r, j * 32 + 8 * g + 4 * hi, a4);
+        }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int row = q * 8 + (l >> 3);
+        v[q] = *(const bf16x8*)(sbuf + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int m = m_w + i * 32 + q * 8 + (l >> 3);
+        if (!GUARD || (col_ok && m < p.M)) *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + n_w + ch * 8) = v[q];
+      }
+    }
+    {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        float gm[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { gm[e] = g0[e]; gm[4 + e] = g1[e]; }
+        const bf16x8 o = qk_norm_rope_chunk(v[2 * qh + k], rs, which == 0 ? p.qk_q_scale : 1.f, gm, cs[k], sn[k]);
+        const int m = row_of(s, k);
+        if (!GUARD || m < p.M) *(bf16x8*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n_w + ch * 8) = o;
+      }
+    }
+  }
+}
+template <int NI>
+TFX_DEV void staged_epilogue_qknr(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  if (n_w + 64 > 2 * p.qk_heads * 64) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }      // v / gate columns: the plain staged store (wave-uniform)
+  if (m_w + 32 * NI <= p.M) staged_epilogue_qknr_<NI, false>(p, acc, m_w, n_w, st);
+  else staged_epilogue_qknr_<NI, true>(p, acc, m_w, n_w, st);
+}
 template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
   bool ok = ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0;
   if constexpr (EPI == EPI_GEGLU) ok = ok && (p.ldc2 & 7) == 0 && (((uintptr_t)p.C2) & 15) == 0;
@@ -534,7 +629,8 @@ TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w
   } else if constexpr (EPI == EPI_RESID) {
     if (can_stage<EPI>(p)) { staged_epilogue_resid<NI>(p, acc, m_w, n_w, st); return; }
   }
-  fast_epilogue<EPI, NI>(p, acc, m_w, n_w);
+  if constexpr (EPI == EPI_QKNR) staged_epilogue_qknr<NI>(p, acc, m_w, n_w, st);      // (the launcher only takes stageable layouts here: qknr_fusable)
+  else fast_epilogue<EPI, NI>(p, acc, m_w, n_w);
 }
 
 
@@ -1278,6 +1374,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
   // GEGLU forward / backward: the 32 KiB GELU table (gelu_grid / gtab_lookup) goes into the LDS the operand ring leaves free, 4 KiB per wave, issued AHEAD of the first
   // K-tile - the DMAs retire in order, so the prologue's wait for K-tile 0 covers the table as well
+  if constexpr (EPI == EPI_QKNR) {                                 // the layer's soft-cap plan (tfx.h), by the first wave of the first block
+    if (p.qk_plan && blockIdx.x == 0 && w == 0) softcap_plan_write(p.qk_gamma_q, p.qk_gamma_k, p.qk_norm_scale, p.qk_q_scale, p.qk_softcap, p.qk_plan);
+  }
   const float* gtab_lds = (const float*)(smem_raw + 8 * HALF * 2);  // (only dereferenced when the launch reserved it: gtab != nullptr)
   if constexpr (EPI == EPI_GEGLU_BWD || EPI == EPI_GEGLU) {
     if (gtab) {                                                   // kernel argument: block-uniform
@@ -1676,6 +1775,15 @@ static NtPlan nt_plan(const GemmNT& p) {
   return {dma ? NT_GLDS : NT_FALLBACK, grid};
 }
 
+template <int EPI> static void launch_pp(const GemmNT& p, int grid, hipStream_t s) {
+  static bool attr_pp = false;
+  const float* gtab = EPI == EPI_GEGLU_BWD ? gelu_table(1) : EPI == EPI_GEGLU ? gelu_table(0) : nullptr;
+  const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2 + (gtab ? GTAB_N * 8 : 0);       // GEGLU forward / backward: + the 32 KiB GELU table = all 160 KiB of the CU
+  if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8); attr_pp = true; }
+  static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
+  if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
+  hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), smem2, s, p, stagger, gtab);
+}
 template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const NtPlan pl = nt_plan(p);
   const int smem = 2 * (BM * BK + BN * BK) * 2;
@@ -1694,16 +1802,7 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
       hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sk, s, p);
       break;
     }
-    case NT_PP: {
-      static bool attr_pp = false;
-      const float* gtab = EPI == EPI_GEGLU_BWD ? gelu_table(1) : EPI == EPI_GEGLU ? gelu_table(0) : nullptr;
-      const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2 + (gtab ? GTAB_N * 8 : 0);       // GEGLU forward / backward: + the 32 KiB GELU table = all 160 KiB of the CU
-      if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8); attr_pp = true; }
-      static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
-      if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
-      hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(pl.grid), dim3(512), smem2, s, p, stagger, gtab);
-      break;
-    }
+    case NT_PP: launch_pp<EPI>(p, pl.grid, s); break;
     case NT_MID: {
       static bool attr_md = false;
       const int smem_md = MD_ST * MD_STAGE * 2;
@@ -1724,6 +1823,29 @@ int gemm_nt_plan(const GemmNT& p, int* kind, int* grid) {
   return 0;
 }
 
+// TFX_EPI_QKV_NORM_ROPE: fused in the ping-pong kernel when the shape runs there and the staged (16-byte, row-contiguous) stores apply; otherwise the
+// plain projection followed by the token-wise kernel - same results either way.  TFX_QKNR_FUSED=0 forces the two launches (A/B, tests).
+static bool qknr_fusable(const GemmNT& p) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("TFX_QKNR_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || nt_plan(p).kind != NT_PP) return false;
+  const int hd = p.qk_heads * 64;
+  return !p.rowmap && !p.a_rowmap && !p.bias && ((p.ldc | p.ldc2 | p.N) & 7) == 0 && (((uintptr_t)p.C | (uintptr_t)p.C2) & 15) == 0 && 2 * hd <= p.N && p.ldc2 >= 2 * hd;
+}
+static int gemm_nt_qknr(const GemmNT& p, hipStream_t s) {
+  if (p.qk_heads <= 0 || !p.C2 || !p.qk_gamma_q || !p.qk_gamma_k || !p.qk_rot_pos || !p.qk_cos || !p.qk_sin) return -5;
+  if (qknr_fusable(p)) { launch_pp<EPI_QKNR>(p, nt_plan(p).grid, s); return (int)hipGetLastError(); }
+  GemmNT q = p; q.epi = EPI_BF16; q.C2 = nullptr;
+  const int rc = launch_nt<EPI_BF16>(q, s);
+  if (rc) return rc;
+  tfx_qk_norm_rope_args a;
+  memset(&a, 0, sizeof(a));
+  a.T = p.M; a.H = p.qk_heads; a.qkv = (const tfx_bf16*)p.C; a.ld_qkv = p.ldc; a.qk = (tfx_bf16*)p.C2; a.ld_qk = p.ldc2;
+  a.gamma_q = p.qk_gamma_q; a.gamma_k = p.qk_gamma_k; a.rot_pos = p.qk_rot_pos; a.cos_tab = p.qk_cos; a.sin_tab = p.qk_sin;
+  a.q_scale = p.qk_q_scale; a.norm_scale = p.qk_norm_scale; a.sc_plan = p.qk_plan; a.softcap = p.qk_softcap;
+  return tfx_qk_norm_rope_fwd(&a, (void*)s);
+}
+
 int gemm_nt(const GemmNT& p, hipStream_t s) {
   if (p.K % BK != 0 || (p.A2 && p.K1 % BK != 0) || p.M <= 0 || p.N <= 0) return -1;
   if ((p.lda | p.ldb) & 7) return -2;
@@ -1734,6 +1856,7 @@ int gemm_nt(const GemmNT& p, hipStream_t s) {
     case EPI_RESID: return launch_nt<EPI_RESID>(p, s);
     case EPI_GEGLU: return (p.N % 64) ? -3 : launch_nt<EPI_GEGLU>(p, s);
     case EPI_GEGLU_BWD: return (p.N % 64) ? -3 : launch_nt<EPI_GEGLU_BWD>(p, s);
+    case EPI_QKNR: return gemm_nt_qknr(p, s);
   }
   return -4;
 }

@@ -101,6 +101,46 @@ TFX_DEV bf16x8 lds_tr8(const bf16* tile, int stride, int rowA, int rowB, int c0)
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// QK-RMSNorm + RoPE (+ the q scale) of one 8-column chunk - 4 rotary pairs - of a 64-wide head vector held by 8 adjacent lanes (T:950-952, T:965,
+// T:998): ONE spelling for the token-wise kernel and for the fused epilogue of the projection GEMM, every multiply-add an explicit fma and compiler
+// contraction off - left to itself hipcc contracts `a cs - b sn` differently in the two kernels, one bf16 ulp apart where the products cancel.
+// rs = norm_scale x (q ? q_scale : 1); gm = the chunk's 8 gains; cs / sn = the row's cos / sin for the chunk's 4 pairs.
+TFX_DEV bf16x8 qk_norm_rope_chunk(const bf16x8 x, float ns, float qs, const float* gm, const f32x4 cs, const f32x4 sn) {
+#pragma clang fp contract(off)
+  float v[8], q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q = __builtin_fmaf(v[e], v[e], q); }
+  q = group8_sum(q);
+  const float r = ns / fmaxf(sqrtf(q), 1e-12f) * qs;
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = v[2 * i] * r * (1.f + gm[2 * i]), b = v[2 * i + 1] * r * (1.f + gm[2 * i + 1]);
+    o[2 * i] = f2bf(__builtin_fmaf(a, cs[i], -(b * sn[i])));
+    o[2 * i + 1] = f2bf(__builtin_fmaf(b, cs[i], a * sn[i]));
+  }
+  return o;
+}
+
+// The layer's soft-cap plan (tfx.h tfx_qk_norm_rope_args.sc_plan), written by ONE wave (all 64 lanes call; lane e holds gain e).
+TFX_DEV void softcap_plan_write(const float* gamma_q, const float* gamma_k, float norm_scale, float q_scale, float cap, float* o) {
+  const int lane = threadIdx.x & 63;
+  const float mq = wave_max(fabsf(1.f + gamma_q[lane])), mk = wave_max(fabsf(1.f + gamma_k[lane]));
+  if (lane == 0) {
+    const float ns = norm_scale > 0.f ? norm_scale : 8.f;
+    const float B = 1.02f * ns * ns * q_scale * mq * mk, L2E = 1.4426950408889634f;
+    const float bx = B / cap, b2 = bx * bx, ic2 = 1.f / (cap * cap);
+    float mode = 2.f, a1 = 1.f, a3 = -1.f / 3.f, a5 = 0.f;
+    if (bx <= 0.2f) { mode = 0.f; a1 = 1.f - b2 * b2 / 24.f; a3 = -1.f / 3.f + b2 / 6.f; }      // x^5 economised: (2/15)((5/4) b^2 x^3 - (5/16) b^4 x)
+    else if (bx <= 0.35f) {                                                                        // x^7 economised: -(17/315)((7/4) b^2 x^5 - (7/8) b^4 x^3 + (7/64) b^6 x)
+      const float c7 = 17.f / 315.f;
+      mode = 1.f; a1 = 1.f - c7 * (7.f / 64.f) * b2 * b2 * b2; a3 = -1.f / 3.f + c7 * (7.f / 8.f) * b2 * b2; a5 = 2.f / 15.f - c7 * (7.f / 4.f) * b2;
+    }
+    o[0] = mode; o[1] = L2E * a1; o[2] = L2E * a3 * ic2; o[3] = L2E * a5 * ic2 * ic2;
+    o[4] = a1; o[5] = 3.f * a3 * ic2; o[6] = 5.f * a5 * ic2 * ic2; o[7] = B;
+  }
+}
+
 // LDS-DMA (global_load_lds_dwordx4) issued from inline asm: lane i of the wave writes 16 bytes at lds_wave_base + 16*i
 // (lane-linear 1 KiB piece), M0 = wave-uniform LDS byte address.  hipcc models the builtin form as a pending LDS write
 // and drains it with vmcnt(0); the asm form is invisible to that bookkeeping, so kernels count their own DMAs with

@@ -9,7 +9,7 @@ namespace tfx {
 using GemmNT = tfx_gemm_nt_args;
 using GemmTN = tfx_gemm_tn_args;
 enum { EPI_BF16 = TFX_EPI_BF16, EPI_F32 = TFX_EPI_F32, EPI_SILU = TFX_EPI_SILU, EPI_RESID = TFX_EPI_RESID,
-       EPI_GEGLU = TFX_EPI_GEGLU, EPI_GEGLU_BWD = TFX_EPI_GEGLU_BWD };
+       EPI_GEGLU = TFX_EPI_GEGLU, EPI_GEGLU_BWD = TFX_EPI_GEGLU_BWD, EPI_QKNR = TFX_EPI_QKV_NORM_ROPE };
 int gemm_nt(const GemmNT& p, hipStream_t s);
 int gemm_tn(const GemmTN& p, hipStream_t s);
 int gemm_nt_plan(const GemmNT& p, int* kind, int* grid);

@@ -1450,23 +1450,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args 
   const unsigned vid = gid >> 3;
   const int sub = gid & 7;
   const unsigned twoH = (p.cache ? 3u : 2u) * p.H, nvec = (unsigned)p.T * twoH;      // with a cache the v vectors ride along (copied, not normalised)
-  if (p.sc_plan && blockIdx.x == 0 && threadIdx.x < 64) {                            // the layer's soft-cap plan (tfx.h), one wave
-    const float mq = wave_max(fabsf(1.f + p.gamma_q[threadIdx.x])), mk = wave_max(fabsf(1.f + p.gamma_k[threadIdx.x]));
-    if (threadIdx.x == 0) {
-      const float ns = p.norm_scale > 0.f ? p.norm_scale : 8.f;
-      const float B = 1.02f * ns * ns * p.q_scale * mq * mk, cap = p.softcap, L2E = 1.4426950408889634f;
-      const float bx = B / cap, b2 = bx * bx, ic2 = 1.f / (cap * cap);
-      float mode = 2.f, a1 = 1.f, a3 = -1.f / 3.f, a5 = 0.f;
-      if (bx <= 0.2f) { mode = 0.f; a1 = 1.f - b2 * b2 / 24.f; a3 = -1.f / 3.f + b2 / 6.f; }      // x^5 economised: (2/15)((5/4) b^2 x^3 - (5/16) b^4 x)
-      else if (bx <= 0.35f) {                                                                        // x^7 economised: -(17/315)((7/4) b^2 x^5 - (7/8) b^4 x^3 + (7/64) b^6 x)
-        const float c7 = 17.f / 315.f;
-        mode = 1.f; a1 = 1.f - c7 * (7.f / 64.f) * b2 * b2 * b2; a3 = -1.f / 3.f + c7 * (7.f / 8.f) * b2 * b2; a5 = 2.f / 15.f - c7 * (7.f / 4.f) * b2;
-      }
-      float* o = p.sc_plan;
-      o[0] = mode; o[1] = L2E * a1; o[2] = L2E * a3 * ic2; o[3] = L2E * a5 * ic2 * ic2;
-      o[4] = a1; o[5] = 3.f * a3 * ic2; o[6] = 5.f * a5 * ic2 * ic2; o[7] = B;
-    }
-  }
+  if (p.sc_plan && blockIdx.x == 0 && threadIdx.x < 64)                              // the layer's soft-cap plan (tfx.h), one wave
+    softcap_plan_write(p.gamma_q, p.gamma_k, p.norm_scale, p.q_scale, p.softcap, p.sc_plan);
   if (vid >= nvec) return;
   const int t = (int)(vid / twoH), rem = (int)(vid - (unsigned)t * twoH);
   const int which = rem >= p.H;
@@ -1477,22 +1462,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_k(tfx_qk_norm_rope_args 
     if (cp >= 0) *(bf16x8*)(p.cache + (size_t)cp * p.ld_cache + (col - p.H * 64)) = x;
     return;
   }
-  float v[8], q = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; e++) { v[e] = bf2f(x[e]); q += v[e] * v[e]; }
-  q = group8_sum(q);
-  const float r = (p.norm_scale > 0.f ? p.norm_scale : 8.f) / fmaxf(sqrtf(q), 1e-12f) * (which == 0 ? p.q_scale : 1.f);
   const float* gm = (which == 0 ? p.gamma_q : p.gamma_k) + sub * 8;
   const int pos = p.rot_pos[t];
   const f32x4 cs = *(const f32x4*)(p.cos_tab + (size_t)pos * 32 + sub * 4);
   const f32x4 sn = *(const f32x4*)(p.sin_tab + (size_t)pos * 32 + sub * 4);
-  bf16x8 o;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    float a = v[2 * i] * r * (1.f + gm[2 * i]), b = v[2 * i + 1] * r * (1.f + gm[2 * i + 1]);
-    o[2 * i] = f2bf(a * cs[i] - b * sn[i]);
-    o[2 * i + 1] = f2bf(b * cs[i] + a * sn[i]);
-  }
+  const bf16x8 o = qk_norm_rope_chunk(x, p.norm_scale > 0.f ? p.norm_scale : 8.f, which == 0 ? p.q_scale : 1.f, gm, cs, sn);
   *(bf16x8*)(p.qk + (size_t)t * p.ld_qk + col) = o;
   if (p.cache && which) {
     const int cp = p.cache_pos[t];

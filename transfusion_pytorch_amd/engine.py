@@ -367,18 +367,21 @@ class Plan:
             else:
                 L.append(('tfx_adaln_pre_fwd', a_pre_attn))
                 self._hbm(L, 2, 8 * T)                                  # x in, u out, mean / rstd out
-            self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[lkv], ldc=ldq)
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
-            # decode plans: the KV-cache append (k~ | v rows at `cache_pos`, T:1005-1016) rides in the same launch - a decode step is launch-bound
-            ck = dict(cache=self.cache[i], ld_cache=2 * hd, cache_pos=self.cache_pos) if self.cache is not None else {}
-            self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[lkv], ld_qkv=ldq, qk=self.qkr[lkv], ld_qk=2 * hd,
-                    gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
-                    cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck,
-                    **(dict(sc_plan=self.sc_plan[i], softcap=50.0) if self.sc_plan is not None else {}))
-            self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
-            L.meta = L.meta or {}
-            L.meta[len(L) - 1] = ('hbm', 2 * 2 * T * hd * 2)                # q, k in; q~, k~ out
-            self._k(L, 'tfx_attn_fwd' if (self.cache is None or self.tile_attn) else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
+            plan_kw = dict(sc_plan=self.sc_plan[i], softcap=50.0) if self.sc_plan is not None else {}
+            if self.cache is None and os.environ.get('TFX_QKNR', '1') != '0':
+                # SURVEY K4 (T:946-965): QK-RMSNorm + RoPE ride in the epilogue of the [q | k | v | gates] projection (TFX_EPI_QKV_NORM_ROPE: the raw
+                # projection AND q~ | k~ leave the GEMM; shapes off the 256 x 256 kernel run as two launches inside the call).  Decode plans keep the
+                # token-wise launch: it also appends to the KV cache
+                self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_QKV_NORM_ROPE'], C=self.qkvg[lkv], ldc=ldq,
+                         C2=self.qkr[lkv], ldc2=2 * hd, qk_heads=H, qk_gamma_q=gam('q'), qk_gamma_k=gam('k'), qk_rot_pos=self.rot_pos, qk_cos=0, qk_sin=0,
+                         qk_q_scale=md.dim_head ** -0.5, qk_norm_scale=md.dim_head ** 0.5,
+                         **({'qk_plan': plan_kw['sc_plan'], 'qk_softcap': 50.0} if plan_kw else {}))
+                self._rope_nt_args = getattr(self, '_rope_nt_args', []) + [L[-1][1]]
+                self._k(L, 'tfx_attn_fwd', 'tfx_attn_args', **self._attn_kw(i))
+            else:
+                self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[lkv], ldc=ldq)
+                self._qknr_separate(L, i, li, lkv, gam, plan_kw)
             self._nt(L, algo_k=md.hd, A=self.og[li], lda=hd, B=S[f'out{i}'], ldb=hd, M=T, N=d, K=hd, epi=E['TFX_EPI_BF16'], C=self.ya[li], ldc=d)
             a_post = capi.make_args('tfx_adaln_post_args', T=T, d=d, x=x_a, y=self.ya[li], out=self.xb[li], tok_inst=self.tok_inst,
                                     table=ta, ld_table=nt3, layerscale=pp(f'{p}.1.layerscale'))
@@ -473,6 +476,19 @@ class Plan:
                                                **(dict(row_inst=self.row_inst[t], inst_time=self.inst_time, clean_eps=float(md.clean_eps)) if md.model_output_clean else {}))
             self.rec.append(('tfx_mse_fwd_bwd', self._rec_args[t]))
 
+    def _qknr_separate(self, L, i, li, lkv, gam, plan_kw):
+        """QK-RMSNorm + RoPE as its own token-wise launch behind the plain projection, then the attention launch (decode plans; TFX_QKNR=0)"""
+        md, T, H, hd, ldq = self.md, self.T, self.md.heads, self.md.hdk, self.md.ldq
+        # decode plans: the KV-cache append (k~ | v rows at `cache_pos`, T:1005-1016) rides in the same launch - a decode step is launch-bound
+        ck = dict(cache=self.cache[i], ld_cache=2 * hd, cache_pos=self.cache_pos) if self.cache is not None else {}
+        self._k(L, 'tfx_qk_norm_rope_fwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[lkv], ld_qkv=ldq, qk=self.qkr[lkv], ld_qk=2 * hd,
+                gamma_q=gam('q'), gamma_k=gam('k'), rot_pos=self.rot_pos,
+                cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5, **ck, **plan_kw)
+        self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
+        L.meta = L.meta or {}
+        L.meta[len(L) - 1] = ('hbm', 2 * 2 * T * hd * 2)                # q, k in; q~, k~ out
+        self._k(L, 'tfx_attn_fwd' if (self.cache is None or self.tile_attn) else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
+
     def _clean_q(self, L, t, r):
         """q = W proj of `_clean_flow`: one GEMM over the type's projected token rows"""
         md, d = self.md, self.md.dim
@@ -528,6 +544,8 @@ class Plan:
         self.cos_tab, self.sin_tab = cos_tab, sin_tab
         for a in getattr(self, '_rope_args', []):
             a.cos_tab, a.sin_tab = cos_tab.data_ptr(), sin_tab.data_ptr()
+        for a in getattr(self, '_rope_nt_args', []):                      # projections with the fused QK-norm / RoPE epilogue
+            a.qk_cos, a.qk_sin = cos_tab.data_ptr(), sin_tab.data_ptr()
 
     def set_segments(self, seg_start, seg_len):
         n_seg = int(seg_start.numel())
@@ -715,7 +733,7 @@ class Plan:
             self._k(L, 'tfx_qk_norm_rope_bwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, gamma_q=gam('q'),
                     gamma_k=gam('k'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5,
                     dqk=self.dqk, ld_dqk=2 * hd, dqkv=dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
-            self._rope_args.append(L[-1][1])
+            self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
             L.meta = L.meta or {}
             L.meta[len(L) - 1] = ('hbm', 3 * 2 * T * hd * 2)                # q, k (raw) in; d q~, d k~ in; d q, d k out
             self._nt(L, algo_k=md.nq, A=dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
