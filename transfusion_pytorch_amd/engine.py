@@ -369,10 +369,12 @@ class Plan:
                 self._hbm(L, 2, 8 * T)                                  # x in, u out, mean / rstd out
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             plan_kw = dict(sc_plan=self.sc_plan[i], softcap=50.0) if self.sc_plan is not None else {}
-            if self.cache is None and os.environ.get('TFX_QKNR', '1') != '0':
+            if self.cache is None and os.environ.get('TFX_QKNR', '0') == '1':
                 # SURVEY K4 (T:946-965): QK-RMSNorm + RoPE ride in the epilogue of the [q | k | v | gates] projection (TFX_EPI_QKV_NORM_ROPE: the raw
                 # projection AND q~ | k~ leave the GEMM; shapes off the 256 x 256 kernel run as two launches inside the call).  Decode plans keep the
-                # token-wise launch: it also appends to the KV cache
+                # token-wise launch: it also appends to the KV cache.  Built, bit-identical (tests/test_kernels_gpu.py) - and OFF by default: the
+                # projection grows from 150 to 195 us (the extra q~ | k~ stream alone is 27 us of HBM time; 16 us are the cos / sin row loads) for the
+                # 53 us launch it removes: 27.50 vs 27.50 ms per step in the same-box A/B, and the GEMM family's TFLOP/s falls with the work it absorbs
                 self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_QKV_NORM_ROPE'], C=self.qkvg[lkv], ldc=ldq,
                          C2=self.qkr[lkv], ldc2=2 * hd, qk_heads=H, qk_gamma_q=gam('q'), qk_gamma_k=gam('k'), qk_rot_pos=self.rot_pos, qk_cos=0, qk_sin=0,
                          qk_q_scale=md.dim_head ** -0.5, qk_norm_scale=md.dim_head ** 0.5,
