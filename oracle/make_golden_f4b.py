@@ -218,9 +218,81 @@ def make_unet():
           'sample', [tuple(p.shape) if torch.is_tensor(p) else tuple(p[2].shape) for p in parts])
 
 
+def teacher_parts(cfg):
+    """the EMA teacher of the combination goldens: same architecture, its own deterministic weights everywhere"""
+    sd = base_sd(cfg, 'f4b/unet/teacher', drop_proj=True)
+    enc, dec = nn.Conv2d(4, cfg.dim, 3, 2, 1), nn.ConvTranspose2d(cfg.dim, 4, 3, 2, 1, output_padding=1)
+    fill_module_(enc, 'f4b/unet/t_enc', 0.15); fill_module_(dec, 'f4b/unet/t_dec', 0.05)
+    return sd, enc, dec
+
+
+def teacher_noises():
+    return [D.det_normalish(f'f4b/u/tn{i}', s) for i, s in enumerate([(4, 8, 8), (4, 4, 8), (4, 8, 8)])]
+
+
+COMBO_DELTA = 1e-3
+
+
+def make_unet_combo(clean):
+    """SURVEY 8(f) rank 3 x rank 4: `velocity_consistency_ema_model` (T:3084-3088, T:3378-3418) - and, `clean`, `model_output_clean` (MP:786-792,
+    T:2770-2810) - on the model whose modality type runs through a learnable conv encoder / decoder pair (MP:715-745).  Student and teacher
+    are two reference models with different deterministic weights; `torch.randn_like` hands out the student's per-instance noises, then the
+    teacher's (its `return_only_pred_flows` call noises again, T:3016)."""
+    tp = import_reference()
+    cfg, sd, batch, times, noises, xm, nm, tm, g0 = unet_case()
+
+    def build(sd_, enc, dec, mlp_tag):
+        m = tp.Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=4, modality_default_shape=(8, 8), channel_first_latent=True,
+                           pre_post_transformer_enc_dec=(enc, dec), add_pos_emb=True, modality_num_dim=2, modality_processing='flat', prob_uncond=0.,
+                           model_output_clean=clean, transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+        missing, unexpected = m.load_state_dict(sd_, strict=False)
+        assert not unexpected and all(k.startswith(('pos_emb_mlp', 'latent_to_model_projs', 'model_to_latent_projs')) for k in missing), (missing, unexpected)
+        fill_module_(m.pos_emb_mlp, mlp_tag)
+        return m, {k: v.clone() for k, v in m.state_dict().items() if k.startswith(('pos_emb_mlp', 'latent_to_model_projs', 'model_to_latent_projs'))}
+
+    student, ext_sd = build(sd, *unet_modules(cfg.dim), 'f4b/unet/mlp')
+    teacher, ext_sd_t = build(*teacher_parts(cfg), 'f4b/unet/t_mlp')
+    student.train(); teacher.eval()
+    with patched('randn_like', noises + teacher_noises()) as q:
+        loss, bd = student(batch, times=times, velocity_consistency_ema_model=teacher, velocity_consistency_delta_time=COMBO_DELTA, return_breakdown=True)
+        assert not q.queue
+    loss.backward()
+    gn, gh = summarize(grads_of(student))
+    out = dict(ext_sd=ext_sd, ext_sd_teacher=ext_sd_t, loss=loss.detach(), text_loss=bd.text.detach(), flow_losses=[f.detach() for f in bd.flow],
+               velocity_losses=[v.detach() for v in bd.velocity], grad_norms=gn, grad_heads=gh)
+    if clean:
+        student.zero_grad(set_to_none=True)
+        with patched('randn_like', [nm]):
+            lm = student.forward_modality(xm, times=tm)
+        lm.backward()
+        gn_m, gh_m = summarize(grads_of(student))
+        with torch.no_grad():
+            pm = student.forward_modality(xm, times=tm, return_loss=False)
+        with patched('randn', [g0]):
+            gen = student.generate_modality_only(batch_size=2, modality_steps=GEN_STEPS)
+        import transfusion_pytorch.transfusion as T
+        orig_fn = T.default_modality_length_to_time_fn
+        T.default_modality_length_to_time_fn = lambda num_modalities: torch.ones(num_modalities.shape[0], max(int(num_modalities.amax()), 1))
+        try:                                                                # the un-cached sample_one, as in make_unet (same pinning of the text steps' times)
+            smp = student.sample_one(SAMPLE_PROMPT(), max_length=SAMPLE_MAX_LEN, text_temperature=0., init_modality_noise=SAMPLE_NOISE(), modality_steps=GEN_STEPS,
+                                     cfg_scale=1., force_modality_at_start=0, cache_kv=False)
+        finally:
+            T.default_modality_length_to_time_fn = orig_fn
+        out.update(fm_loss=lm.detach(), fm_grad_norms=gn_m, fm_grad_heads=gh_m, fm_pred=pm, gen=gen,
+                   sample=[(p if not isinstance(p, tuple) else ('mod', p[0], p[1])) for p in smp])
+    name = 'f4b_unet_clean_velocity.pt' if clean else 'f4b_unet_velocity.pt'
+    torch.save(out, os.path.join(OUT, name))
+    print(name, 'loss', float(loss), 'flow', [float(f) for f in bd.flow], 'velocity', [float(v) for v in bd.velocity],
+          *(('fm', float(out['fm_loss'])) if clean else ()))
+
+
 if __name__ == '__main__':
     import sys
-    which = sys.argv[1:] or ['pos', 'unet', 'pos_clean']
+    which = sys.argv[1:] or ['pos', 'unet', 'pos_clean', 'unet_velocity', 'unet_clean_velocity']
+    if 'unet_velocity' in which:
+        make_unet_combo(False)
+    if 'unet_clean_velocity' in which:
+        make_unet_combo(True)
     if 'pos' in which:
         make_pos()
     if 'unet' in which:

@@ -124,6 +124,34 @@ def test_sample_one_through_forward_cached_equals_uncached_and_batched_decoder()
             assert len(la) == len(lo)
 
 
+def test_decode_forward_with_model_output_clean_wraps_the_closures_in_the_model_space_conversion():
+    """`model_output_clean` in the decode contract: every `get_pred_flows` closure returns (embed rows - projected tokens) / max(1 - t, eps)
+    (the decorator of build_record_closures, MP:786-792 / MP:99-126), so the reference's `sample_one` loop over forward() decodes the same
+    modality as the batched KV-cached decoder, whose fused conversion is pinned to the reference by the `sampling_clean` golden."""
+    from transfusion_pytorch_amd import Transfusion
+    cfg, sd, prompts, noise = sampling_case()
+    m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents[0], modality_default_shape=(4,), model_output_clean=True,
+                    transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    prefix, block, t = prompts[0].cuda(), noise[:4].cuda(), torch.tensor([[0.37]])
+    with torch.no_grad():
+        emb, fns = m([[prefix, (0, block)]], times=t, return_embed=True, return_loss=False)
+        rows = fns[0][-1](emb)
+        n0 = prefix.numel()
+        packed = torch.nn.functional.linear(block, m.store.view('latent_to_model_projs.0.weight'), m.store.view('latent_to_model_projs.0.bias'))
+        want = (emb[0, n0:n0 + 4] - packed) / (1. - 0.37)
+    assert rows.shape == (4, cfg.dim) and rel(rows, want) < 1e-5
+    kw = dict(max_length=14, text_temperature=0., init_modality_noise=noise, modality_steps=3, fixed_modality_shape=(4,), cfg_scale=1., force_modality_at_start=0)
+    a = m._sample_one_through_forward(prefix, cache_kv=True, **kw)
+    b = m._sample_one_through_forward(prefix, cache_kv=False, **kw)
+    c = m.sample_one(prefix, **kw)
+    mod = lambda parts: next(p for p in parts if isinstance(p, tuple))[1]
+    e_ab, e_ac = rel(mod(a), mod(b)), rel(mod(a), mod(c))
+    print(f'decoded modality (model_output_clean): forward()-loop cached vs un-cached {e_ab:.2e}, vs the batched decoder {e_ac:.2e}')
+    assert mod(a).shape == mod(c).shape and e_ab < 5e-2 and e_ac < 5e-2
+
+
 def test_processing_strategy_registry_returns_the_reference_batch_type():
     """seam (2) of SURVEY 8(b): `PROCESSING_STRATEGIES[name](modalities, times, model, *, need_axial_pos_emb, return_loss, return_embed)` ->
     `ProcessedModalityBatch` (MP:138-147, MP:1050-1058).  Layout against the oracle's packer (pinned to the reference's known answers),

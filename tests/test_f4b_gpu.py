@@ -12,8 +12,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle.make_golden_f4b import (GEN_STEPS, SAMPLE_MAX_LEN, SAMPLE_NOISE, SAMPLE_PROMPT, pos_case, unet_case,      # noqa: E402
-                                    unet_modules)
+from oracle.make_golden_f4b import (COMBO_DELTA, GEN_STEPS, SAMPLE_MAX_LEN, SAMPLE_NOISE, SAMPLE_PROMPT, pos_case,      # noqa: E402
+                                    teacher_noises, teacher_parts, unet_case, unet_modules)
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 GRAD_TOL, GRAD_MEAN_TOL, GRAD_HEAD_TOL = 4e-2, 1.2e-2, 6e-2
@@ -226,6 +226,66 @@ def test_sample_with_unet_encoder_decoder_matches_the_references_uncached_sample
     # (the null-text cache of the guidance branch is the first cached modality step of the loop - where the reference fails, too)
     with pytest.raises(AssertionError):
         model._sample_one_through_forward(SAMPLE_PROMPT().cuda(), cache_kv=True, cfg_scale=3., **kw)
+
+
+@pytest.mark.parametrize('clean', [False, True], ids=['velocity', 'clean_velocity'])
+def test_unet_types_with_velocity_consistency_and_model_output_clean_match_reference_golden(clean):
+    """SURVEY 8(f) rank 3 x rank 4: the EMA teacher's velocity-consistency term (T:3084-3088, T:3378-3418) and `model_output_clean` (MP:786-792,
+    T:2770-2810) on a modality type whose maps are a learnable conv pair (MP:715-745).  The student's and the teacher's decoders run in PyTorch on
+    the engine's embedding rows; with `clean` the rows go through (embed - encoder output) / max(1 - t, eps) first.  Goldens from the unmodified
+    reference (oracle/make_golden_f4b.py: f4b_unet_velocity.pt, f4b_unet_clean_velocity.pt)."""
+    from transfusion_pytorch_amd import Transfusion
+    g = torch.load(os.path.join(GOLDEN, 'f4b_unet_clean_velocity.pt' if clean else 'f4b_unet_velocity.pt'), weights_only=False)
+    cfg, sd, batch, times, noises, xm, nm, tm, g0 = unet_case()
+
+    def build(sd_, enc, dec, ext_sd):
+        m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=4, modality_default_shape=(8, 8), channel_first_latent=True,
+                        pre_post_transformer_enc_dec=(enc, dec), add_pos_emb=True, modality_num_dim=2, prob_uncond=0., model_output_clean=clean,
+                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
+        m.load_state_dict({**sd_, **ext_sd}, strict=True)
+        return m.cuda()
+
+    student = build(sd, *unet_modules(cfg.dim), g['ext_sd']).train()
+    teacher = build(*teacher_parts(cfg), g['ext_sd_teacher']).eval()
+    student._noise_override = {0: [n.cuda() for n in noises]}
+    teacher._noise_override = {0: [n.cuda() for n in teacher_noises()]}
+    loss, bd = student(to_cuda(batch), times=times, velocity_consistency_ema_model=teacher, velocity_consistency_delta_time=COMBO_DELTA, return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f'[unet x velocity{" x clean" if clean else ""}] interleaved step')
+    # (clean: the conversion divides by 1 - t >= 0.05 - the flow terms carry up to 20x the bf16 noise of the embedding rows, as in the pos_clean golden)
+    tol = 5e-3 if clean else 2e-3
+    close(loss, g['loss'], 'loss', tol=tol); close(bd.text, g['text_loss'], 'text'); close(bd.flow[0], g['flow_losses'][0], 'flow', tol=tol)
+    assert len(bd.velocity) == len(g['velocity_losses']) == 1
+    close(bd.velocity[0], g['velocity_losses'][0], 'velocity', tol=tol)
+    check_grads(student, g['grad_norms'], g['grad_heads'], 'interleaved')
+    assert all(p.grad is None for p in teacher.parameters())
+    if not clean:
+        return
+    for p in student.parameters():
+        p.grad = None
+    student._noise_override = {0: nm.cuda()}
+    lm = student.forward_modality(xm.cuda(), times=tm)
+    lm.backward()
+    print('[unet x clean] forward_modality')
+    close(lm, g['fm_loss'], 'loss', tol=tol)
+    check_grads(student, g['fm_grad_norms'], g['fm_grad_heads'], 'forward_modality')
+    with torch.no_grad():
+        pm = student.forward_modality(xm.cuda(), times=tm, return_loss=False)
+    assert pm.shape == g['fm_pred'].shape and rel(pm, g['fm_pred']) <= 1.5e-2
+    student._gen_noise_override = g0
+    gen = student.generate_modality_only(batch_size=2, modality_steps=GEN_STEPS)
+    assert gen.shape == g['gen'].shape == (2, 4, 8, 8) and rel(gen, g['gen']) <= 2e-2
+    # the un-cached sample_one through the decode contract of forward(): its closures carry the conversion (MP:786-792)
+    student.eval()
+    ref = g['sample']
+    out = student.sample(SAMPLE_PROMPT().cuda(), cfg_scale=1., max_length=SAMPLE_MAX_LEN, text_temperature=0., init_modality_noise=SAMPLE_NOISE().cuda(),
+                         modality_steps=GEN_STEPS, force_modality_at_start=0)
+    assert [isinstance(p, tuple) for p in out] == [isinstance(p, tuple) for p in ref] == [False, True, False]
+    assert out[0].tolist() == ref[0].tolist() and out[1][1].shape == ref[1][2].shape == (4, 8, 8)
+    e = rel(out[1][1], ref[1][2])
+    print(f'[unet x clean] sample(): decoded image rel {e:.2e}; continuation {out[2].tolist()} vs reference {ref[2].tolist()}')
+    assert e <= 3e-2 and out[2].tolist()[0] == ref[2].tolist()[0] == student.eom_ids[0]
 
 
 def test_reconstruction_loss_matches_reference_golden():

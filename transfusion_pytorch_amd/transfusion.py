@@ -298,8 +298,6 @@ class Transfusion(nn.Module):
             if self.channel_first_latent[t]:                                                # T:1487-1491
                 pre, post = nn.Sequential(pre, _MoveDim(1, -1)), nn.Sequential(_MoveDim(-1, 1), post)
             ext_modules[t] = (pre, post)
-        if ext_modules and self.model_output_clean:
-            raise NotImplementedError('model_output_clean together with pre_post_transformer_enc_dec is not wired in the native path')
 
         self.md = ModelDims(num_text_tokens=num_text_tokens, dim=dim, depth=transformer.depth, heads=transformer.heads,
                             dim_head=transformer.dim_head, dim_latents=tuple(self.dim_latents), ff_expansion_factor=transformer.ff_expansion_factor, model_output_clean=bool(model_output_clean), clean_eps=float(eps),
@@ -493,12 +491,14 @@ class Transfusion(nn.Module):
                     if ty in self._ext:
                         c = ctx[ty]
                         x = x.to(dev, torch.float32)
+                        if times is not None:
+                            c['time'].append(times[bi, m])
                         if return_loss:
                             tt = times[bi, m]
                             ov = self._noise_override
                             eps = ov[ty][len(c['tok'])].to(dev, torch.float32) if ov is not None else torch.randn_like(x)
                             noised, flow = x * tt + eps * (1. - tt), x - eps                # MP:717-719
-                            c['flow'].append(flow); c['eps'].append(eps); c['noised'].append(noised); c['time'].append(tt)
+                            c['flow'].append(flow); c['eps'].append(eps); c['noised'].append(noised)
                         else:
                             noised = x
                         pre = self.latent_to_model_projs[ty]
@@ -511,16 +511,25 @@ class Transfusion(nn.Module):
             out.append(row)
         return out, ctx
 
-    def _ext_flow_loss(self, t, rows, ctx):
-        """flow loss of an `ext` type: the user's decoder on each instance's embedding rows (add_temp_batch_dim(model_to_latent), T:3300-3301),
-        then ONE mse over all instances of the type packed together (T:3356-3364); with a reconstruction loss also the mean over the instances of
-        mse(noised, noise + pred (1 - t)) (MP:177-200, T:3422-3426).  Returns (flow loss, reconstruction loss | None)."""
+    def _ext_decode(self, t, rows, ctx):
+        """the user's decoder on each instance's embedding rows (add_temp_batch_dim(model_to_latent), T:3300-3301), one instance at a time in scan
+        order.  `model_output_clean`: the rows go through the model-space conversion first - (embed - projected tokens) / max(1 - t, eps), the
+        decorator build_record_closures puts around every closure (MP:786-792, MP:99-126); the subtrahend is the encoder's output WITH its
+        autograd history, as there.  Returns the per-instance predictions in the decoder's layout."""
         post, d = self.model_to_latent_projs[t], self.md.dim
         preds, lo = [], 0
-        for shape in ctx['shape']:
+        for j, shape in enumerate(ctx['shape']):
             L = int(np.prod(shape))
-            preds.append(post(rows[lo:lo + L].reshape(1, *shape, d))[0])
+            e = rows[lo:lo + L]
+            if self.model_output_clean:
+                e = (e - ctx['tok'][j]) / (1. - ctx['time'][j]).clamp_min(self.md.clean_eps)
+            preds.append(post(e.reshape(1, *shape, d))[0])
             lo += L
+        return preds
+
+    def _ext_flow_loss(self, t, preds, ctx):
+        """flow loss of an `ext` type: ONE mse over all instances of the type packed together (T:3356-3364); with a reconstruction loss also the
+        mean over the instances of mse(noised, noise + pred (1 - t)) (MP:177-200, T:3422-3426).  Returns (flow loss, reconstruction loss | None)."""
         fl = torch.nn.functional.mse_loss(torch.cat([p.reshape(-1) for p in preds]), torch.cat([f.reshape(-1) for f in ctx['flow']]))
         rec = None
         if self.has_recon_loss:
@@ -739,8 +748,6 @@ class Transfusion(nn.Module):
             if return_loss and not return_embed:
                 raise NotImplementedError('kv cache / hiddens are returned by the inference forward only (return_loss = False or return_embed = True), '
                                           'as in the reference\'s own decode calls (T:1917-1924, T:1998-2006)')
-            if self.model_output_clean:
-                raise NotImplementedError('model_output_clean is not wired in the decode forward')
             return self._forward_decode(modalities, times, cache, decode_length, decoding_text_or_modality, return_embed=return_embed,
                                         return_kv_cache=return_kv_cache, return_hiddens=return_hiddens, return_times=return_times)
         ema = velocity_consistency_ema_model
@@ -756,16 +763,17 @@ class Transfusion(nn.Module):
         ps, md = self.store, self.md
 
         # ---- modality types whose encoder / decoder are user modules: their part of the packing happens in PyTorch, BEFORE the structure scan
-        ext_ctx = None
+        ext_ctx = orig_times = None
         if self._ext:
-            if ema is not None or return_only_pred_flows:
-                raise NotImplementedError('velocity consistency is not wired for pre_post_transformer_enc_dec modality types')
             is_mod = lambda p: isinstance(p, tuple) or (torch.is_tensor(p) and p.is_floating_point())
             if times is None:                                                              # T:3075-3082 (drawn before the packing, as there)
                 num_mod = np.array([sum(1 for p in sample if is_mod(p)) for sample in modalities], dtype=np.int64)
                 fn = num_modalities_to_times_fn
                 times = fn(torch.from_numpy(num_mod).to(dev)) if fn is not None else self._default_times(num_mod)
             times = times.to(dev, torch.float32)
+            if ema is not None:                                                            # T:3086-3088: the packing below noises at the shortened times
+                orig_times = times.clone()
+                times = times * (1. - velocity_consistency_delta_time)
             modalities, ext_ctx = self._ext_preprocess(modalities, times, return_loss)
 
         # ---- structure: one cheap signature pass; everything derived from it is cached ON THE DEVICE per signature
@@ -788,7 +796,7 @@ class Transfusion(nn.Module):
             fn = num_modalities_to_times_fn
             times = fn(S['num_mod_dev'].long()) if fn is not None else self._default_times(S['num_mod'], S['num_mod_dev'])
         times = times.to(dev, torch.float32)
-        if ema is not None:                                                                # T:3086-3088
+        if ema is not None and orig_times is None:                                         # T:3086-3088
             orig_times = times.clone()
             times = times * (1. - velocity_consistency_delta_time)
 
@@ -864,12 +872,17 @@ class Transfusion(nn.Module):
 
         if return_only_pred_flows:                                                        # T:3313-3316 (the EMA teacher's call)
             Plan.run(plan.fwd, stream, 0, plan.fwd_pred_end)
+            # types with user modules: their decoder on the embedding rows of every instance, in PyTorch (the teacher's call runs under no_grad)
+            ext_preds = {t: self._ext_decode(t, plan.embed.index_select(0, plan.row_tok[t].long().clamp(min=0)).float(), ext_ctx[t]) for t in R if t in plan.ext}
             if getattr(self, '_flat_pred_flows', False):
-                return {t: plan.lat[t]['pred'] for t in R}
+                return {t: (ext_preds[t] if t in plan.ext else plan.lat[t]['pred']) for t in R}
             out = [[] for _ in range(self.num_modalities)]
             cursor = {t: 0 for t in R}
             for gi in range(len(P.inst_b)):
                 t, L = int(P.inst_type[gi]), int(P.inst_len[gi])
+                if t in plan.ext:
+                    out[t].append(ext_preds[t][cursor[t]]); cursor[t] += 1
+                    continue
                 rows = plan.lat[t]['pred'][cursor[t]:cursor[t] + L]; cursor[t] += L
                 out[t].append(self._from_channel_last(t, rows.view(*P.inst_shape[gi], md.dim_latents[t]).clone()))
             return out
@@ -911,8 +924,10 @@ class Transfusion(nn.Module):
             finally:
                 ema._flat_pred_flows = False
                 ema.train(was_training)
-            velocity_losses = []
+            velocity_losses = {}
             for t, r in sorted(R.items()):
+                if t in plan.ext:                         # the student's side of these needs the user's decoder: below, with the flow loss
+                    continue
                 w_t = float(tm.is_type[t]) / total
                 plan.lat[t]['vel'].copy_(teacher[t])
                 va = plan._vel_args[t]
@@ -920,8 +935,10 @@ class Transfusion(nn.Module):
                 va.grad_scale = 2.0 * self.velocity_consistency_loss_weight * w_t / (r * md.dim_latents[t])
             Plan.run(plan.vel, stream)
             for t, r in sorted(R.items()):
+                if t in plan.ext:
+                    continue
                 vl = plan.acc[2 + M + t] / (r * md.dim_latents[t])
-                velocity_losses.append(vl)
+                velocity_losses[t] = vl
                 loss = loss + self.velocity_consistency_loss_weight * vl * (float(tm.is_type[t]) / total)
 
         recon_losses = {}
@@ -952,12 +969,19 @@ class Transfusion(nn.Module):
         else:
             emb_rows = [plan.embed.index_select(0, plan.row_tok[t].long().clamp(min=0)).float() for t in ext_out]
         for t, rows in zip(ext_out, emb_rows):                                              # the user's decoders and their flow losses, in PyTorch
-            fl, rec = self._ext_flow_loss(t, rows, ext_ctx[t])
+            preds = self._ext_decode(t, rows, ext_ctx[t])
+            fl, rec = self._ext_flow_loss(t, preds, ext_ctx[t])
             flow_losses[t] = fl
             loss = loss + self.flow_loss_weight * fl * (float(tm.is_type[t]) / total)
             if rec is not None:
                 recon_losses[t] = rec
                 loss = loss + self.reconstruction_loss_weight * rec * (float(tm.is_type[t]) / total)
+            if ema is not None:                                                             # T:3397-3411: mse(student flows, teacher flows), all instances of the type packed
+                vl = torch.nn.functional.mse_loss(torch.cat([p.reshape(-1) for p in preds]), torch.cat([p.reshape(-1) for p in teacher[t]]))
+                velocity_losses[t] = vl
+                loss = loss + self.velocity_consistency_loss_weight * vl * (float(tm.is_type[t]) / total)
+        if velocity_losses is not None:
+            velocity_losses = [velocity_losses[t] for t in sorted(velocity_losses)]
         flow_losses = [flow_losses[t] for t in sorted(flow_losses)]
         recon_losses = [recon_losses[t] for t in sorted(recon_losses)] if self.has_recon_loss else None
         if not return_breakdown and not return_times:
@@ -970,11 +994,14 @@ class Transfusion(nn.Module):
         return ret
 
     # ------------------------------------------------------------------ decode contract of forward() (T:2926-2948, T:3186-3271)
-    def _pred_flow_closures(self, P):
+    def _pred_flow_closures(self, P, clean_src=None):
         """`get_pred_flows` of the reference (build_record_closures MP:764-805, model_to_pred_flow MP:160-175): per modality type, in scan
-        order, closures that cut an instance's rows out of an `embed` (b, n, d) tensor and reshape them to (*axial shape, d)."""
+        order, closures that cut an instance's rows out of an `embed` (b, n, d) tensor and reshape them to (*axial shape, d).
+        `model_output_clean` (`clean_src`: per instance its (type, tensor as the packer saw it, time)): every closure is wrapped in the model-space
+        conversion (embed - projected tokens) / max(1 - t, eps) (get_model_output_to_flow_fn as decorator, MP:99-126, MP:786-792) - the projection
+        of the instance is evaluated when the closure is called (the samplers only ever call the last one)."""
         out = [[] for _ in range(self.num_modalities)]
-        d = self.md.dim
+        d, eps = self.md.dim, self.md.clean_eps
         for gi in range(len(P.inst_b)):
             bi, off, L, shape = int(P.inst_b[gi]), int(P.inst_off[gi]), int(P.inst_len[gi]), tuple(P.inst_shape[gi])
 
@@ -983,7 +1010,37 @@ class Transfusion(nn.Module):
                 if need_splice:
                     e = e[-L:] if e.shape[0] < off + L else e[off:off + L]      # MP:167-171: a decode-step embed holds the new block only
                 return e.reshape(*shape, d)
+            if clean_src is not None:
+                def inner(embed, need_splice=True, fn=inner, src=clean_src[gi]):
+                    o = fn(embed, need_splice)
+                    ty, x, tt = src
+                    return (o - self._packed_tokens(ty, x).reshape_as(o).to(o)) / (1. - tt).clamp_min(eps)
             out[int(P.inst_type[gi])].append(inner)
+        return out
+
+    def _packed_tokens(self, ty, x):
+        """`processed.packed` of an instance (MP:729-732): latent_to_model of the (noised) latents - the user's encoder for an `ext` type (encoder
+        layout in), else the Linear in fp32 from the master weights on (*axial, dim_latent) - before any positional embedding (T:3173-3176)"""
+        x = x.to(self.device, torch.float32)
+        if ty in self._ext:
+            pre = self.latent_to_model_projs[ty]
+            return pre(x[None])[0] if self.channel_first_latent[ty] else pre(x)
+        if self.md.dim_latents[ty] == self.md.dim:
+            return x
+        return torch.nn.functional.linear(x, self.store.view(f'latent_to_model_projs.{ty}.weight'), self.store.view(f'latent_to_model_projs.{ty}.bias'))
+
+    def _clean_sources(self, modalities, times):
+        """per modality instance of the batch, in scan order: (type, tensor, time) for the `model_output_clean` closures of the decode forward"""
+        out = []
+        for bi, sample in enumerate(modalities):
+            m = 0
+            for part in sample:
+                if torch.is_tensor(part) and part.is_floating_point():
+                    part = (0, part)
+                if isinstance(part, tuple):
+                    tt = times[bi, min(m, times.shape[1] - 1)] if (times is not None and times.ndim == 2 and times.shape[1]) else torch.ones((), device=self.device)
+                    out.append((int(part[0]), part[1], tt.to(self.device, torch.float32)))
+                    m += 1
         return out
 
     def model_to_latent(self, modality_type: int, embed_rows):
@@ -1049,7 +1106,8 @@ class Transfusion(nn.Module):
             # the padding columns sit behind every real token and are cut off again below
             plan, S = self._forward_plain(modalities, times, add_meta=not return_embed, pad_n=64)
             n_pad, n, P, tm = S['n'], S['n_true'], S['P'], S['tm']
-            out = (plan.embed.view(b, n_pad, md.dim)[:, :n].float(), self._pred_flow_closures(P)) if return_embed \
+            out = (plan.embed.view(b, n_pad, md.dim)[:, :n].float(),
+                   self._pred_flow_closures(P, self._clean_sources(modalities, times) if md.model_output_clean else None)) if return_embed \
                 else plan.logits.view(b, n_pad, md.vp)[:, :n, :md.vocab].clone()
             kv = None
             if return_kv_cache:
@@ -1121,7 +1179,8 @@ class Transfusion(nn.Module):
                     with torch.no_grad():
                         scan_in, _ = self._ext_preprocess(modalities, None, return_loss=False)
                 P = self._scan(scan_in, add_sos_eos=False, add_meta=False)
-                out = (plan.embed.view(b, L, md.dim).float(), self._pred_flow_closures(P))
+                out = (plan.embed.view(b, L, md.dim).float(),
+                       self._pred_flow_closures(P, self._clean_sources(modalities, times.to(dev, torch.float32).reshape(b, -1) if times is not None else None) if md.model_output_clean else None))
             else:
                 out = plan.logits.view(b, L, md.vp)[..., :md.vocab].clone()
             kv = None
@@ -1321,7 +1380,10 @@ class Transfusion(nn.Module):
         if not return_loss:
             if ext:
                 Plan.run(plan.fwd, stream, 0, plan.fwd_embed_end)
-                return self.model_to_latent_projs[t](plan.embed.view(b, *axial, d).float())
+                out = self.model_to_latent_projs[t](plan.embed.view(b, *axial, d).float())
+                if md.model_output_clean:                                             # T:2770-2771, T:2810: the latent-space conversion around the user's decoder
+                    out = (out - noised) / (1. - times.view(b, *([1] * (raw.ndim - 1)))).clamp_min(md.clean_eps)
+                return out
             plan.set_noise(t, None)                                                  # T:2759-2760: no noising
             Plan.run(plan.fwd, stream, 0, plan.fwd_pred_end)
             out = lt['pred'].view(x.shape).clone()
@@ -1405,6 +1467,8 @@ class Transfusion(nn.Module):
             emb_rows = [plan.embed.float()]
         if ext:                                                                            # the user's decoder and the flow loss, in PyTorch (T:2806-2817)
             pred = self.model_to_latent_projs[t](emb_rows[0].view(b, *axial, d))
+            if md.model_output_clean:                                                   # T:2770-2771, T:2810
+                pred = (pred - noised) / (1. - tt).clamp_min(md.clean_eps)
             flow_loss = torch.nn.functional.mse_loss(pred, flow_ext)
             loss = loss + flow_loss
             if self.has_recon_loss:
