@@ -764,6 +764,7 @@ class Transfusion(nn.Module):
 
         # ---- modality types whose encoder / decoder are user modules: their part of the packing happens in PyTorch, BEFORE the structure scan
         ext_ctx = orig_times = None
+        packer_in = modalities                                # what the packer sees (channel-last; `ext` types in their encoder's layout)
         if self._ext:
             is_mod = lambda p: isinstance(p, tuple) or (torch.is_tensor(p) and p.is_floating_point())
             if times is None:                                                              # T:3075-3082 (drawn before the packing, as there)
@@ -865,7 +866,7 @@ class Transfusion(nn.Module):
             end = plan.fwd_embed_end if return_embed else plan.fwd_logits_end
             Plan.run(plan.fwd, stream, 0, end)
             if return_embed:                                                               # T:3275-3276: (embed, get_pred_flows)
-                out = (plan.embed.view(b, n, md.dim).float(), self._pred_flow_closures(P))
+                out = (plan.embed.view(b, n, md.dim).float(), self._pred_flow_closures(P, self._clean_sources(packer_in, times) if md.model_output_clean else None))
                 return out if not return_times else (out, times)
             logits = plan.logits.view(b, n, md.vp)[..., :md.vocab].clone()
             return (logits, times) if return_times else logits
