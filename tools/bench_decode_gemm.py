@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transfusion_pytorch_amd import capi
 from bench_gemm import timeit, st, dev, BF
-for M in (64, 128, 640):
+for M in ([int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else (64, 128, 640)):
     for (N, K, epi) in [(1544, 1024, 'TFX_EPI_BF16'), (1024, 512, 'TFX_EPI_BF16'), (5504, 1024, 'TFX_EPI_GEGLU'), (1024, 2752, 'TFX_EPI_BF16'), (1024, 2048, 'TFX_EPI_RESID'), (448, 1024, 'TFX_EPI_F32')]:
         A = torch.randn(M, K, device=dev).to(BF); B = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
         C = torch.empty(M, N, device=dev, dtype=torch.float32 if epi.endswith('F32') else BF)

@@ -12,7 +12,10 @@ smp = Sampler(m)
 m._decode_plans = {}
 B, maxlen, filled = 64, 512, 200
 stream = m._stream()
-for rows, Lq, name in ((B, 1, 'text step (64 rows)'), (2 * B, 4, 'joint modality evaluation (512 rows)')):
+cases = ((B, 1, 'text step (64 rows)'), (2 * B, 4, 'joint modality evaluation (512 rows)'))
+if len(sys.argv) > 1:                      # rows-per-step sweep: "samples:Lq,samples:Lq,..." (what compaction of a mixed step would buy)
+    cases = tuple((int(a.split(':')[0]), int(a.split(':')[1]), f'{a.split(":")[0]} samples x {a.split(":")[1]} rows') for a in sys.argv[1].split(','))
+for rows, Lq, name in cases:
     cache = smp._alloc_cache(rows, maxlen)
     p = smp._decode_plan((name, cache.data_ptr()), rows, Lq, cache, Lq > 1)
     T = rows * Lq

@@ -30,6 +30,37 @@ __global__ __launch_bounds__(256) void burn(const bf16x8* ops, float* out, unsig
   if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+// the 16x16x32 shape (what the vendor library's kernels issue, `MI16x16x1`): 8 independent accumulators of 4 registers, half the flops per instruction
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__global__ __launch_bounds__(256) void burn16(const bf16x8* ops, float* out, unsigned long long* ticks, int iters) {
+  bf16x8 a = ops[threadIdx.x & 63], b = ops[64 + (threadIdx.x & 63)];
+  f32x4 c[8] = {};
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[k]) : "v"(a), "v"(b));
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+  for (int k = 0; k < 8; k++) for (int i = 0; i < 4; i++) s += c[k][i];
+  if (s == 1.2345f) out[1] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+void run16(const bf16x8* ops, float* out, unsigned long long* ticks, int blocks_per_cu) {
+  const int iters = 20000, nblk = 256 * blocks_per_cu;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(burn16, dim3(nblk), dim3(256), 0, 0, ops, out, ticks, iters / 10);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(burn16, dim3(nblk), dim3(256), 0, 0, ops, out, ticks, iters);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long t; hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+  const double flop = 2.0 * 16 * 16 * 32 * 8.0 * iters * (nblk * 4.0);
+  printf("%-44s %d block(s)/CU: %7.1f TFLOP/s  (%.3f ms, shader clock %.2f GHz, %.1f clocks per MFMA per SIMD)\n", "MFMA only, 16x16x32", blocks_per_cu, flop / ms * 1e-9, ms,
+         t / (ms * 1e6), (double)t / (8.0 * iters) / blocks_per_cu);
+}
+
 template <int NV> void run(const char* name, const bf16x8* ops, float* out, unsigned long long* ticks, int blocks_per_cu) {
   const int iters = 20000, nblk = 256 * blocks_per_cu;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -56,6 +87,8 @@ int main() {
     printf("== operands: %s\n", fill ? "uniform random [-1, 1)" : "zero");
     run<0>("MFMA only", ops, out, ticks, 1);
     run<0>("MFMA only", ops, out, ticks, 2);
+    run16(ops, out, ticks, 1);
+    run16(ops, out, ticks, 2);
     run<4>("MFMA + 4 v_fma per MFMA", ops, out, ticks, 1);
     run<8>("MFMA + 8 v_fma per MFMA", ops, out, ticks, 1);
     run<8>("MFMA + 8 v_fma per MFMA", ops, out, ticks, 2);
