@@ -387,11 +387,11 @@ def main():
     families = [{args.roofline_kernel}]
     n_inst, L_lat, n_tok = 32, 4, 1024
     attn_flops = 4.0 * 64 * (n_tok * (n_tok + 1) / 2 + n_inst * L_lat * (L_lat - 1) / 2) * args.batch * 8      # per launch: 4 dh pairs per (sample, head), mask-aware
-    def run(launches, stream_, lo=0, hi=None):
+    def run(launches, stream_, lo=0, hi=None, graph=False):
         if sampled[0]:
             timed_run(orig_run, launches, stream_, lo, hi, families[0], events, attn_flops)
         else:
-            orig_run(launches, stream_, lo, hi)
+            orig_run(launches, stream_, lo, hi, graph=graph)
     Plan.run = staticmethod(run)
     n_sampled = 0
     host_t = 0.0

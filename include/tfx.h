@@ -440,6 +440,10 @@ int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* faile
 int tfx_graph_create(const tfx_launch* list, int32_t n, void** graph_out);
 int tfx_graph_launch(void* graph, void* stream);
 int tfx_graph_destroy(void* graph);
+/* 64-bit fingerprint of everything a capture of the list would freeze: ops, stream tags, the bytes of every args struct (and of the host structs
+ * the two-struct entry points point at), the single-stream switch.  A caller that replays a TRAINING list as a graph compares it with the
+ * fingerprint the graph was captured under and re-captures (or replays the list) when a scalar / pointer of the step has changed. */
+int tfx_list_fingerprint(const tfx_launch* list, int32_t n, int64_t* out);
 /* on != 0: replay every item on the caller's stream (FORK / JOIN become no-ops) - same results, kernels one at a time (used to time a
  * kernel family without its side-stream neighbours); returns the previous setting */
 int tfx_set_single_stream(int32_t on);

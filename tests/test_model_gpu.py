@@ -483,7 +483,7 @@ def test_native_list_replay_equals_per_launch_calls():
     orig = Plan.run
     for per_launch in (False, True):
         if per_launch:
-            Plan.run = staticmethod(lambda launches, stream, lo=0, hi=None: orig(list(launches), stream, lo, hi))
+            Plan.run = staticmethod(lambda launches, stream, lo=0, hi=None, graph=False: orig(list(launches), stream, lo, hi))
         try:
             cfg, model, out = run_native('small2')
         finally:
@@ -515,6 +515,50 @@ def test_side_stream_weight_gradients_equal_single_stream():
         assert abs(o['loss'] - ref['loss']) <= 1e-6 * max(1., abs(ref['loss']))
         for k in ref['grads']:
             assert rel(o['grads'][k], ref['grads'][k]) <= 2e-3, k
+
+
+def test_training_lists_replay_as_graphs_while_their_fingerprint_holds(monkeypatch):
+    """TFX_TRAIN_GRAPH=1: the forward / backward launch lists of a fixed-shape training loop run as ONE hipGraph launch each from the third step
+    on (LaunchList.replay_auto: captured once `tfx_list_fingerprint` - every byte a capture freezes - has repeated), the side-stream
+    weight-gradient GEMMs in list order on the one chain.  Same launches, same arguments: loss and gradients equal the list replay's to
+    fp32-atomic ordering noise; a step whose scalars differ (another loss weight -> other seeds in the args structs) drops the graph, runs
+    through the list, and is captured again when it repeats."""
+    from transfusion_pytorch_amd import engine
+    cfg, sd, batch, times, noise = build_case('canon512')
+
+    def steps(model, n):
+        outs = []
+        for _ in range(n):
+            for p in model.parameters():
+                p.grad = None
+            loss = model(batch, times=times)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((float(loss), {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None}))
+        return outs
+
+    def fresh():
+        m = build_native(cfg, sd).train()
+        m._noise_override = {t: v.cuda() for t, v in noise.items()}
+        return m
+
+    ref_loss, ref_grads = steps(fresh(), 1)[0]
+    monkeypatch.setattr(engine, 'TRAIN_GRAPH', True)
+    model = fresh()
+    outs = steps(model, 5)
+    plan = model._live[0]
+    st_f, st_b = plan.fwd._auto[(0, len(plan.fwd))], plan.bwd._auto[(0, len(plan.bwd))]
+    assert st_f[1] and st_b[1] and st_f[2] >= 4, 'the fixed-shape loop must end up on graph replays'
+    for i, (l, g) in enumerate(outs):
+        assert abs(l - ref_loss) <= 1e-6 * max(1., abs(ref_loss)), i
+        for k in ref_grads:
+            assert rel(g[k], ref_grads[k]) <= 2e-3, (i, k)
+    # a changed scalar: other loss seeds -> another fingerprint -> list replay, then a new capture
+    model.flow_loss_weight = 2.0 * model.flow_loss_weight
+    l2 = steps(model, 1)[0][0]
+    assert plan.fwd._auto[(0, len(plan.fwd))][1] is None and abs(l2 - ref_loss) > 1e-4
+    l3 = [o[0] for o in steps(model, 3)]
+    assert plan.fwd._auto[(0, len(plan.fwd))][1] and all(abs(x - l2) <= 1e-6 * max(1., abs(l2)) for x in l3)
 
 
 def test_upstream_gradient_scales_seeds_once_and_second_backward_raises():

@@ -3,6 +3,7 @@
 // Host code only; every case forwards to the public entry point of the same name.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstdint>
 #include "../../include/tfx.h"
 
 namespace {
@@ -183,6 +184,64 @@ extern "C" int tfx_graph_launch(void* graph, void* stream) {
 extern "C" int tfx_graph_destroy(void* graph) {
   if (!graph) return 0;
   return (int)hipGraphExecDestroy((hipGraphExec_t)graph);
+}
+
+// ---- fingerprint of a launch list: has anything a capture would freeze changed since the last replay? ----------------------------------
+namespace {
+inline size_t struct_bytes(int op) {
+  switch (op) {
+    case TFX_OP_GEMM_NT: return sizeof(tfx_gemm_nt_args);
+    case TFX_OP_GEMM_TN: return sizeof(tfx_gemm_tn_args);
+    case TFX_OP_ATTN_FWD: case TFX_OP_ATTN_BWD: case TFX_OP_DECODE_ATTN: return sizeof(tfx_attn_args);
+    case TFX_OP_ADALN_PRE_FWD: case TFX_OP_ADALN_PRE_BWD: return sizeof(tfx_adaln_pre_args);
+    case TFX_OP_ADALN_POST_FWD: case TFX_OP_ADALN_POST_BWD: return sizeof(tfx_adaln_post_args);
+    case TFX_OP_QK_NORM_ROPE_FWD: case TFX_OP_QK_NORM_ROPE_BWD: return sizeof(tfx_qk_norm_rope_args);
+    case TFX_OP_ATTNRES_FWD: case TFX_OP_ATTNRES_BWD: return sizeof(tfx_attnres_args);
+    case TFX_OP_RMSNORM_FWD: case TFX_OP_RMSNORM_BWD: return sizeof(tfx_rmsnorm_args);
+    case TFX_OP_EMBED_FWD: case TFX_OP_EMBED_BWD: return sizeof(tfx_embed_args);
+    case TFX_OP_NOISE_MIX: return sizeof(tfx_noise_mix_args);
+    case TFX_OP_FOURIER: return sizeof(tfx_fourier_args);
+    case TFX_OP_CE_FWD_BWD: return sizeof(tfx_ce_args);
+    case TFX_OP_MSE_FWD_BWD: return sizeof(tfx_mse_args);
+    case TFX_OP_CAST_ROWS: case TFX_OP_CAST_ROWS_T: return sizeof(tfx_cast_args);
+    case TFX_OP_ADAM_STEP: return sizeof(tfx_adam_args);
+    default: return op >= TFX_OP_OUTPUT_TO_FLOW ? sizeof(tfx_raw_args) : 0;
+  }
+}
+inline uint64_t mix(uint64_t h, const void* p, size_t n) {           // FNV-1a over 8-byte words (+ tail bytes)
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) { uint64_t w; __builtin_memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ull; }
+  for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+}  // namespace
+extern "C" int tfx_list_fingerprint(const tfx_launch* list, int32_t n, int64_t* out) {
+  if (!out || n < 0 || (n > 0 && !list)) return -1;
+  uint64_t h = 1469598103934665603ull ^ (g_single_stream ? 0x9e3779b97f4a7c15ull : 0ull);
+  for (int32_t i = 0; i < n; ++i) {
+    const tfx_launch& l = list[i];
+    h = mix(h, &l.op, 4); h = mix(h, &l.stream, 4);
+    if (l.op >= TFX_OP_FORK && l.op <= TFX_OP_JOIN_WAIT) continue;
+    if (!l.args) return -2;
+    const size_t nb = struct_bytes(l.op);
+    if (nb == 0) return -100;
+    h = mix(h, l.args, nb);
+    // entry points that take pointers to HOST structs: what they point at is part of the frozen state
+    const tfx_raw_args* r = static_cast<const tfx_raw_args*>(l.args);
+    switch (l.op) {
+      case TFX_OP_ADALN_POST_PRE_FWD: h = mix(h, r->p0, sizeof(tfx_adaln_post_args)); h = mix(h, r->p1, sizeof(tfx_adaln_pre_args)); break;
+      case TFX_OP_LAYER_END_FWD:
+        h = mix(h, r->p0, sizeof(tfx_adaln_post_args)); h = mix(h, r->p1, sizeof(tfx_attnres_args));
+        if (r->p2) h = mix(h, r->p2, sizeof(tfx_adaln_pre_args));
+        break;
+      case TFX_OP_ATTNRES_PULL_BWD: h = mix(h, r->p0, sizeof(tfx_attnres_pull_args)); if (r->p1) h = mix(h, r->p1, sizeof(tfx_adaln_post_args)); break;
+      case TFX_OP_ADALN_PRE_POST_BWD: h = mix(h, r->p0, sizeof(tfx_adaln_pre_args)); h = mix(h, r->p1, sizeof(tfx_adaln_post_args)); break;
+      default: break;
+    }
+  }
+  *out = (int64_t)h;
+  return 0;
 }
 
 extern "C" int tfx_set_single_stream(int32_t on) {

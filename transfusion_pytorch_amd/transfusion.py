@@ -900,7 +900,7 @@ class Transfusion(nn.Module):
         plan.set_ce_vocab(md.vocab)
         self._bwd_scale = None
         plan.acc.zero_()
-        Plan.run(plan.fwd, stream)
+        Plan.run(plan.fwd, stream, graph='auto')
 
         acc = plan.acc
         text_loss = acc[0] / acc[1].clamp(min=1.)
@@ -1400,7 +1400,7 @@ class Transfusion(nn.Module):
         plan.set_ce_vocab(md.vocab)
         self._bwd_scale = None
         plan.acc.zero_()
-        Plan.run(plan.fwd, stream)
+        Plan.run(plan.fwd, stream, graph='auto')
         flow_loss = torch.zeros((), device=dev) if ext else plan.acc[2 + t] / (rows * dl)   # T:2817
         loss = flow_loss
         velocity_loss = None
@@ -1544,17 +1544,17 @@ class Transfusion(nn.Module):
         if red is None or red.defer or not plan.bwd_cuts or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             if red is not None and red.defer:
                 red.check_fresh()                               # (accumulating AFTER a backward that already exchanged would add into summed ranges)
-            Plan.run(plan.bwd, stream)                          # `opt.no_sync()`: accumulate only - the step's last backward exchanges the sums
+            Plan.run(plan.bwd, stream, graph='auto')            # `opt.no_sync()`: accumulate only - the step's last backward exchanges the sums
             return
         # data parallel with overlap: replay the list group by group; a finished group's gradient ranges go out while the rest runs
         red.check_fresh()                                   # one backward per optimizer step (the groups of the previous one are already summed over the ranks)
         red.begin()
         lo = 0
         for idx, first, last in plan.bwd_cuts:
-            Plan.run(plan.bwd, stream, lo, idx)
+            Plan.run(plan.bwd, stream, lo, idx, graph='auto')
             red.group_ready(first, last)
             lo = idx
-        Plan.run(plan.bwd, stream, lo, None)
+        Plan.run(plan.bwd, stream, lo, None, graph='auto')
 
     # ------------------------------------------------------------------ sampling surface (T:1842-2583)
     @torch.no_grad()
