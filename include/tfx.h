@@ -122,6 +122,10 @@ typedef struct {
   tfx_bf16 *dq, *dk, *dv; int32_t ld_dq, ld_dk, ld_dv;
   int32_t order;              /* set by the library (block order of the launch); callers leave it 0 */
   const float* sc_plan;       /* optional, forward and backward: the layer's soft-cap plan (tfx_qk_norm_rope_args.sc_plan); NULL = decide from the scores */
+  /* forward with a KV cache, optional (compacted decode steps): sample s of the launch owns the query rows q_row0[s] .. q_row0[s] + q_cnt[s] - 1 of the
+   * token arrays (q, gate, kv_end, out) instead of rows s * n .. (`n` stays the per-sample maximum and sizes the grid; q_cnt[s] = 0: nothing to do);
+   * keys / values are still the sample's n_kv cache rows.  Device arrays of `b` int32 each; NULL = the dense layout. */
+  const int32_t* q_row0; const int32_t* q_cnt;
 } tfx_attn_args;
 int tfx_attn_fwd(const tfx_attn_args* a, void* stream);
 int tfx_attn_bwd(const tfx_attn_args* a, void* stream);   /* prep + dK/dV kernel + dQ kernel */
@@ -347,10 +351,13 @@ int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, flo
  *   mode 2  second evaluation:           input ym, result y  = y + a f        mode 0  the sample is not inside a modality
  * tfx_ode_stage writes the evaluation inputs into the plan's latent rows: x[(h B + i) Lq + j][c] = input_i[j][c] (h < H halves, j < Lc, c < dl; x: [H B Lq][dl]).
  * tfx_ode_update applies the results: f = pred[i Lq + j] (H == 1) or, with guidance (H == 2, T:2516-2521), pu + cfg_scale (pc - pu) with
- * pc = pred[i Lq + j], pu = pred[(B + i) Lq + j]; samples with sel[i] == 0 are skipped (sel NULL = all: one call per modality type). */
-int tfx_ode_stage(const float* y, const float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, float* x, int32_t H, int32_t Lq, int32_t dl, void* stream);
+ * pc = pred[i Lq + j], pu = pred[(B + i) Lq + j]; samples with sel[i] == 0 are skipped (sel NULL = all: one call per modality type).
+ * rows0 (optional, compacted decode steps): int32 [H B], the first latent row of the block of (half h, sample i) - rows0[h B + i] + j replaces
+ * (h B + i) Lq + j in both kernels; a negative entry = that half carries no block this step (nothing written / read there). */
+int tfx_ode_stage(const float* y, const float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, float* x, int32_t H, int32_t Lq, int32_t dl,
+                  const int32_t* rows0, void* stream);
 int tfx_ode_update(float* y, float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, const float* pred, int32_t H, int32_t Lq, int32_t dl,
-                   float cfg_scale, const float* sel, void* stream);
+                   float cfg_scale, const float* sel, const int32_t* rows0, void* stream);
 
 /* ---- parameter plumbing ---------------------------------------------------------------------- */
 /* dst[r][c] (bf16, ld_dst, Rd rows, Cd cols) = src[rowmap ? rowmap[r] : r][c] or 0 when out of range / map < 0 */

@@ -193,12 +193,21 @@ def test_schedules_and_null_text_cache_forms_agree(monkeypatch):
     monkeypatch.setenv('TFX_SAMPLE_SCHEDULE', 'continuous')
     cont = m.sample_many(prompts, **kw)
     cont_nocfg = m.sample_many(prompts, **{**kw, 'cfg_scale': 1.})
+    # the compacted form of the mixed steps (TFX_DECODE_COMPACT=1): each step carries only the rows its live samples need, two modality types with
+    # blocks of 4 and 9 rows out of step with each other - same samples
+    from transfusion_pytorch_amd import sampling
+    monkeypatch.setattr(sampling, '_COMPACT', True)
+    monkeypatch.setattr(sampling, '_COMPACT_STEP', 64)
+    comp = m.sample_many(prompts, **kw)
+    comp_nocfg = m.sample_many(prompts, **{**kw, 'cfg_scale': 1.})
+    monkeypatch.setattr(sampling, '_COMPACT', False)
     monkeypatch.setenv('TFX_SAMPLE_SCHEDULE', 'phased')
     phased_nocfg = m.sample_many(prompts, **{**kw, 'cfg_scale': 1.})
     n_mod = [sum(isinstance(p, tuple) for p in s) for s in full]
     print('modalities per sample:', n_mod)
     assert max(n_mod) >= 3 and len(set(n_mod)) > 1, 'the test needs samples that pass through several modality phases, out of step with each other'
-    for what, ref, other in (('incremental vs full re-prefill', full, inc), ('continuous vs phased', full, cont), ('continuous vs phased, no guidance', phased_nocfg, cont_nocfg)):
+    for what, ref, other in (('incremental vs full re-prefill', full, inc), ('continuous vs phased', full, cont), ('continuous vs phased, no guidance', phased_nocfg, cont_nocfg),
+                             ('compacted vs dense mixed steps', cont, comp), ('compacted vs dense, no guidance', cont_nocfg, comp_nocfg)):
         worst = 0.
         for a, b in zip(ref, other):
             assert [isinstance(p, tuple) for p in a] == [isinstance(p, tuple) for p in b], what

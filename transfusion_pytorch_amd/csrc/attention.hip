@@ -239,11 +239,12 @@ __global__ __launch_bounds__(256, TFX_ATTN_FWD_WAVES) void attn_fwd_kernel(tfx_a
   __shared__ __attribute__((aligned(1024))) bf16 Ks[2][64 * 64];      // double-buffered LDS-DMA tiles (see swz_f)
   __shared__ __attribute__((aligned(1024))) bf16 Vs[2][64 * 64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
-  const int n = p.n;
-  const BlockId bi = decode_block(p.order, (n + 127) / 128, true);
+  const BlockId bi = decode_block(p.order, (p.n + 127) / 128, true);
   const int h = bi.h, b = bi.b, q0 = bi.tile * 128;
+  const int n = p.q_cnt ? p.q_cnt[b] : p.n;                      // compacted decode steps: this sample's own row count / first row (tfx.h q_row0, q_cnt)
+  if (q0 >= n) return;                                           // (block-uniform: before any barrier)
   const int nkv = p.n_kv > 0 ? p.n_kv : n;                       // KV-cache decode: keys live in a longer per-sample buffer
-  const size_t tok0 = (size_t)b * n, tokk = (size_t)b * nkv;
+  const size_t tok0 = p.q_row0 ? (size_t)p.q_row0[b] : (size_t)b * n, tokk = (size_t)b * nkv;
   const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
   const bf16* kb_ = p.k + tokk * p.ld_k + h * DH;
   const bf16* vb = p.v + tokk * p.ld_v + h * DH;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256, TFX_ATTN_FWD_WAVES) void attn_fwd_kernel(tfx_a
         for (int e = 0; e < 4; e++) v[e] = f2bf(o[db][rg * 4 + e] * sc);
         *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
       }
-    if (hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = __log2f(lsum) * LN2;
+    if (hi == 0) p.lse[((size_t)b * p.h + h) * p.n + qrow] = __log2f(lsum) * LN2;
   }
 }
 
@@ -453,11 +454,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) 
   __shared__ __attribute__((aligned(1024))) bf16 Ks[3][64 * 64];      // rings of LDS-DMA tiles (see swz_f): K(j), K(j+1), K(j+2) / V(j-1), V(j), V(j+1)
   __shared__ __attribute__((aligned(1024))) bf16 Vs[3][64 * 64];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
-  const int n = p.n;
-  const BlockId bi = decode_block(p.order, (n + 127) / 128, true);
+  const BlockId bi = decode_block(p.order, (p.n + 127) / 128, true);
   const int h = bi.h, b = bi.b, q0 = bi.tile * 128;
+  const int n = p.q_cnt ? p.q_cnt[b] : p.n;                      // compacted decode steps (tfx.h q_row0, q_cnt)
+  if (q0 >= n) return;                                           // (block-uniform: before any barrier)
   const int nkv = p.n_kv > 0 ? p.n_kv : n;
-  const size_t tok0 = (size_t)b * n, tokk = (size_t)b * nkv;
+  const size_t tok0 = p.q_row0 ? (size_t)p.q_row0[b] : (size_t)b * n, tokk = (size_t)b * nkv;
   const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
   const bf16* kb_ = p.k + tokk * p.ld_k + h * DH;
   const bf16* vb = p.v + tokk * p.ld_v + h * DH;
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) 
         for (int e = 0; e < 4; e++) ov[db][rg][e] = f2bf(o[db][rg * 4 + e] * sc);
     __syncthreads();                                            // every wave is through with the K / V tiles: their LDS becomes the staging area
     wave_block_store(&Ks[0][0] + w * 2048, ov, p.out + (tok0 + q0 + w * 32) * p.ld_out + h * DH, p.ld_out, n - (q0 + w * 32));
-    if (qrow < n && hi == 0) p.lse[((size_t)b * p.h + h) * n + qrow] = __log2f(ls) * LN2;
+    if (qrow < n && hi == 0) p.lse[((size_t)b * p.h + h) * p.n + qrow] = __log2f(ls) * LN2;
   }
 }
 

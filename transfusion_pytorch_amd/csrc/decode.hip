@@ -58,7 +58,7 @@ __global__ void ode_axpy_k(const float* y, const float* fc, const float* fu, flo
 }
 
 // per-sample solver state machine (tfx.h: tfx_ode_stage / tfx_ode_update): one thread per (sample, row, column < dl)
-__global__ void ode_stage_k(const float* y, const float* ym, const float* ctl, int B, int Lc, int dmax, float* x, int H, int Lq, int dl) {
+__global__ void ode_stage_k(const float* y, const float* ym, const float* ctl, int B, int Lc, int dmax, float* x, int H, int Lq, int dl, const int32_t* rows0) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long long)B * Lc * dl) return;
   const int c = (int)(e % dl), j = (int)((e / dl) % Lc), i = (int)(e / ((long long)dl * Lc));
@@ -66,18 +66,27 @@ __global__ void ode_stage_k(const float* y, const float* ym, const float* ctl, i
   if (mode == 0) return;
   const size_t src = ((size_t)i * Lc + j) * dmax + c;
   const float v = mode == 2 ? ym[src] : y[src];
-  for (int h = 0; h < H; h++) x[((size_t)(h * B + i) * Lq + j) * dl + c] = v;
+  for (int h = 0; h < H; h++) {
+    const int r0 = rows0 ? rows0[h * B + i] : (h * B + i) * Lq;
+    if (r0 >= 0) x[((size_t)r0 + j) * dl + c] = v;
+  }
 }
 
 __global__ void ode_update_k(float* y, float* ym, const float* ctl, int B, int Lc, int dmax, const float* pred, int H, int Lq, int dl, float cfg,
-                             const float* sel) {
+                             const float* sel, const int32_t* rows0) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long long)B * Lc * dl) return;
   const int c = (int)(e % dl), j = (int)((e / dl) % Lc), i = (int)(e / ((long long)dl * Lc));
   const int mode = (int)ctl[i];
   if ((mode != 1 && mode != 2) || (sel && sel[i] == 0.f)) return;
-  float f = pred[((size_t)i * Lq + j) * dl + c];
-  if (H == 2) { const float u = pred[((size_t)(B + i) * Lq + j) * dl + c]; f = u + cfg * (f - u); }
+  const int rc = rows0 ? rows0[i] : i * Lq;
+  if (rc < 0) return;
+  float f = pred[((size_t)rc + j) * dl + c];
+  if (H == 2) {
+    const int ru = rows0 ? rows0[B + i] : (B + i) * Lq;
+    if (ru < 0) return;
+    const float u = pred[((size_t)ru + j) * dl + c]; f = u + cfg * (f - u);
+  }
   const size_t at = ((size_t)i * Lc + j) * dmax + c;
   const float r = y[at] + ctl[B + i] * f;
   if (mode == 1) ym[at] = r; else y[at] = r;
@@ -220,19 +229,20 @@ int tfx_ode_axpy(const float* y, const float* f_cond, const float* f_uncond, flo
   hipLaunchKernelGGL(ode_axpy_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, f_cond, f_uncond, cfg_scale, a, out, (long long)n);
   return (int)hipGetLastError();
 }
-int tfx_ode_stage(const float* y, const float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, float* x, int32_t H, int32_t Lq, int32_t dl, void* s) {
+int tfx_ode_stage(const float* y, const float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, float* x, int32_t H, int32_t Lq, int32_t dl,
+                  const int32_t* rows0, void* s) {
   if (B <= 0 || Lc <= 0 || dl <= 0) return 0;
   if (!y || !ym || !ctl || !x || H < 1 || H > 2 || Lq < Lc || dl > dmax) return -1;
   const long long n = (long long)B * Lc * dl;
-  hipLaunchKernelGGL(ode_stage_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, ym, ctl, B, Lc, dmax, x, H, Lq, dl);
+  hipLaunchKernelGGL(ode_stage_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, ym, ctl, B, Lc, dmax, x, H, Lq, dl, rows0);
   return (int)hipGetLastError();
 }
 int tfx_ode_update(float* y, float* ym, const float* ctl, int32_t B, int32_t Lc, int32_t dmax, const float* pred, int32_t H, int32_t Lq, int32_t dl,
-                   float cfg_scale, const float* sel, void* s) {
+                   float cfg_scale, const float* sel, const int32_t* rows0, void* s) {
   if (B <= 0 || Lc <= 0 || dl <= 0) return 0;
   if (!y || !ym || !ctl || !pred || H < 1 || H > 2 || Lq < Lc || dl > dmax) return -1;
   const long long n = (long long)B * Lc * dl;
-  hipLaunchKernelGGL(ode_update_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, ym, ctl, B, Lc, dmax, pred, H, Lq, dl, cfg_scale, sel);
+  hipLaunchKernelGGL(ode_update_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)s, y, ym, ctl, B, Lc, dmax, pred, H, Lq, dl, cfg_scale, sel, rows0);
   return (int)hipGetLastError();
 }
 int tfx_scale_bf16_copy(const tfx_bf16* src, tfx_bf16* dst, int64_t n, float scale, void* s) {

@@ -190,11 +190,15 @@ class LaunchList(list):
 
 
 class Plan:
-    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None, dp_groups: int = 0, tile_attn: bool = False):
+    def __init__(self, ps: ParamStore, b: int, n: int, I: int, R: dict, training: bool = True, cache=None, dp_groups: int = 0, tile_attn: bool = False, units=None):
         """cache: None, or a KV cache tensor [depth, b, maxlen, 2*heads*64] (k~ | v per token).  With a cache the plan is a
         DECODE step: each layer appends this step's k~ / v rows at `cache_pos` (flat row b*maxlen + position, -1 = skip) and
-        attention reads keys / values from the cache (per-token visible length in `kv_end`)."""
+        attention reads keys / values from the cache (per-token visible length in `kv_end`).
+        units = (samples, max rows per sample): a COMPACTED decode plan - its `b * n` token rows are a flat list in which sample s of `samples`
+        owns the rows unit_row0[s] .. + unit_cnt[s] (device arrays the step fills; 0 rows = the sample sits this step out), so a mixed step of the
+        continuous schedule carries the rows its live samples need instead of (modality length + 1) rows for every sample."""
         md = ps.md
+        self.units = units
         self.cache = cache
         # decode plans: `tile_attn` keeps the tiled forward kernel also for one or two new rows per sample (tfx_decode_attn would pick its
         # matrix-core-free kernel there) - the continuous decode schedule runs a sample's text token in plans of different row counts, and a token
@@ -216,8 +220,11 @@ class Plan:
         # ---- index arrays (filled per step)
         # per-token index arrays: rows of ONE int32 buffer, so that a decode step uploads its five host-built arrays
         # (ids, cache positions, visible lengths, rotary positions, instance ids) with a single pinned, asynchronous copy
-        self.idx = z(7, max(T, 1), dtype=torch.int32)
+        self.idx = z(7, max(T, 1, 4 * units[0] if units else 1), dtype=torch.int32)
         self.text_ids, self.cache_pos, self.kv_end, self.rot_pos, self.tok_inst, self.q_start, self.labels = (self.idx[r, :T] if r != 1 else self.idx[r] for r in range(7))
+        if units:                                                           # per-sample arrays of a compacted decode plan ride in row 6 (a decode plan has no labels)
+            U = units[0]
+            self.unit_row0, self.unit_cnt, self.unit_blk0, self.unit_txt = (self.idx[6, k * U:(k + 1) * U] for k in range(4))
         self.inst_time = z(I1, dtype=torch.float32)
         self.row_tok = {t: z(r, dtype=torch.int32) for t, r in R.items()}
         self.rowbuf = None
@@ -226,7 +233,7 @@ class Plan:
             # uploads them with one copy
             r = next(iter(R.values()))
             self.row_stride = rs = (r + 3) // 4 * 4                       # 16-byte aligned rows
-            self.rowbuf = z(2 * len(R) * rs + 2 * b, dtype=torch.int32)
+            self.rowbuf = z(2 * len(R) * rs + 2 * max(b, units[0] if units else 0), dtype=torch.int32)
             self.row_tok = {t: self.rowbuf[k * rs:k * rs + r] for k, t in enumerate(R)}
             self.ctl = self.rowbuf[2 * len(R) * rs:].view(torch.float32)
         self.row_inst = {t: z(r, dtype=torch.int32) for t, r in R.items()}
@@ -249,8 +256,8 @@ class Plan:
         self.xa = {i: (e(T, d) if training else xa_shared) for i in range(D) if md.has_skip(i)}
         self.stats = e(4, nl, T, dtype=torch.float32)         # mean_a, rstd_a, mean_f, rstd_f
         self.ua = e(nl, T, d); self.uf = e(nl, T, d)
-        self.qkvg = z(nkv, T, ldq); self.qkr = e(nkv, T, 2 * hd); self.og = e(nl, T, hd)
-        self.lse = e(nl, b, md.heads, n, dtype=torch.float32)
+        self.qkvg = z(nkv, T, ldq); self.qkr = e(nkv, T, 2 * hd); self.og = z(nl, T, hd) if units else e(nl, T, hd)       # (compacted plans: padding rows are never written by the attention - keep them finite)
+        self.lse = e(nl, units[0], md.heads, units[1], dtype=torch.float32) if units else e(nl, b, md.heads, n, dtype=torch.float32)
         self.ya = e(nl, T, d); self.xb = e(nl, T, d); self.yf = e(nl, T, d)
         self.ag = e(nl, T, 2 * dip); self.hm = e(nl, T, dip)
         self.embed = e(T, d)
@@ -578,7 +585,9 @@ class Plan:
         li, lkv = self._li(i), self._lkv(i)
         kw = dict(q=self.qkr[lkv], k=_p(self.qkr, lkv) + 2 * hd, v=_p(self.qkvg, lkv) + 2 * 2 * hd, ld_q=2 * hd, ld_k=2 * hd, ld_v=ldq,
                   gate=_p(self.qkvg, lkv) + 2 * 3 * hd, ld_gate=ldq, kv_end=self.kv_end, q_start=self.q_start, out=self.og[li], ld_out=hd,
-                  lse=self.lse[li], b=self.b, h=md.heads, n=self.n, softcap=50.0)
+                  lse=self.lse[li], b=self.units[0] if self.units else self.b, h=md.heads, n=self.units[1] if self.units else self.n, softcap=50.0)
+        if self.units:
+            kw.update(q_row0=self.unit_row0, q_cnt=self.unit_cnt)
         if self.sc_plan is not None:
             kw['sc_plan'] = self.sc_plan[i]
         if self.cache is not None:

@@ -88,6 +88,14 @@ def _ode_axpy(y, f_cond, f_uncond, cfg_scale, a, stream):
     return out
 
 
+# continuous schedule: compacted mixed steps (1) instead of the dense (L + 1)-rows-per-sample layout.  Built, token-identical (tests/test_sampling_gpu.py runs
+# both) - and OFF by default: config 5 measured 1.630 s against 1.646 s (same box).  A decode step's time is flat in its row count between ~256 and 640 rows
+# (tools/bench_decode_step.py: 2.9 - 3.3 ms for 128 samples x 2 / 3 / 5 rows, 2.3 ms at 128 x 1): it is ~225 dependent launches of 6 - 20 us each, set by
+# launch ramps and first-load latencies, not by rows - the rows were never what a step paid for.
+_COMPACT = os.environ.get('TFX_DECODE_COMPACT', '0') == '1'
+_COMPACT_STEP = int(os.environ.get('TFX_DECODE_COMPACT_STEP', '128'))     # row-count bucket of the compacted plans (a plan = buffers + launch list + hipGraph per bucket)
+
+
 class Sampler:
     def __init__(self, model):
         self.m = model
@@ -190,12 +198,12 @@ class Sampler:
         cache[:, :, :n, :hd].copy_(plan.qkr.view(D, B, n, 2 * hd)[..., hd:])
         cache[:, :, :n, hd:].copy_(plan.qkvg.view(D, B, n, ldq)[..., 2 * hd:3 * hd])
 
-    def _decode_plan(self, key, B, Lq, cache, with_latents, n_inst=None, tile_attn=False):
+    def _decode_plan(self, key, B, Lq, cache, with_latents, n_inst=None, tile_attn=False, units=None):
         plans = self.m._decode_plans
         if key not in plans:
             R = {t: B * Lq for t in range(self.m.num_modalities)} if with_latents else {}
             self.m.store.refresh_shadows(self.m._stream())
-            p = Plan(self.m.store, B, Lq, (n_inst or B) if with_latents else 0, R, training=False, cache=cache, tile_attn=tile_attn)
+            p = Plan(self.m.store, B, Lq, (n_inst or B) if with_latents else 0, R, training=False, cache=cache, tile_attn=tile_attn, units=units)
             p.q_start.zero_()
             plans[key] = p
         return plans[key]
@@ -381,36 +389,87 @@ class Sampler:
             if need > joint.shape[2]:
                 joint = self._grow(joint, need + 192)
             cap = joint.shape[2]
-            # one attention kernel - the tiled forward kernel - for every plan of the run: a token's arithmetic must not depend on which plan carried it
-            p = self._decode_plan(('mix' if mixed else 'txt', nb, Lq, joint.data_ptr()), nb, Lq, joint, mixed, n_inst=n_t, tile_attn=True)
-            T = nb * Lq
-            ids = np.zeros((H, B, Lq), np.int32); pos = np.full((H, B, Lq), -1, np.int64); kve = np.ones((H, B, Lq), np.int64)
-            rot = np.zeros((H, B, Lq), np.int64); tok_inst = np.full((H, B, Lq), -1, np.int64)
-            blk_any = np.zeros((H, B, Lq), bool)
-            jj = np.arange(Lq, dtype=np.int64)[None, :]
-            in_blk = jj < A[LL][:, None]                                    # columns a block of this sample's modality length would take
-            for h in range(H):
-                r = (h * B + ar_b)[:, None]
-                base = (A[UL] if h else A[CL])
-                kve[h] = np.maximum(base, 1)[:, None]
-                txt_first = is_m & (A[SP] > 0) if h else np.zeros(B, bool)  # null-text half: the [som] the real history never feeds (T:2411), ahead of the block
-                blk_first = com if h else np.zeros(B, bool)                 # null-text half: the block just decoded, prompt-style (t = 1), ahead of the next token
-                has_blk = (is_m | blk_first)[:, None] & in_blk
-                boff = (base + txt_first)[:, None]
-                pos[h] = np.where(has_blk, r * cap + boff + jj, -1)
-                kve[h] = np.where(has_blk, boff + A[LL][:, None], kve[h])
-                rot[h] = np.where(has_blk, np.where(is_m, A[TS], A[UP])[:, None], 0)          # an ODE block sits at tokens_seen in BOTH halves; a finished one at its history position
-                tok_inst[h] = np.where(has_blk, np.where(is_m, A[OK], n_t - 1)[:, None], -1)   # instance = index of the conditioning time
-                blk_any[h] = has_blk
-                has_txt = is_t | txt_first
-                tbase = base + np.where(blk_first, A[LL], 0)
-                trot = np.where(is_t, (A[UP] + blk_first) if h else A[TS], A[UP])
-                ids[h, :, -1] = np.where(has_txt, m.null_text_id if h else A[LT], 0)
-                pos[h, :, -1] = np.where(has_txt, r[:, 0] * cap + tbase, pos[h, :, -1])
-                kve[h, :, -1] = np.where(has_txt, tbase + 1, kve[h, :, -1])
-                rot[h, :, -1] = np.where(has_txt, trot, rot[h, :, -1])
-            t_1 = time.perf_counter()
-            self._load(p, ids.reshape(-1), pos.reshape(-1), kve.reshape(-1), rot.reshape(-1), tok_inst.reshape(-1))
+            compact = mixed and _COMPACT
+            if compact:
+                # COMPACTED mixed step: the step carries exactly the rows its live samples need - a block's L rows for a sample inside a modality (and for
+                # the null-text twin of a block just finished), one row for a text token / a pending [som] - packed back to back, unit (half h, sample i)
+                # = cache row h B + i owning rows unit_row0 .. + unit_cnt of the plan (Plan `units`; the attention kernel reads its query rows through
+                # them, tfx_attn_args.q_row0 / q_cnt).  The dense layout below spends (L + 1) rows on EVERY sample, done or not: 640 rows per step at
+                # config 5 against ~270 needed.  Plans come in row-count buckets of `_COMPACT_STEP`.
+                U = nb
+                cap_ = cap
+                blk = np.zeros((H, B), bool); txt = np.zeros((H, B), bool)
+                boff = np.zeros((H, B), np.int64); tbase = np.zeros((H, B), np.int64); trot = np.zeros((H, B), np.int64)
+                rblk = np.zeros((H, B), np.int64); iblk = np.zeros((H, B), np.int64); itxt = np.zeros((H, B), np.int64)
+                for h in range(H):
+                    base = (A[UL] if h else A[CL])
+                    txt_first = is_m & (A[SP] > 0) if h else np.zeros(B, bool)
+                    blk_first = com if h else np.zeros(B, bool)
+                    blk[h] = is_m | blk_first
+                    boff[h] = base + txt_first
+                    rblk[h] = np.where(is_m, A[TS], A[UP])
+                    iblk[h] = np.where(is_m, A[OK], n_t - 1)
+                    txt[h] = is_t | txt_first
+                    tbase[h] = base + np.where(blk_first, A[LL], 0)
+                    trot[h] = np.where(is_t, (A[UP] + blk_first) if h else A[TS], A[UP])
+                    itxt[h] = m.null_text_id if h else A[LT]
+                LLu = np.broadcast_to(A[LL], (H, B))
+                nblk = np.where(blk, LLu, 0).reshape(-1)
+                cnt = nblk + txt.reshape(-1)
+                row0 = np.cumsum(cnt) - cnt
+                Ts = int(cnt.sum())
+                Tb = max(_COMPACT_STEP, -(-Ts // _COMPACT_STEP) * _COMPACT_STEP)
+                p = self._decode_plan(('mixc', nb, Tb, Lq, joint.data_ptr()), Tb, 1, joint, True, n_inst=n_t, tile_attn=True, units=(U, Lq))
+                T = Tb
+                u = np.repeat(np.arange(U, dtype=np.int64), cnt)
+                j = np.arange(Ts, dtype=np.int64) - row0[u]
+                isb = j < nblk[u]
+                f = lambda a: a.reshape(-1)[u]
+                ids = np.zeros(Tb, np.int32); pos = np.full(Tb, -1, np.int64); kve = np.ones(Tb, np.int64); rot = np.zeros(Tb, np.int64); tok_inst = np.full(Tb, -1, np.int64)
+                ids[:Ts] = np.where(isb, 0, f(itxt))
+                pos[:Ts] = u * cap_ + np.where(isb, f(boff) + j, f(tbase))
+                kve[:Ts] = np.where(isb, f(boff) + f(LLu), f(tbase) + 1)
+                rot[:Ts] = np.where(isb, f(rblk), f(trot))
+                tok_inst[:Ts] = np.where(isb, f(iblk), -1)
+                blk_rows = np.zeros(Tb, bool); blk_rows[:Ts] = isb
+                row_ty = np.zeros(Tb, np.int64); row_ty[:Ts] = np.broadcast_to(A[TY], (H, B)).reshape(-1)[u]
+                unit_arrays = np.zeros(4 * U, np.int32)
+                unit_arrays[:U] = row0; unit_arrays[U:2 * U] = cnt
+                unit_arrays[2 * U:3 * U] = np.where(blk.reshape(-1), row0, -1)
+                unit_arrays[3 * U:3 * U + B] = np.where(txt[0], row0[:B] + nblk[:B], 0)
+                t_1 = time.perf_counter()
+                self._load(p, ids, pos, kve, rot, tok_inst, units=unit_arrays)
+            else:
+                # one attention kernel - the tiled forward kernel - for every plan of the run: a token's arithmetic must not depend on which plan carried it
+                p = self._decode_plan(('mix' if mixed else 'txt', nb, Lq, joint.data_ptr()), nb, Lq, joint, mixed, n_inst=n_t, tile_attn=True)
+                T = nb * Lq
+                ids = np.zeros((H, B, Lq), np.int32); pos = np.full((H, B, Lq), -1, np.int64); kve = np.ones((H, B, Lq), np.int64)
+                rot = np.zeros((H, B, Lq), np.int64); tok_inst = np.full((H, B, Lq), -1, np.int64)
+                blk_any = np.zeros((H, B, Lq), bool)
+                jj = np.arange(Lq, dtype=np.int64)[None, :]
+                in_blk = jj < A[LL][:, None]                                    # columns a block of this sample's modality length would take
+                for h in range(H):
+                    r = (h * B + ar_b)[:, None]
+                    base = (A[UL] if h else A[CL])
+                    kve[h] = np.maximum(base, 1)[:, None]
+                    txt_first = is_m & (A[SP] > 0) if h else np.zeros(B, bool)  # null-text half: the [som] the real history never feeds (T:2411), ahead of the block
+                    blk_first = com if h else np.zeros(B, bool)                 # null-text half: the block just decoded, prompt-style (t = 1), ahead of the next token
+                    has_blk = (is_m | blk_first)[:, None] & in_blk
+                    boff = (base + txt_first)[:, None]
+                    pos[h] = np.where(has_blk, r * cap + boff + jj, -1)
+                    kve[h] = np.where(has_blk, boff + A[LL][:, None], kve[h])
+                    rot[h] = np.where(has_blk, np.where(is_m, A[TS], A[UP])[:, None], 0)          # an ODE block sits at tokens_seen in BOTH halves; a finished one at its history position
+                    tok_inst[h] = np.where(has_blk, np.where(is_m, A[OK], n_t - 1)[:, None], -1)   # instance = index of the conditioning time
+                    blk_any[h] = has_blk
+                    has_txt = is_t | txt_first
+                    tbase = base + np.where(blk_first, A[LL], 0)
+                    trot = np.where(is_t, (A[UP] + blk_first) if h else A[TS], A[UP])
+                    ids[h, :, -1] = np.where(has_txt, m.null_text_id if h else A[LT], 0)
+                    pos[h, :, -1] = np.where(has_txt, r[:, 0] * cap + tbase, pos[h, :, -1])
+                    kve[h, :, -1] = np.where(has_txt, tbase + 1, kve[h, :, -1])
+                    rot[h, :, -1] = np.where(has_txt, trot, rot[h, :, -1])
+                t_1 = time.perf_counter()
+                self._load(p, ids.reshape(-1), pos.reshape(-1), kve.reshape(-1), rot.reshape(-1), tok_inst.reshape(-1))
             if mixed:
                 if not getattr(p, '_cont_ready', False):
                     for t in range(M):
@@ -424,9 +483,12 @@ class Sampler:
                 hv = hb.numpy()
                 rs = p.row_stride
                 rowidx = np.arange(T, dtype=np.int32)
-                flat_blk = blk_any.reshape(-1)
+                flat_blk = blk_rows if compact else blk_any.reshape(-1)
                 for t in range(M):
-                    mine = flat_blk if M == 1 else (blk_any & (A[TY] == t)[None, :, None]).reshape(-1)
+                    if compact:
+                        mine = flat_blk if M == 1 else flat_blk & (row_ty == t)
+                    else:
+                        mine = flat_blk if M == 1 else (blk_any & (A[TY] == t)[None, :, None]).reshape(-1)
                     hv[t * rs:t * rs + T] = np.where(mine, rowidx, -1)
                     hv[(M + t) * rs:(M + t) * rs + T] = np.where(mine, rowidx, 0)
                 ctl = hv[2 * M * rs:].view(np.float32)
@@ -439,7 +501,7 @@ class Sampler:
                         p.row_inst[t].copy_(p.tok_inst.clamp(min=0))
                 for t in range(M):
                     dl = md.dim_latents[t]
-                    capi.check(lib.tfx_ode_stage(Y.data_ptr(), Ym.data_ptr(), p.ctl.data_ptr(), B, Lc, dmax, p.lat[t]['x'].data_ptr(), H, Lq, dl, sp), 'tfx_ode_stage')
+                    capi.check(lib.tfx_ode_stage(Y.data_ptr(), Ym.data_ptr(), p.ctl.data_ptr(), B, Lc, dmax, p.lat[t]['x'].data_ptr(), H, Lq, dl, p.unit_blk0.data_ptr() if compact else None, sp), 'tfx_ode_stage')
                 for t in p.ext_add:                                         # blocks that carry their axial positional embedding (history-style always, T:3173-3176)
                     add = p.lat[t]['add']
                     add.zero_()
@@ -448,20 +510,20 @@ class Sampler:
                             continue
                         rows = m._pos_rows(t, [states[i].modality_shape])
                         for h in range(H) if is_m[i] else [1]:
-                            lo = (h * B + i) * Lq
+                            lo = int(row0[h * B + i]) if compact else (h * B + i) * Lq
                             add[lo:lo + rows.shape[0]].copy_(rows)
                 self._run(p, stream, 0, p.fwd_cond[0])
                 self._run(p, stream, p.fwd_cond[1], p.fwd_pred_end)
                 for t in range(M):
                     dl = md.dim_latents[t]
                     capi.check(lib.tfx_ode_update(Y.data_ptr(), Ym.data_ptr(), p.ctl.data_ptr(), B, Lc, dmax, p.lat[t]['pred'].data_ptr(), H, Lq, dl,
-                                                  float(cfg_scale), sel[t].data_ptr() if multi else None, sp), 'tfx_ode_update')
+                                                  float(cfg_scale), sel[t].data_ptr() if multi else None, p.unit_blk0.data_ptr() if compact else None, sp), 'tfx_ode_update')
             else:
                 self._run(p, stream, 0, p.fwd_logits_end)
             t_2 = time.perf_counter()
             toks = None
             if is_t.any():
-                lg = p.logits.view(nb, Lq, md.vp)[:B, Lq - 1]
+                lg = p.logits.view(T, md.vp).index_select(0, p.unit_txt[:B]) if compact else p.logits.view(nb, Lq, md.vp)[:B, Lq - 1]
                 toks = _sample_text_token(lg, md.vocab, text_temperature, text_min_p, stream).tolist()      # host sync
                 async_steps = 0
             else:
@@ -710,21 +772,25 @@ class Sampler:
         self.m._decode_plans = {}
         return new
 
-    def _load(self, p, ids, pos, kve, rot, tok_inst):
+    def _load(self, p, ids, pos, kve, rot, tok_inst, units=None):
         """the step's five index arrays go up in ONE pinned, asynchronous copy (rows 0..4 of Plan.idx): no host sync, no pageable staging"""
         T = p.T
         # pinned staging buffers are kept in a small ring (a pinned allocation per step costs more than the step's copy); a text step ends in
         # a host sync, a modality phase issues at most four uploads before one
         ring = self.__dict__.setdefault('_stage', {})
         key = p.idx.shape[1]
+        rows = 5 if units is None else 7                                 # compacted plans: the per-sample arrays ride in row 6 (row 5, q_start, stays zero)
+        key = (rows, key)
         if key not in ring:
-            ring[key] = [[torch.empty(5, key, dtype=torch.int32, pin_memory=True) for _ in range(8)], 0]
+            ring[key] = [[torch.zeros(rows, key[1], dtype=torch.int32, pin_memory=True) for _ in range(8)], 0]
         bufs, k = ring[key]
         ring[key][1] = (k + 1) % len(bufs)
         host = bufs[k]
         hv = host.numpy()
         hv[0, :T], hv[1, :T], hv[2, :T], hv[3, :T], hv[4, :T] = ids, pos, kve, rot, tok_inst
-        p.idx[:5].copy_(host, non_blocking=True)
+        if units is not None:
+            hv[6, :units.size] = units
+        p.idx[:rows].copy_(host, non_blocking=True)
         p.set_rope_tables(*self.m._rope_tables(int(rot.max()) + 1))
 
     def _load_modality(self, p, states, group, Lmax, maxlen, halves=1):
