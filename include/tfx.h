@@ -60,12 +60,16 @@ typedef struct {
    * projection as with TFX_EPI_BF16 (the backward of the norm reads it); C2 (bf16, ldc2 >= 2 qk_heads 64) receives q~ | k~ = QK-RMSNorm + RoPE
    * (+ the q scale) of the first 2 qk_heads 64 columns - exactly what tfx_qk_norm_rope_fwd computes from C, bit for bit, without the launch and
    * without reading q, k back.  The qk_* fields mirror tfx_qk_norm_rope_args (gammas [64], rot_pos [M], cos / sin tables [P, 32], scales, optional
-   * soft-cap plan).  Shapes the 256 x 256 kernel does not take run as the plain projection followed by tfx_qk_norm_rope_fwd inside the call. */
+   * soft-cap plan).  Decode steps: qk_cache (bf16 rows of ld_cache = [k~ (qk_heads 64) | v (qk_heads 64)]) + qk_cache_pos [M] append this step's
+   * k~ and v rows at row qk_cache_pos[m] (< 0: skip) - the KV-cache append of tfx_qk_norm_rope_args.cache in the same epilogue (T:1005-1016).
+   * Fused in the 256 x 256 kernel (training shapes) and in the decode-step kernel (M <= 1024); every other shape runs as the plain projection
+   * followed by tfx_qk_norm_rope_fwd inside the call - same results bit for bit. */
   int32_t qk_heads;
   const float* qk_gamma_q; const float* qk_gamma_k;
   const int32_t* qk_rot_pos; const float* qk_cos; const float* qk_sin;
   float qk_q_scale, qk_norm_scale;
   float* qk_plan; float qk_softcap;
+  tfx_bf16* qk_cache; int32_t qk_ld_cache; const int32_t* qk_cache_pos;
 } tfx_gemm_nt_args;
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
 /* which kernel tfx_gemm_nt would launch for these arguments and on how many blocks, without launching (host logic only, no device needed):

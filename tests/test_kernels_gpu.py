@@ -629,6 +629,53 @@ def test_gemm_nt_fused_qk_norm_rope_epilogue_is_bit_identical(T, H):
     assert (kind.value == 3) == (T > 60000)                        # the large shapes really took the ping-pong kernel (fused), the small one the two launches
 
 
+@pytest.mark.parametrize('T', [640, 600, 130])
+def test_decode_step_qkv_projection_with_fused_norm_rope_and_cache_append_is_bit_identical(T):
+    """decode steps: the [q | k | v | gates] projection on the decode-step GEMM kernel (M <= 1024) with TFX_EPI_QKV_NORM_ROPE + `qk_cache` - q~ | k~, the raw
+    projection AND this step's k~ / v rows in the KV cache (rows `qk_cache_pos`, -1 = skip) - against the plain projection followed by
+    tfx_qk_norm_rope_fwd with its `cache` arguments: everything identical bit for bit, cache rows that are not addressed untouched."""
+    torch.manual_seed(41)
+    d, H = 1024, 8
+    HD = H * 64
+    N = 3 * HD + H; ldq = (N + 63) // 64 * 64
+    u, W = rnd(T, d), rnd(N, d, scale=d ** -0.5)
+    gq = torch.randn(64, device=DEV) * 0.2; gk = torch.randn(64, device=DEV) * 0.2
+    pos = torch.randint(0, 1000, (T,), device=DEV, dtype=torch.int32)
+    freqs = 1. / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(1024).float()[:, None] * freqs[None]
+    cos_t, sin_t = ang.cos().to(DEV).contiguous(), ang.sin().to(DEV).contiguous()
+    rows_cache = 4 * T
+    cpos = torch.randperm(rows_cache, device=DEV)[:T].to(torch.int32)
+    cpos[torch.rand(T, device=DEV) < 0.2] = -1
+    kind, grid = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    pa = capi.make_args('tfx_gemm_nt_args', A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_BF16'], C=torch.empty(T, ldq, device=DEV, dtype=BF), ldc=ldq)
+    capi.lib().tfx_gemm_nt_plan(ctypes.byref(pa), ctypes.byref(kind), ctypes.byref(grid))
+    assert kind.value == 5, 'the shape must run on the decode-step kernel'
+    outs = []
+    for fused in (False, True):
+        C = torch.full((T, ldq), float('nan'), device=DEV, dtype=BF); qk = torch.full((T, 2 * HD), float('nan'), device=DEV, dtype=BF)
+        cache = torch.full((rows_cache, 2 * HD), 7.0, device=DEV, dtype=BF); plan = torch.full((8,), float('nan'), device=DEV)
+        if fused:
+            gemm_nt(A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_QKV_NORM_ROPE'], C=C, ldc=ldq, C2=qk, ldc2=2 * HD, qk_heads=H, qk_gamma_q=gq,
+                    qk_gamma_k=gk, qk_rot_pos=pos, qk_cos=cos_t, qk_sin=sin_t, qk_q_scale=0.125, qk_norm_scale=8.0, qk_plan=plan, qk_softcap=50.0,
+                    qk_cache=cache, qk_ld_cache=2 * HD, qk_cache_pos=cpos)
+        else:
+            gemm_nt(A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_BF16'], C=C, ldc=ldq)
+            a = capi.make_args('tfx_qk_norm_rope_args', T=T, H=H, qkv=C, ld_qkv=ldq, qk=qk, ld_qk=2 * HD, gamma_q=gq, gamma_k=gk, rot_pos=pos, cos_tab=cos_t,
+                               sin_tab=sin_t, q_scale=0.125, norm_scale=8.0, sc_plan=plan, softcap=50.0, cache=cache, ld_cache=2 * HD, cache_pos=cpos)
+            capi.call('tfx_qk_norm_rope_fwd', a, stream())
+        torch.cuda.synchronize()
+        outs.append((C[:, :N].clone(), qk, cache, plan))
+    (C0, qk0, ca0, pl0), (C1, qk1, ca1, pl1) = outs
+    assert torch.isfinite(qk1.float()).all() and torch.isfinite(C1.float()).all()
+    assert torch.equal(C1, C0), 'raw projection'
+    assert torch.equal(qk1, qk0), f'q~ | k~ differ in {(qk1 != qk0).sum().item()} elements'
+    assert torch.equal(ca1, ca0), f'cache differs in {(ca1 != ca0).sum().item()} elements'
+    assert torch.equal(pl1, pl0)
+    live = cpos[cpos >= 0].long()
+    assert (ca1[live] != 7.0).any() and torch.equal(ca1[live][:, HD:], C1[(cpos >= 0)][:, 2 * HD:3 * HD])       # v rows are the raw projection's
+
+
 def test_embed_noise_fourier():
     torch.manual_seed(0)
     T, d, V = 700, 512, 390

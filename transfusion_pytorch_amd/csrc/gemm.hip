@@ -540,6 +540,14 @@ TFX_DEV void staged_epilogue_qknr_(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
 #pragma unroll
     for (int k = 0; k < 2; k++) pos[k] = p.qk_rot_pos[min(row_of(s, k), p.M - 1)];
   };
+  // decode steps: the k~ rows also go to the KV cache (row qk_cache_pos[m]); the positions of all NS half-blocks are fetched up front with the
+  // other side data (a load behind a store waits for the store's round trip)
+  const bool to_cache = p.qk_cache != nullptr && which == 1;      // wave-uniform
+  int cpos[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; s++)
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const int m = row_of(s, k); cpos[s][k] = (to_cache && m < p.M) ? p.qk_cache_pos[m] : -1; }
   auto load_cs = [&](const int (&pos)[2], f32x4 (&cs)[2], f32x4 (&sn)[2]) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -601,12 +609,53 @@ TFX_DEV void staged_epilogue_qknr_(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
         const bf16x8 o = qk_norm_rope_chunk(v[2 * qh + k], rs, which == 0 ? p.qk_q_scale : 1.f, gm, cs[k], sn[k]);
         const int m = row_of(s, k);
         if (!GUARD || m < p.M) *(bf16x8*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n_w + ch * 8) = o;
+        if (to_cache && cpos[s][k] >= 0) *(bf16x8*)((bf16*)p.qk_cache + (size_t)cpos[s][k] * p.qk_ld_cache + (n_w - hd) + ch * 8) = o;
       }
+    }
+  }
+}
+// v columns of a decode step: the raw projection goes to C and, as bf16 rows, to the KV cache behind the k~ columns (tfx_qk_norm_rope_fwd's `cache` path)
+template <int NI>
+TFX_DEV void staged_epilogue_vcache(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+  const int hd = p.qk_heads * 64;
+  const bool col_ok = n_w + ch * 8 < p.N;
+  int cp[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int m = m_w + i * 32 + q * 8 + (l >> 3); cp[i][q] = m < p.M ? p.qk_cache_pos[m] : -1; }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+    bf16* sbuf = st + (i & 1) * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        f32x4 a4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) a4[e] = acc[i][j][4 * g + e];
+        stage_put4(sbuf, r, j * 32 + 8 * g + 4 * hi, a4);
+      }
+    bf16x8 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int row = q * 8 + (l >> 3);
+      v[q] = *(const bf16x8*)(sbuf + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int m = m_w + i * 32 + q * 8 + (l >> 3);
+      if (col_ok && m < p.M) *(bf16x8*)((bf16*)p.C + (size_t)m * p.ldc + n_w + ch * 8) = v[q];
+      if (col_ok && cp[i][q] >= 0) *(bf16x8*)((bf16*)p.qk_cache + (size_t)cp[i][q] * p.qk_ld_cache + (n_w - hd) + ch * 8) = v[q];
     }
   }
 }
 template <int NI>
 TFX_DEV void staged_epilogue_qknr(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
+  const int hd_ = p.qk_heads * 64;
+  if (p.qk_cache && n_w >= 2 * hd_ && n_w + 64 <= 3 * hd_) { staged_epilogue_vcache<NI>(p, acc, m_w, n_w, st); return; }      // v columns of a decode step (wave-uniform)
   if (n_w + 64 > 2 * p.qk_heads * 64) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }      // v / gate columns: the plain staged store (wave-uniform)
   if (m_w + 32 * NI <= p.M) staged_epilogue_qknr_<NI, false>(p, acc, m_w, n_w, st);
   else staged_epilogue_qknr_<NI, true>(p, acc, m_w, n_w, st);
@@ -1198,6 +1247,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_decode_kernel(GemmNT p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  if constexpr (EPI == EPI_QKNR) {                                 // the layer's soft-cap plan (tfx.h), by the first wave of the first block
+    if (p.qk_plan && blockIdx.x == 0 && w == 0) softcap_plan_write(p.qk_gamma_q, p.qk_gamma_k, p.qk_norm_scale, p.qk_q_scale, p.qk_softcap, p.qk_plan);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
   for (int sl = s0; sl < min(s0 + SD_ST - 1, s1); sl++) issue(sl);
   const int swz = ((l & 31) >> 2) & 3;
@@ -1828,13 +1880,24 @@ int gemm_nt_plan(const GemmNT& p, int* kind, int* grid) {
 static bool qknr_fusable(const GemmNT& p) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("TFX_QKNR_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!on || nt_plan(p).kind != NT_PP) return false;
+  const int kind = nt_plan(p).kind;
+  if (!on || (kind != NT_PP && kind != NT_DECODE)) return false;
+  if (kind == NT_PP && p.qk_cache) return false;                  // (the cache append exists in the decode-step kernel's instantiation only)
   const int hd = p.qk_heads * 64;
+  if (p.qk_cache && (!p.qk_cache_pos || (p.qk_ld_cache & 7) || (((uintptr_t)p.qk_cache) & 15) || p.N < 3 * hd)) return false;
   return !p.rowmap && !p.a_rowmap && !p.bias && ((p.ldc | p.ldc2 | p.N) & 7) == 0 && (((uintptr_t)p.C | (uintptr_t)p.C2) & 15) == 0 && 2 * hd <= p.N && p.ldc2 >= 2 * hd;
 }
 static int gemm_nt_qknr(const GemmNT& p, hipStream_t s) {
   if (p.qk_heads <= 0 || !p.C2 || !p.qk_gamma_q || !p.qk_gamma_k || !p.qk_rot_pos || !p.qk_cos || !p.qk_sin) return -5;
-  if (qknr_fusable(p)) { launch_pp<EPI_QKNR>(p, nt_plan(p).grid, s); return (int)hipGetLastError(); }
+  if (qknr_fusable(p)) {
+    const NtPlan pl = nt_plan(p);
+    if (pl.kind == NT_PP) { launch_pp<EPI_QKNR>(p, pl.grid, s); return (int)hipGetLastError(); }
+    static bool attr_sd = false;
+    const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
+    if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI_QKNR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }
+    hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI_QKNR>, dim3(pl.grid), dim3(256), smem_sd, s, p);
+    return (int)hipGetLastError();
+  }
   GemmNT q = p; q.epi = EPI_BF16; q.C2 = nullptr;
   const int rc = launch_nt<EPI_BF16>(q, s);
   if (rc) return rc;
@@ -1843,6 +1906,7 @@ static int gemm_nt_qknr(const GemmNT& p, hipStream_t s) {
   a.T = p.M; a.H = p.qk_heads; a.qkv = (const tfx_bf16*)p.C; a.ld_qkv = p.ldc; a.qk = (tfx_bf16*)p.C2; a.ld_qk = p.ldc2;
   a.gamma_q = p.qk_gamma_q; a.gamma_k = p.qk_gamma_k; a.rot_pos = p.qk_rot_pos; a.cos_tab = p.qk_cos; a.sin_tab = p.qk_sin;
   a.q_scale = p.qk_q_scale; a.norm_scale = p.qk_norm_scale; a.sc_plan = p.qk_plan; a.softcap = p.qk_softcap;
+  a.cache = p.qk_cache; a.ld_cache = p.qk_ld_cache; a.cache_pos = p.qk_cache_pos;
   return tfx_qk_norm_rope_fwd(&a, (void*)s);
 }
 

@@ -427,7 +427,10 @@ class Plan:
                 self._hbm(L, 2, 8 * T)                                  # x in, u out, mean / rstd out
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             plan_kw = dict(sc_plan=self.sc_plan[i], softcap=50.0) if self.sc_plan is not None else {}
-            if self.cache is None and os.environ.get('TFX_QKNR', '0') == '1':
+            # decode plans (round 4): the same epilogue in the decode-step GEMM kernel, with the KV-cache append (`qk_cache`): one launch per layer
+            # less in a step that is nothing but ~225 dependent launches (TFX_DECODE_QKNR=0: the separate token-wise launch, A/B)
+            fuse_qk = (os.environ.get('TFX_QKNR', '0') == '1') if self.cache is None else (os.environ.get('TFX_DECODE_QKNR', '1') != '0')
+            if fuse_qk:
                 # SURVEY K4 (T:946-965): QK-RMSNorm + RoPE ride in the epilogue of the [q | k | v | gates] projection (TFX_EPI_QKV_NORM_ROPE: the raw
                 # projection AND q~ | k~ leave the GEMM; shapes off the 256 x 256 kernel run as two launches inside the call).  Decode plans keep the
                 # token-wise launch: it also appends to the KV cache.  Built, bit-identical (tests/test_kernels_gpu.py) - and OFF by default: the
@@ -436,9 +439,10 @@ class Plan:
                 self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_QKV_NORM_ROPE'], C=self.qkvg[lkv], ldc=ldq,
                          C2=self.qkr[lkv], ldc2=2 * hd, qk_heads=H, qk_gamma_q=gam('q'), qk_gamma_k=gam('k'), qk_rot_pos=self.rot_pos, qk_cos=0, qk_sin=0,
                          qk_q_scale=md.dim_head ** -0.5, qk_norm_scale=md.dim_head ** 0.5,
-                         **({'qk_plan': plan_kw['sc_plan'], 'qk_softcap': 50.0} if plan_kw else {}))
+                         **({'qk_plan': plan_kw['sc_plan'], 'qk_softcap': 50.0} if plan_kw else {}),
+                         **(dict(qk_cache=self.cache[i], qk_ld_cache=2 * hd, qk_cache_pos=self.cache_pos) if self.cache is not None else {}))
                 self._rope_nt_args = getattr(self, '_rope_nt_args', []) + [L[-1][1]]
-                self._k(L, 'tfx_attn_fwd', 'tfx_attn_args', **self._attn_kw(i))
+                self._k(L, 'tfx_attn_fwd' if (self.cache is None or self.tile_attn) else 'tfx_decode_attn', 'tfx_attn_args', **self._attn_kw(i))
             else:
                 self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_BF16'], C=self.qkvg[lkv], ldc=ldq)
                 self._qknr_separate(L, i, li, lkv, gam, plan_kw)
