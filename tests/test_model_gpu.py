@@ -618,6 +618,52 @@ def test_overlapped_gradient_exchange_equals_plain_step_rccl_world1():
             dist.destroy_process_group()
 
 
+def test_training_graphs_under_the_overlapped_exchange_rccl_world1(monkeypatch):
+    """TFX_TRAIN_GRAPH=1 together with the overlapped gradient exchange: the backward list is replayed in segments (one per exchange group), and
+    a segment that ends between a side-stream fork and its join cannot be captured on its own - the capture fails cleanly, that range stays on
+    `tfx_run_list` for good, the others become graphs.  Five identical steps: losses and post-step parameters equal the list replay's."""
+    import torch.distributed as dist
+    from transfusion_pytorch_amd import engine
+    from transfusion_pytorch_amd.optim import FusedAdam
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29543')
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        cfg, sd, batch, times, noise = build_case('canon512')
+        res = []
+        for graphs in (False, True):
+            monkeypatch.setattr(engine, 'TRAIN_GRAPH', graphs)
+            model = build_native(cfg, sd).train()
+            model._noise_override = {t: v.cuda() for t, v in noise.items()}
+            opt = FusedAdam(model, lr=3e-4, max_grad_norm=0.5)
+            opt.always_sync = True
+            opt.overlap_grad_sync(groups=4)
+            losses = []
+            for _ in range(5):
+                loss = model(batch, times=times)
+                loss.backward()
+                opt.step(); opt.zero_grad()
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            plan = model._live[0]
+            if graphs:
+                states = {k: (bool(v[1]), v[2]) for k, v in plan.bwd._auto.items()}
+                print('backward ranges (captured, replays):', states)
+                assert len(states) == len(plan.bwd_cuts) + 1 and plan.fwd._auto[(0, len(plan.fwd))][1]
+            res.append((losses, model.store.flat.clone()))
+        (l0, p0), (l1, p1) = res
+        # (the first step is the same forward: identical; afterwards the two runs drift apart like any two runs of this step do - Adam's first updates
+        #  are +-lr whatever a gradient's size, so the fp32-atomic ordering noise of near-zero gradients moves single weights by 2 lr)
+        assert abs(l0[0] - l1[0]) <= 1e-6 * max(1., abs(l0[0]))
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 5e-4 * max(1., abs(a)), (l0, l1)
+        assert rel(p1, p0) <= 1e-3
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def test_overlapped_exchange_world1_default_gates_and_accumulation_rccl():
     """ `torchrun --nproc-per-node 1`: torch.distributed is initialised at world size 1 and `always_sync` keeps its
     default - the backward still takes the overlapped path, so `step()` must wait for its handles and re-arm the reducer: two consecutive steps
