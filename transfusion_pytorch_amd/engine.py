@@ -199,6 +199,7 @@ class Plan:
         continuous schedule carries the rows its live samples need instead of (modality length + 1) rows for every sample."""
         md = ps.md
         self.units = units
+        assert not units or (cache is not None and tile_attn), 'compacted plans are decode plans on the tiled attention kernel (the row ranges are its arguments)'
         self.cache = cache
         # decode plans: `tile_attn` keeps the tiled forward kernel also for one or two new rows per sample (tfx_decode_attn would pick its
         # matrix-core-free kernel there) - the continuous decode schedule runs a sample's text token in plans of different row counts, and a token
