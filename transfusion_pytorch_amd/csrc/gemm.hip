@@ -542,12 +542,15 @@ TFX_DEV void staged_epilogue_qknr_(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
   };
   // decode steps: the k~ rows also go to the KV cache (row qk_cache_pos[m]); the positions of all NS half-blocks are fetched up front with the
   // other side data (a load behind a store waits for the store's round trip)
-  const bool to_cache = p.qk_cache != nullptr && which == 1;      // wave-uniform
-  int cpos[NS][2];
+  // (NI == 1 = the decode-step kernel's instantiation: the 256 x 256 kernel never appends - qknr_fusable - and has no registers to spare for the positions)
+  const bool to_cache = NI == 1 && p.qk_cache != nullptr && which == 1;      // wave-uniform
+  int cpos[NI == 1 ? NS : 1][2];
+  if constexpr (NI == 1) {
 #pragma unroll
-  for (int s = 0; s < NS; s++)
+    for (int s = 0; s < NS; s++)
 #pragma unroll
-    for (int k = 0; k < 2; k++) { const int m = row_of(s, k); cpos[s][k] = (to_cache && m < p.M) ? p.qk_cache_pos[m] : -1; }
+      for (int k = 0; k < 2; k++) { const int m = row_of(s, k); cpos[s][k] = (to_cache && m < p.M) ? p.qk_cache_pos[m] : -1; }
+  }
   auto load_cs = [&](const int (&pos)[2], f32x4 (&cs)[2], f32x4 (&sn)[2]) {
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -609,7 +612,9 @@ TFX_DEV void staged_epilogue_qknr_(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
         const bf16x8 o = qk_norm_rope_chunk(v[2 * qh + k], rs, which == 0 ? p.qk_q_scale : 1.f, gm, cs[k], sn[k]);
         const int m = row_of(s, k);
         if (!GUARD || m < p.M) *(bf16x8*)((bf16*)p.C2 + (size_t)m * p.ldc2 + n_w + ch * 8) = o;
-        if (to_cache && cpos[s][k] >= 0) *(bf16x8*)((bf16*)p.qk_cache + (size_t)cpos[s][k] * p.qk_ld_cache + (n_w - hd) + ch * 8) = o;
+        if constexpr (NI == 1) {
+          if (to_cache && cpos[s][k] >= 0) *(bf16x8*)((bf16*)p.qk_cache + (size_t)cpos[s][k] * p.qk_ld_cache + (n_w - hd) + ch * 8) = o;
+        }
       }
     }
   }
@@ -655,10 +660,62 @@ TFX_DEV void staged_epilogue_vcache(const GemmNT& p, f32x16 (&acc)[NI][2], int m
 template <int NI>
 TFX_DEV void staged_epilogue_qknr(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
   const int hd_ = p.qk_heads * 64;
-  if (p.qk_cache && n_w >= 2 * hd_ && n_w + 64 <= 3 * hd_) { staged_epilogue_vcache<NI>(p, acc, m_w, n_w, st); return; }      // v columns of a decode step (wave-uniform)
+  if constexpr (NI == 1) {
+    if (p.qk_cache && n_w >= 2 * hd_ && n_w + 64 <= 3 * hd_) { staged_epilogue_vcache<NI>(p, acc, m_w, n_w, st); return; }      // v columns of a decode step (wave-uniform)
+  }
   if (n_w + 64 > 2 * p.qk_heads * 64) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }      // v / gate columns: the plain staged store (wave-uniform)
   if (m_w + 32 * NI <= p.M) staged_epilogue_qknr_<NI, false>(p, acc, m_w, n_w, st);
   else staged_epilogue_qknr_<NI, true>(p, acc, m_w, n_w, st);
+}
+// C(fp32)[mo][n_w .. n_w+63] = acc + bias (the logits / flow-prediction projections): the same staging idea for 4-byte outputs.  The direct form
+// stores 16 bytes per lane in accumulator shape - 32 rows x 32 bytes behind every instruction, 32 cache lines walked one by one (the logits
+// GEMM of the step, 65536 x 448 x 512 with a 117 MB fp32 result, took 195 us: 0.9 TB/s).  Here a 32 x 64 block goes through a wave-private
+// [32][68] fp32 image (272-byte rows: the 16-byte accumulator-shaped writes of rows r and r + 16 share banks, nothing else does) and leaves as
+// 16-byte stores with 16 lanes per 256-byte row segment: 8 lines per instruction.  Needs ldc % 4 == 0, N % 4 == 0, C 16-byte aligned.
+template <int NI>
+TFX_DEV void staged_epilogue_f32(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st_) {
+  float* st = (float*)st_;                                       // 8704 of the wave's 16384 bytes
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, c16 = l & 15;
+  int mo[NI][8];                                               // output row of (block i, flush pass q): row q * 4 + (l >> 4)
+#pragma unroll
+  for (int i = 0; i < NI; i++)
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int m = m_w + i * 32 + q * 4 + (l >> 4);
+      mo[i][q] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
+    }
+  f32x4 bias[2][4];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) bias[j][g] = zero4;
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
+  }
+  asm volatile("" ::: "memory");                               // side loads stay ahead of the first store (one in-order counter)
+  const bool col_ok = n_w + c16 * 4 < p.N;
+#pragma unroll
+  for (int i = 0; i < NI; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] + bias[j][g][e];
+        *(f32x4*)(st + r * 68 + j * 32 + 8 * g + 4 * hi) = v;
+      }
+    f32x4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = *(const f32x4*)(st + (q * 4 + (l >> 4)) * 68 + c16 * 4);
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (col_ok && mo[i][q] >= 0) *(f32x4*)((float*)p.C + (size_t)mo[i][q] * p.ldc + n_w + c16 * 4) = v[q];
+  }
 }
 template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
   bool ok = ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0;
@@ -673,6 +730,8 @@ template <int EPI, int NI>
 TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st, const float* gtab = nullptr, bool use_tab = false) {
   if constexpr (EPI == EPI_BF16) {
     if (can_stage<EPI>(p)) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }
+  } else if constexpr (EPI == EPI_F32) {
+    if (((p.ldc | p.N) & 3) == 0 && (((uintptr_t)p.C) & 15) == 0) { staged_epilogue_f32<NI>(p, acc, m_w, n_w, st); return; }
   } else if constexpr (EPI == EPI_GEGLU || EPI == EPI_GEGLU_BWD) {
     if (can_stage<EPI>(p)) { staged_epilogue_geglu<EPI, NI>(p, acc, m_w, n_w, st, gtab, use_tab); return; }
   } else if constexpr (EPI == EPI_RESID) {
