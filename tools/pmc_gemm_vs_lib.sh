@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of ONE NT shape on the hand-written kernel and on torch.matmul (hipBLASLt), same process: what the library's kernel does differently
 # usage (on the GPU box): bash tools/pmc_gemm_vs_lib.sh <tag> [N K]      -> gpurun_out/<tag>_pmc_gemm_vs_lib.txt
+# (SQ / GRBM counters only: a pass with TA_* / TCC_* / TCP_* counters on this workload did not return within 10 minutes on this pool)
 TAG=${1:-pmc}; N=${2:-512}; K=${3:-2816}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
