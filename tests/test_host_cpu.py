@@ -76,6 +76,49 @@ def _native(cfg):
                        transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads))
 
 
+def test_launch_list_fingerprint_follows_everything_a_capture_freezes():
+    """`tfx_list_fingerprint` (host logic, no device): the hash a training-graph replay is validated with (LaunchList.replay_auto) moves when an args
+    struct field, a positional argument, a host struct behind a two-struct entry point, an op, a stream tag or the single-stream switch changes -
+    and only then."""
+    from transfusion_pytorch_amd.engine import LaunchList, Side
+    lib = capi.lib()
+    L = LaunchList()
+    a = capi.make_args('tfx_gemm_nt_args', M=64, N=128, K=256)
+    post = capi.make_args('tfx_adaln_post_args', T=7, d=64)
+    pre = capi.make_args('tfx_adaln_pre_args', T=7, d=64)
+    live = [16, 32, None, 48, 64, 5, 6, 0.25]
+    L.append(('tfx_gemm_nt', a))
+    L.append(Side(('tfx_gemm_nt', a)))
+    L.append((lib.tfx_output_to_flow, live))
+    L.append((lib.tfx_adaln_post_pre_fwd, (ctypes.addressof(post), ctypes.addressof(pre))))
+    L.append(('tfx_fork', 3))
+    keep = (post, pre)
+
+    def fp(lo=0, hi=None):
+        arr = L.native()
+        out = ctypes.c_int64()
+        hi_ = len(L) if hi is None else hi
+        from transfusion_pytorch_amd.engine import _LAUNCH
+        assert lib.tfx_list_fingerprint(ctypes.byref(arr, lo * ctypes.sizeof(_LAUNCH)), hi_ - lo, ctypes.byref(out)) == 0
+        return out.value
+
+    base = fp()
+    assert fp() == base and fp(0, 2) != base
+    a.M = 65; f1 = fp(); assert f1 != base
+    a.M = 64; assert fp() == base
+    live[7] = 0.5; assert fp() != base                       # a positional (re-packed) argument
+    live[7] = 0.25; assert fp() == base
+    post.T = 8; assert fp() != base                          # a host struct the entry point only points at
+    post.T = 7; assert fp() == base
+    prev = lib.tfx_set_single_stream(1)
+    try:
+        assert fp() != base
+    finally:
+        lib.tfx_set_single_stream(prev)
+    assert fp() == base
+    assert lib.tfx_list_fingerprint(None, 1, ctypes.byref(ctypes.c_int64())) == -1
+
+
 @pytest.mark.parametrize('name', ['tiny1', 'small2', 'mid2', 'head8', 'canon512'])
 def test_packer_matches_reference_layout(name):
     cfg, sd, batch, times, noise = build_case(name)
