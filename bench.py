@@ -1,7 +1,9 @@
 """bench.py - training-step throughput of the native Transfusion hot path on MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...            # N > 1 without a launcher: re-executes itself under torch.distributed.run (one rank per GPU, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --config 3 | --config 4   # BASELINE configs[2] (dim1024/d24, the 8-GPU model) / configs[3] (two modalities, dim768/d16, the 4-GPU model)
 
 Workload (BASELINE.json configs[1]): Transfusion(num_text_tokens=256, dim_latent=384, dim=512, depth=8), per-GPU batch
 64 x packed length 1024 of interleaved text + (4,384) latents (the canonical synthetic sample of SURVEY.md section 8(d)),
@@ -42,6 +44,20 @@ def canonical_batch(b, device, gen, num_text_tokens=256, dim_latent=384, n_inst=
     return batch
 
 
+def two_modality_batch(b, device, gen, num_text_tokens=256, dim_latents=(384, 192), lens=(4, 2), n_inst=32, text_len=25, last_text_len=24):
+    """SURVEY.md section 8(d) config 4 (README.md:59-67 scaled): per sample 32 x [text, (type, latent)] with even instances type 0 = randn(4,384) and odd
+    instances type 1 = randn(2,192); text fillers 25 (last 24) so that the sample packs to 1025 tokens (16 x 8 + 16 x 6 instance tokens + 799 text + sos/eos)."""
+    batch = []
+    for _ in range(b):
+        parts = []
+        for i in range(n_inst):
+            parts.append(torch.randint(0, num_text_tokens, (text_len if i < n_inst - 1 else last_text_len,), device=device, generator=gen))
+            ty = i % 2
+            parts.append((ty, torch.randn(lens[ty], dim_latents[ty], device=device, generator=gen)))
+        batch.append(parts)
+    return batch
+
+
 def ragged_batch(b, device, gen, num_text_tokens=256, dim_latent=384, seed=0):
     """a batch whose STRUCTURE is new: per sample a random number of [text, latent] pairs with random text lengths (latents of 2..6 rows), packed
     lengths between 982 and 1022 tokens incl. [sos] / [eos] (padded to the main workload's 1024 columns) - what a real corpus hands the packer
@@ -65,13 +81,17 @@ def ragged_batch(b, device, gen, num_text_tokens=256, dim_latent=384, seed=0):
     return batch
 
 
-def f_core_per_sample(d=512, D=8, h=8, dh=64, n=1024, n_inst=32, L=4):
+def score_pairs(n=1024, inst_lens=(4,) * 32):
+    """mask-aware (query, key) pairs of one sample: the causal triangle + the in-instance pairs above the diagonal"""
+    return n * (n + 1) / 2 + sum(L * (L - 1) / 2 for L in inst_lens)
+
+
+def f_core_per_sample(d=512, D=8, h=8, dh=64, n=1024, inst_lens=(4,) * 32):
     """F_core = 6 n D (P_attn + P_ff + SDPA) flop / sample, mask-aware SDPA pairs."""
     hd, di = h * dh, int(d * 8 / 3)
     p_attn = d * 2 * hd + d * hd + d * h + hd * d
     p_ff = d * 2 * di + di * d
-    pairs = n * (n + 1) / 2 + n_inst * L * (L - 1) / 2
-    sdpa = 2 * dh * h * (pairs / n)
+    sdpa = 2 * dh * h * (score_pairs(n, inst_lens) / n)
     return 6 * n * D * (p_attn + p_ff + sdpa)
 
 
@@ -113,8 +133,44 @@ def timed_run(orig_run, launches, stream, lo, hi, families, events, attn_flops=0
     orig_run(launches, stream, seg, hi)
 
 
+def cpu_baseline_reference(budget_s=30.0):
+    """the UNMODIFIED reference (TFX_REFERENCE_ROOT, default /root/reference; through oracle/shims for its absent third-party packages) on the host
+    cores of THIS box in THIS run: train_toy.py:50-57's step (fwd + bwd + clip 0.5 + Adam 3e-4) at dim512/depth8 on 4 canonical samples.  Returns
+    None where the reference tree does not exist (the GPU box of this pool: the caller then times the oracle restatement, kind "port")."""
+    from oracle import ref_runner
+    if not ref_runner.reference_available():
+        return None
+    tp = ref_runner.import_reference()
+    threads = min(32, os.cpu_count())
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = tp.Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=512, depth=8), modality_processing='flat')
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+    bs = 4
+    gen = torch.Generator().manual_seed(1234)
+    batch = canonical_batch(bs, 'cpu', gen)
+    def step():
+        loss = model([list(s) for s in batch]); loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5); opt.step(); opt.zero_grad()
+    t0 = time.time(); step(); t1 = time.time() - t0
+    steps, tsum = 0, 0.0
+    while tsum + t1 < budget_s and steps < 3:
+        t0 = time.time(); step(); tsum += time.time() - t0; steps += 1
+    per_step = (tsum / steps) if steps else t1
+    return {'value': bs / per_step, 'unit': 'samples/s', 'cores': threads, 'host_cores': os.cpu_count(), 'kind': 'reference',
+            'sample': f'the unmodified reference ({ref_runner.REF_ROOT}, torch fp32 CPU, modality_processing=flat), dim512/depth8, batch {bs} x 1024 canonical samples, '
+                      f'{"1 warm-up + " + str(steps) + " timed" if steps else "1 timed (cold)"} step(s) of fwd+bwd+clip+Adam; {threads} torch threads of the box\'s {os.cpu_count()}'}
+
+
 def cpu_baseline(budget_s=30.0):
-    """the oracle restatement ("port") on the host cores: 1 train step (fwd+bwd+clip+Adam) on a bounded sample."""
+    """the reference itself where its tree exists on this box (kind "reference"), else the oracle restatement ("port") on the host cores:
+    1 train step (fwd+bwd+clip+Adam) on a bounded sample."""
+    try:
+        r = cpu_baseline_reference(budget_s)
+        if r is not None:
+            return r
+    except Exception as e:
+        print(f'[bench] reference CPU baseline unavailable ({e!r}); timing the oracle restatement', file=sys.stderr)
     from oracle import detdata as D
     from oracle.transfusion_oracle import OracleConfig, train_step
     # 256 torch threads on the GPU box's host oversubscribe badly on these small ops (measured: 469 s / step);
@@ -199,14 +255,36 @@ def bench_sample(args):
     os.write(json_fd, (json.dumps(out) + '\n').encode())
 
 
-CONFIGS = {2: (512, 8), 3: (1024, 24)}          # BASELINE.json configs[1] (the metric's) and configs[2] (the 8-GPU model), single modality type
+# BASELINE.json configs[1] (the metric's), configs[2] (the 8-GPU model) and configs[3] (two modality types, the 4-GPU model); SURVEY.md section 8(d)
+CONFIGS = {2: dict(dim=512, depth=8, two=False), 3: dict(dim=1024, depth=24, two=False), 4: dict(dim=768, depth=16, two=True)}
 
 
-def workload_label(dim, depth, batch, world, use_pg, overlap):
-    cfgname = {(512, 8): 'BASELINE config 2', (1024, 24): 'BASELINE config 3 (per-GPU share of global batch 512 at 8 GPUs)'}.get((dim, depth), 'non-BASELINE dims')
-    return (f'{cfgname}: Transfusion dim={dim} depth={depth} heads=8 dim_head=64 num_text_tokens=256 dim_latent=384; '
-            f'per-GPU batch {batch} x seq 1024 (32 x [24 text tokens + (4,384) latent] per sample); '
-            'step = pack + fwd + bwd + ' + (('grad all-reduce (4 layer groups + tail = 5 collective launches, overlapped with the backward) + '
+def build_model(dim, depth, two, dev=None):
+    """the model of a BASELINE config (README.md:27-35 / :59-67): random init under the caller's seed"""
+    from transfusion_pytorch_amd import Transfusion
+    if two:
+        m = Transfusion(num_text_tokens=256, dim_latent=(384, 192), modality_default_shape=((4,), (2,)), transformer=dict(dim=dim, depth=depth))
+    else:
+        m = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=dim, depth=depth))
+    return m if dev is None else m.to(dev)
+
+
+def make_batch(two, b, dev, gen):
+    return two_modality_batch(b, dev, gen) if two else canonical_batch(b, dev, gen)
+
+
+def inst_lens_of(two):
+    return (4, 2) * 16 if two else (4,) * 32
+
+
+def workload_label(dim, depth, batch, world, use_pg, overlap, two=False):
+    cfgname = {(512, 8, False): 'BASELINE config 2', (1024, 24, False): 'BASELINE config 3 (per-GPU share of global batch 512 at 8 GPUs)',
+               (768, 16, True): 'BASELINE config 4 (two modality types; per-GPU share of the 4-GPU DP run)'}.get((dim, depth, two), 'non-BASELINE dims')
+    sample = ('16 x [25 text + (0, (4,384) latent)] interleaved with 16 x [25 text + (1, (2,192) latent)] per sample' if two
+              else '32 x [24 text tokens + (4,384) latent] per sample')
+    return (f'{cfgname}: Transfusion dim={dim} depth={depth} heads=8 dim_head=64 num_text_tokens=256 dim_latent={"(384,192)" if two else "384"}; '
+            f'per-GPU batch {batch} x seq 1024 ({sample}); '
+            'step = pack + fwd + bwd + ' + (('grad all-reduce (4 layer groups + tail, collective launches overlapped with the backward) + '
                                             if overlap else 'ONE grad all-reduce after the backward + ') if use_pg else '')
             + 'clip(0.5) + Adam(3e-4)' + ('' if use_pg else ' (one GPU: no gradient exchange)'))
 
@@ -258,20 +336,19 @@ def dry_run(args, world, rank, json_fd):
     `value` is null: nothing was computed."""
     import collections
     import torch.distributed as dist
-    from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd.engine import Plan
     from transfusion_pytorch_amd.params import geglu_phys_to_ref_rows
     dev = torch.device('cpu')
     use_pg = dp_setup(world, rank, dev, backend='gloo')
     torch.manual_seed(0)
-    model = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,), transformer=dict(dim=args.dim, depth=args.depth))
+    model = build_model(args.dim, args.depth, args.two)
     opt, overlap = make_optimizer(model, use_pg)
     opt.time_exchange = False                                   # (HIP events)
     ps = model.store
     ps.grad = torch.zeros(ps.numel)
     ps.shadows = collections.defaultdict(lambda: torch.zeros(8, 8, dtype=torch.bfloat16))
     ps._map('geglu', geglu_phys_to_ref_rows(model.md.di, model.md.dip))
-    plan = Plan(ps, b=2, n=64, I=4, R={0: 8}, training=True, dp_groups=getattr(model, '_dp_groups', 0))
+    plan = Plan(ps, b=2, n=64, I=4, R=({0: 8, 1: 4} if args.two else {0: 8}), training=True, dp_groups=getattr(model, '_dp_groups', 0))
     torch.manual_seed(7 + rank)
     same_init = float(ps.flat.double().sum())
     t0 = time.perf_counter()
@@ -298,11 +375,100 @@ def dry_run(args, world, rank, json_fd):
         out = {'metric': f'train samples/sec, dim{args.dim} d{args.depth} seq1024 text+latent', 'value': None, 'unit': 'samples/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                'dry_run': True, 'exchange_ok': ok, 'collective_launches_per_step': opt.reducer.last_launches if overlap else 1,
-               'config': {'workload': workload_label(args.dim, args.depth, args.batch, world, use_pg, overlap), 'global_batch': world * args.batch,
+               'config': {'workload': workload_label(args.dim, args.depth, args.batch, world, use_pg, overlap, args.two), 'global_batch': world * args.batch,
                           'seq_len': 1024, 'parallelism': f'dp{world}'}, 'per_rank_ms_per_step': per_rank}
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_pg:
         dist.destroy_process_group()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks ourselves, the way the reference's examples are started by
+    `accelerate launch` (train_mnist.py:114-126) - one process per GPU under `torch.distributed.run` on 127.0.0.1 with a free port.  The ranks inherit
+    this process's fd 1; rank 0 alone writes the JSON line there (every rank points its own fd 1 at stderr first), so the line arrives on the
+    caller's stdout unchanged.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this pool's hosts (RCCL across processes needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] self-launch:', ' '.join(cmd), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
+def time_other_config(c, dev, batch=64, steps=3, warmup=2):
+    """one BASELINE config behind the timed region of the N = 1 line (`other_configs`): the 8-GPU model (config 3) and the two-modality 4-GPU model
+    (config 4) at their per-GPU batch, full step (pack + fwd + bwd + clip + Adam), `steps` timed steps after `warmup`."""
+    from transfusion_pytorch_amd.optim import FusedAdam
+    cfg = CONFIGS[c]
+    torch.manual_seed(0)
+    m = build_model(cfg['dim'], cfg['depth'], cfg['two'], dev).train()
+    opt = FusedAdam(m, lr=3e-4, max_grad_norm=0.5)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    batches = [make_batch(cfg['two'], batch, dev, gen) for _ in range(2)]
+    def step(k):
+        loss = m(batches[k % 2]); loss.backward(); opt.step(); opt.zero_grad(); return loss
+    for k in range(warmup):
+        step(k)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(steps):
+        loss = step(k)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    f = f_core_per_sample(d=cfg['dim'], D=cfg['depth'], inst_lens=inst_lens_of(cfg['two']))
+    out = {'ms_per_step': dt * 1e3, 'samples_per_s': batch / dt, 'batch': batch, 'steps': steps, 'loss': float(loss.detach()),
+           'model_flops_utilization': batch / dt * f / (PEAK_BF16_TFLOPS * 1e12), 'f_core_gflop_per_sample': f / 1e9,
+           'peak_mem_gib': torch.cuda.max_memory_allocated() / 2**30}
+    del m, opt, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def parity_in_run(dev):
+    """parity measured by THIS process: the `canon512` golden - outputs of the UNMODIFIED reference (fp32 CPU) on two canonical
+    1024-token samples at the metric's model, tests/golden/canon512.pt - against the native step at the BENCH geometry (the two samples 32 times
+    over = b 64 x 1024: the GEMM tilings, split counts and segment grids the timed step ran on).  The oracle package only supplies the case's
+    deterministic inputs here (checker role, after the timed region)."""
+    from oracle.cases import build_case
+    from transfusion_pytorch_amd import Transfusion
+    g = torch.load(os.path.join(ROOT, 'tests', 'golden', 'canon512.pt'), weights_only=False)
+    cfg, sd, batch, times, noise = build_case('canon512')
+    rep = 32
+    m = Transfusion(num_text_tokens=cfg.num_text_tokens, dim_latent=cfg.dim_latents[0],
+                    transformer=dict(dim=cfg.dim, depth=cfg.depth, dim_head=cfg.dim_head, heads=cfg.heads), prob_uncond=0.)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    m._noise_override = {t: v.repeat(rep, 1).to(dev) for t, v in noise.items()}
+    loss, bd = m(batch * rep, times=times.repeat(rep, 1), return_breakdown=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = m._live[0]
+    nt, rs = m._live_n_true, g['row_step']
+    lg = plan.logits.view(plan.b, plan.n, -1)[:, :nt:rs, :cfg.vocab].float().cpu().double()
+    lr = g['logits'].double().repeat(rep, 1, 1)
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    top2 = lr.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 0.05
+    same = lg.argmax(-1) == lr.argmax(-1)
+    num = den = 0.
+    for k, gn in g['grad_norms'].items():
+        go = dict(m.named_parameters())[k].grad.detach().float().cpu()
+        e = rel(go.double(), g['grads'][k].double()) if 'grads' in g else abs(float(go.double().norm()) - gn) / (gn + 1e-30)
+        num += e * gn; den += gn
+    ref = float(g['loss'])
+    out = {'case': 'canon512 golden (unmodified reference, fp32 CPU) x32 = b 64 x 1024, dim512/depth8, measured in this run',
+           'loss_native': float(loss), 'loss_reference': ref, 'loss_rel': abs(float(loss) - ref) / max(1., abs(ref)),
+           'text_loss_delta': abs(float(bd.text) - float(g['text_loss'])), 'flow_loss_delta': abs(float(bd.flow[0]) - float(g['flow_losses'][0])),
+           'logits_rel': rel(lg, lr), 'logits_rel_worst_sample': max(rel(lg[i], lr[i]) for i in range(lg.shape[0])),
+           'argmax_unfiltered': float(same.float().mean()), 'argmax_margin_gt_0p05': float(same[safe].float().mean()), 'margin_gt_0p05_share': float(safe.float().mean()),
+           'grad_mean_rel': num / den, 'gates': {'loss_rel': 1e-3, 'logits_rel': 1e-2, 'argmax_margin_gt_0p05': 1.0}}
+    out['met'] = bool(out['loss_rel'] <= 1e-3 and out['logits_rel'] <= 1e-2 and out['argmax_margin_gt_0p05'] == 1.0)
+    del m
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -311,9 +477,13 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64)
-    ap.add_argument('--dim', type=int, default=512)
-    ap.add_argument('--depth', type=int, default=8)
-    ap.add_argument('--config', type=int, default=0, help='2 = dim512/depth8 (the metric, default), 3 = dim1024/depth24 (BASELINE config 3, the 8-GPU model)')
+    ap.add_argument('--dim', type=int, default=None, help='default: the config\'s (512)')
+    ap.add_argument('--depth', type=int, default=None, help='default: the config\'s (8)')
+    ap.add_argument('--config', type=int, default=0, help='2 = dim512/depth8 (the metric, default), 3 = dim1024/depth24 (BASELINE config 3, the 8-GPU model), '
+                    '4 = two modality types (384,192), dim768/depth16 (BASELINE config 4, the 4-GPU model)')
+    ap.add_argument('--two-modality', dest='two', action='store_true', help='the two-modality sample layout of config 4 at --dim / --depth')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the config 3 / config 4 steps that ride in the N = 1 config-2 line (other_configs)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the in-run parity measurement (parity_met.bench_shape)')
     ap.add_argument('--roofline-kernel', default='tfx_gemm_nt')
     ap.add_argument('--roofline-every', type=int, default=5, help='bracket the roofline kernels with HIP events on every E-th timed step '
                     '(each bracketed launch costs two ~5 us event bubbles: 84 launches = ~0.9 ms on a step)')
@@ -325,16 +495,18 @@ def main():
     ap.add_argument('--ragged-steps', type=int, default=10, help='timed steps of the ragged steady state (every batch a new structure signature); 0 = skip')
     ap.add_argument('--dry-run', action='store_true', help='no GPU: drive the N > 1 host path (gloo) without launching kernels (tests/test_dp_gloo.py)')
     args = ap.parse_args()
-    if args.config:
-        args.dim, args.depth = CONFIGS[args.config]
+    c = CONFIGS[args.config or 2]
+    args.dim, args.depth, args.two = args.dim or c['dim'], args.depth or c['depth'], args.two or c['two']
     if args.sample:
         return bench_sample(args)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1'
+    assert world == args.gpus, f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks'
     # keep stdout for the ONE JSON line: libraries print banners there (RCCL's version block at communicator init), so everything
     # else this process writes to fd 1 goes to stderr
     sys.stdout.flush()
@@ -346,20 +518,18 @@ def main():
     dev = torch.device('cuda', local_rank)
     use_pg = dp_setup(world, rank, dev)
 
-    from transfusion_pytorch_amd import Transfusion
     from transfusion_pytorch_amd import capi
     from transfusion_pytorch_amd.engine import Plan
 
     torch.manual_seed(0)                                      # identical init on every rank (replicas)
-    model = Transfusion(num_text_tokens=256, dim_latent=384, modality_default_shape=(4,),
-                        transformer=dict(dim=args.dim, depth=args.depth)).to(dev).train()
+    model = build_model(args.dim, args.depth, args.two, dev).train()
     opt, overlap = make_optimizer(model, use_pg)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     torch.manual_seed(7 + rank)                               # per-rank noise / times / CFG streams
     # a FRESH batch for every step (train_toy.py:50-52 draws new data each iteration): generated before the timed region (the metric excludes
     # data generation), so no step ever sees token / latent values it has seen before.  The batches share one structure
     # signature (the canonical sample), i.e. the steady state the metric is quoted on; `structure_miss_ms` below prices a new signature.
-    batches = [canonical_batch(args.batch, dev, gen) for _ in range(min(args.steps + args.warmup, 24))]
+    batches = [make_batch(args.two, args.batch, dev, gen) for _ in range(min(args.steps + args.warmup, 24))]
     state = {'k': 0}
 
     def step(batch=None):
@@ -385,8 +555,8 @@ def main():
     orig_run = Plan.run
     sampled = [False]
     families = [{args.roofline_kernel}]
-    n_inst, L_lat, n_tok = 32, 4, 1024
-    attn_flops = 4.0 * 64 * (n_tok * (n_tok + 1) / 2 + n_inst * L_lat * (L_lat - 1) / 2) * args.batch * 8      # per launch: 4 dh pairs per (sample, head), mask-aware
+    inst_lens = inst_lens_of(args.two)
+    attn_flops = 4.0 * 64 * score_pairs(1024, inst_lens) * args.batch * 8      # per launch: 4 dh pairs per (sample, head), mask-aware
     def run(launches, stream_, lo=0, hi=None, graph=False):
         if sampled[0]:
             timed_run(orig_run, launches, stream_, lo, hi, families[0], events, attn_flops)
@@ -487,7 +657,7 @@ def main():
     # segments and index uploads are paid on every step, as on a real corpus; steps are issued back to back (no sync in between), so whatever of
     # that host work hides behind the previous step's GPU work is hidden here too.  Two warm-up steps create the plan of the padded length.
     ragged_ms = None
-    if args.ragged_steps > 0:
+    if args.ragged_steps > 0 and not args.two:
         rb = [ragged_batch(args.batch, dev, gen, seed=1000 * rank + k) for k in range(args.ragged_steps + 2)]
         step(rb[0]); step(rb[1])
         torch.cuda.synchronize(); tr0 = time.perf_counter()
@@ -497,7 +667,7 @@ def main():
         del rb
     # one step on a structure the model has never seen (same packed length, different text / latent placement): host structure scan, index
     # uploads and - at a new padded length - a new plan are paid here and nowhere in `value`
-    miss = canonical_batch(args.batch, dev, gen, text_len=23, last_text_len=54)
+    miss = two_modality_batch(args.batch, dev, gen, text_len=24, last_text_len=55) if args.two else canonical_batch(args.batch, dev, gen, text_len=23, last_text_len=54)
     # the ragged phase above leaves ~50 k dead tensor objects behind; without this collection CPython's generation-2 pass (46 ms on this heap,
     # tools/prof_miss.py) lands inside the one step timed here and is reported as structure work (107 vs 40 ms)
     import gc
@@ -515,14 +685,14 @@ def main():
         kf = sum(f for _, _, f, _, _ in nt_events)
         achieved = kf / kt / 1e12 if kt > 0 else 0.0
         n_launch = len(nt_events)
-        fcore = f_core_per_sample(d=args.dim, D=args.depth)
+        fcore = f_core_per_sample(d=args.dim, D=args.depth, inst_lens=inst_lens)
         # HBM bytes per launch of the roofline kernel family: rocprofv3 PMC passes of this same command, committed under
         # profiles/ (tools/pmc_traffic.sh; FETCH_SIZE x2 gfx950 correction applied there) - counters cannot be read in-process
         traffic, traffic_src = None, None
         pdir = os.path.join(ROOT, 'profiles')
         for tname in ('r04_traffic.json', 'r03_traffic.json'):
             tj = os.path.join(pdir, tname)
-            if os.path.exists(tj) and (args.batch, args.dim, args.depth) == (64, 512, 8):
+            if os.path.exists(tj) and (args.batch, args.dim, args.depth, args.two) == (64, 512, 8, False):
                 tr = json.load(open(tj))
                 if tr.get('kernel_family') == args.roofline_kernel:
                     traffic, traffic_src = tr['bytes_per_launch'], tr['source']
@@ -531,7 +701,7 @@ def main():
             'metric': f'train samples/sec, dim{args.dim} d{args.depth} seq1024 text+latent', 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': workload_label(args.dim, args.depth, args.batch, world, use_pg, overlap),
+            'config': {'workload': workload_label(args.dim, args.depth, args.batch, world, use_pg, overlap, args.two),
                        'global_batch': world * args.batch, 'seq_len': 1024, 'parallelism': f'dp{world}'},
             'loss': float(loss.detach()),
             'model_flops_utilization': value / world * fcore / (PEAK_BF16_TFLOPS * 1e12),
@@ -554,14 +724,37 @@ def main():
             out['roofline_by_family'] = by_family
             out['aggregate_attn_mlp'] = aggregate
             out['step_kernel_time'] = step_gpu_ms
-        pj = os.path.join(pdir, 'r04_parity.json')
-        if os.path.exists(pj):
-            pm = json.load(open(pj))
-            out['parity_met'] = pm
-        if world == 1 and not args.no_sample and (args.batch, args.dim, args.depth) == (64, 512, 8):
-            # SURVEY 8(d) config 5 rides in the same line (outside the timed region): the training model's plans are dropped first
-            model._plans, model._struct_cache = {}, {}
-            torch.cuda.empty_cache()
+        # parity: the suite-wide figures (every golden case, measured by tests/test_model_gpu.py on MI355X and committed under profiles/) are QUOTED;
+        # `bench_shape` is MEASURED by this process on the bench geometry against the reference's golden (parity_in_run)
+        for pname in ('r05_parity.json', 'r04_parity.json'):
+            pj = os.path.join(pdir, pname)
+            if os.path.exists(pj):
+                out['parity_met'] = json.load(open(pj))
+                out['parity_met']['suite_figures_source'] = f'profiles/{pname} (quoted; measured by the GPU test suite)'
+                break
+        is_metric_cfg = (args.batch, args.dim, args.depth, args.two) == (64, 512, 8, False)
+        model._plans, model._struct_cache = {}, {}              # the riders below build their own models: drop the training plans first
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_parity:
+            try:
+                out.setdefault('parity_met', {})['bench_shape'] = parity_in_run(dev)
+                out['parity_met']['bench_shape_source'] = 'measured in this bench.py run (parity_in_run), after the timed region'
+            except Exception as e:                               # a rider never costs the line
+                out.setdefault('parity_met', {})['bench_shape_error'] = repr(e)
+        if world == 1 and not args.no_other_configs and is_metric_cfg:
+            # the 8-GPU model (config 3) and the two-modality 4-GPU model (config 4) at their per-GPU batch, 3 timed steps each, one GPU: the
+            # per-GPU work of those DP runs is exactly this (weak scaling, one all-reduce per step on top)
+            oc = {}
+            for c in (3, 4):
+                try:
+                    r = time_other_config(c, dev)
+                    oc[f'config{c}_b64_ms_per_step'] = r['ms_per_step']
+                    oc[f'config{c}'] = r
+                except Exception as e:
+                    oc[f'config{c}_error'] = repr(e)
+            out['other_configs'] = oc
+        if world == 1 and not args.no_sample and is_metric_cfg:
+            # SURVEY 8(d) config 5 rides in the same line (outside the timed region)
             runs = time_sample_many(dev)
             fx = os.path.join(ROOT, 'tests', 'golden', 'reference_sampling_time.json')
             out['sample_many'] = {'config5_forced_s': runs['config5_forced']['seconds'], 'config5_free_s': runs['config5']['seconds'],

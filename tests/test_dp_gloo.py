@@ -344,8 +344,10 @@ def test_bench_two_rank_host_path_dry_run():
     env = dict(os.environ, PYTHONPATH=ROOT)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    for extra_env, want_launches in ((dict(), 5), (dict(TFX_DP_COALESCE='0'), 10), (dict(TFX_DP_OVERLAP='0'), 1)):
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+    launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port']
+    # the first case is the PLAIN command (`python bench.py --gpus 2 ...`, no launcher): bench.py starts its two ranks itself
+    for extra_env, want_launches, plain in ((dict(), 10, True), (dict(TFX_DP_COALESCE='1'), 5, False), (dict(TFX_DP_OVERLAP='0'), 1, False)):
+        cmd = ([sys.executable] if plain else launcher + [str(port)]) + [
                os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run', '--dim', '128', '--depth', '8']
         r = subprocess.run(cmd, env=dict(env, **extra_env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -359,6 +361,13 @@ def test_bench_two_rank_host_path_dry_run():
     # a driver line at the 8-GPU model's dimensions names BASELINE config 3
     sys.path.insert(0, ROOT)
     import bench
-    lab = bench.workload_label(*bench.CONFIGS[3], 64, 8, True, True)
-    assert 'BASELINE config 3' in lab and 'dim=1024 depth=24' in lab and '5 collective launches' in lab
+    c3 = bench.CONFIGS[3]
+    lab = bench.workload_label(c3['dim'], c3['depth'], 64, 8, True, True, c3['two'])
+    assert 'BASELINE config 3' in lab and 'dim=1024 depth=24' in lab and 'collective launches' in lab
     assert 'BASELINE config 2' in bench.workload_label(512, 8, 64, 1, False, False)
+    # BASELINE config 4 (two modality types, dim768 / depth16) is a named bench configuration: plain command, self-launched, dry run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', '4', '--steps', '2', '--warmup', '1', '--dry-run', '--depth', '2'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['exchange_ok'] and 'dim_latent=(384,192)' in d['config']['workload'] and 'dim=768' in d['config']['workload']

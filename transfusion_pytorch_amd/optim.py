@@ -74,8 +74,8 @@ class GradReducer:
             if async_op:
                 self.handles.append(cm)
         else:
-            # public API only: one all-reduce per range (two collective launches per layer group instead of one).  Selected by TFX_DP_COALESCE=0,
-            # or by itself when this torch build has no `_coalescing_manager` (a private name) - a torch-side change costs an env var, not a run
+            # public API only: one all-reduce per range (two collective launches per layer group instead of one).  THE DEFAULT until a real
+            # multi-rank RCCL run has validated the private `_coalescing_manager` path (TFX_DP_COALESCE=1 selects it)
             for a, b in ranges:
                 h = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
                 if async_op:
@@ -86,7 +86,7 @@ class GradReducer:
 
     @staticmethod
     def _coalesce() -> bool:
-        return os.environ.get('TFX_DP_COALESCE', '1') != '0' and hasattr(dist, '_coalescing_manager')
+        return os.environ.get('TFX_DP_COALESCE', '0') == '1' and hasattr(dist, '_coalescing_manager')
 
     def _unstage(self, ranges, buf):
         g, off = self.model.store.grad, 0
