@@ -42,7 +42,10 @@ enum { TFX_EPI_BF16 = 0, TFX_EPI_F32 = 1, TFX_EPI_SILU = 2, TFX_EPI_RESID = 3, T
  * Optional second A source A2 for k >= K1 (skip-proj concat without the cat copy, T:1214-1219).
  * a_rowmap: gather A rows (row index = a_rowmap[m]); rowmap: scatter output rows (negative = drop).
  * GEGLU layout: physical column c of the 2*dip-wide [value|gate] buffer: block j = c/64, c%64 < 32 is
- * value feature j*32 + c%32, else gate feature j*32 + c%64-32 (weights/bias shadows use the same order). */
+ * value feature j*32 + c%32, else gate feature j*32 + c%64-32 (weights/bias shadows use the same order).
+ * TFX_EPI_GEGLU (FeedForward T:845-853, GEGLU T:831-834): with a | g = acc + bias in that layout, C2 (ldc2 = dip) receives h = a gelu(g) and C (ldc = 2 dip)
+ * receives what the backward needs, in the same layout: u = gelu(g) in the value slots and v = a gelu'(g) in the gate slots (round 5; the round-1..4 form
+ * stored the pre-activations a | g).  TFX_EPI_GEGLU_BWD: acc = dh (N = dip), aux = that saved [u|v]; C (ldc = 2 dip) receives d[a|g] = dh u | dh v. */
 typedef struct {
   const tfx_bf16* A; int32_t lda;
   const tfx_bf16* A2; int32_t lda2; int32_t K1;

@@ -112,6 +112,28 @@ def test_gemm_nt_silu():
     check('gemm_nt silu act', C, F.silu(pre), 6e-3)
 
 
+def gelu_grad(g):
+    """gelu'(g) = Phi(g) + g phi(g) (erf form, F.gelu's derivative)"""
+    return 0.5 * (1 + torch.erf(g * 2 ** -0.5)) + g * torch.exp(-0.5 * g * g) * (2 * torch.pi) ** -0.5
+
+
+def geglu_saved_ref(a, g, is_gate, feat):
+    """what the GEGLU forward saves for its backward (round 5; csrc/tfx_common.h geglu_uvh): u = gelu(g) in the value slots, v = a gelu'(g) in the gate
+    slots of the interleaved buffer"""
+    return torch.where(is_gate[None], (a * gelu_grad(g))[:, feat], F.gelu(g)[:, feat])
+
+
+def geglu_bwd_refs(dh, ag, a, g, is_gate):
+    """(d[a|g] from the SAVED bf16 [u|v]: da = dh u, dg = dh v - the epilogue's own arithmetic;  d[a|g] by autograd from the fp32 pre-activations)"""
+    from_saved = torch.zeros_like(ag, dtype=torch.float32)
+    from_saved[:, ~is_gate] = dh * ag.float()[:, ~is_gate]; from_saved[:, is_gate] = dh * ag.float()[:, is_gate]
+    a_, g_ = a.detach().clone().requires_grad_(True), g.detach().clone().requires_grad_(True)
+    (a_ * F.gelu(g_)).backward(dh)
+    auto = torch.zeros_like(from_saved)
+    auto[:, ~is_gate] = a_.grad; auto[:, is_gate] = g_.grad
+    return from_saved, auto
+
+
 def geglu_perm(dip):
     """physical column c of the interleaved layout -> (is_gate, feature)."""
     c = torch.arange(2 * dip)
@@ -137,8 +159,7 @@ def test_gemm_nt_geglu_fwd_bwd(M):
             C2=hm, ldc2=dip, bias=bphys)
     a = u.float() @ Wa.float().T + ba
     g = u.float() @ Wg.float().T + bg
-    ag_ref = torch.where(is_gate[None], g[:, feat], a[:, feat])
-    check('geglu pre-activation (interleaved)', ag, ag_ref, 6e-3)
+    check('geglu saved [gelu(g) | a gelu\'(g)] (interleaved)', ag, geglu_saved_ref(a, g, is_gate, feat), 6e-3)
     check('geglu hidden', hm, a * F.gelu(g), 8e-3)
     # backward epilogue: dh = dy @ W2t^T (here: plain GEMM against random B), d[a|g] from saved ag
     K2 = 320 if M in (130, 640) else 128
@@ -147,12 +168,9 @@ def test_gemm_nt_geglu_fwd_bwd(M):
     gemm_nt(A=dy, lda=K2, B=W2t, ldb=K2, M=M, N=dip, K=K2, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip,
             aux=ag, ldaux=2 * dip)
     dh = dy.float() @ W2t.float().T
-    a_s, g_s = ag.float()[:, ~is_gate], ag.float()[:, is_gate]     # saved (bf16-rounded) pre-activations, feature order
-    g_s = g_s.requires_grad_(True); a_s = a_s.requires_grad_(True)
-    (a_s * F.gelu(g_s)).backward(dh)
-    dag_ref = torch.zeros(M, 2 * dip, device=DEV)
-    dag_ref[:, ~is_gate] = a_s.grad; dag_ref[:, is_gate] = g_s.grad
-    check('geglu backward epilogue', dag, dag_ref, 8e-3)
+    from_saved, auto = geglu_bwd_refs(dh, ag, a, g, is_gate)
+    check('geglu backward epilogue (from the saved [u|v])', dag, from_saved, 6e-3)
+    check('geglu backward epilogue (autograd of a gelu(g), fp32 pre-activations)', dag, auto, 1e-2)
 
 
 def test_gemm_nt_bench_shapes_resid_skip_geglu():
@@ -180,26 +198,27 @@ def test_gemm_nt_bench_shapes_resid_skip_geglu():
     gemm_nt(A=A, lda=d, B=Wphys, ldb=d, M=M, N=2 * dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU'], C=ag, ldc=2 * dip, C2=hm, ldc2=dip, bias=bphys)
     a = A.float() @ Wa.float().T + ba
     g = A.float() @ Wg.float().T + bg
-    check('bench geglu pre-activation', ag, torch.where(is_gate[None], g[:, feat], a[:, feat]), 6e-3)
+    check('bench geglu saved [u|v]', ag, geglu_saved_ref(a, g, is_gate, feat), 6e-3)
     check('bench geglu hidden', hm, a * F.gelu(g), 8e-3)
-    del a, g
     dy, W2t = rnd(M, d), rnd(dip, d, scale=d ** -0.5)
     dag = torch.full((M, 2 * dip), float('nan'), device=DEV, dtype=BF)
     gemm_nt(A=dy, lda=d, B=W2t, ldb=d, M=M, N=dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip, aux=ag, ldaux=2 * dip)
     dh = dy.float() @ W2t.float().T
-    a_s, g_s = ag.float()[:, ~is_gate].requires_grad_(True), ag.float()[:, is_gate].requires_grad_(True)
-    (a_s * F.gelu(g_s)).backward(dh)
-    dag_ref = torch.zeros(M, 2 * dip, device=DEV)
-    dag_ref[:, ~is_gate] = a_s.grad; dag_ref[:, is_gate] = g_s.grad
-    check('bench geglu backward epilogue', dag, dag_ref, 8e-3)
+    from_saved, auto = geglu_bwd_refs(dh, ag, a, g, is_gate)
+    del a, g
+    check('bench geglu backward epilogue (from the saved [u|v])', dag, from_saved, 6e-3)
+    check('bench geglu backward epilogue (autograd, fp32 pre-activations)', dag, auto, 1e-2)
 
 
 def test_geglu_table_range_ends():
-    """round 4: the ping-pong kernel's GEGLU epilogues look gelu / its derivative up in a 32 KiB LDS table (forward: second-order Taylor on a 2^-7 grid over
-    [-8, 8); backward: indexed by the bits of the saved bf16 gate for 2^-13 <= |g| < 8).  Gate pre-activations pinned (through the bias) far outside,
-    at the ends of and deep inside those ranges - saturated, clamped and tiny - against fp32 torch."""
+    """The ping-pong kernel's GEGLU forward reads gelu AND its derivative from a 32 KiB LDS grid (second-order Taylor on a 2^-7 grid over [-8, 8), linear
+    extrapolation beyond: csrc/gemm.hip geglu_uvh_grid) and saves u = gelu(g), v = a gelu'(g) for the backward, whose epilogue is da = dh u, dg = dh v
+    (round 5; ADVICE r4: the round-4 backward table clamped |g| >= 8 and the test ran on a shape that never took the table kernel).  Gate pre-activations
+    pinned (through the bias) far outside, at the ends of and deep inside the grid - saturated, clamped and tiny - against fp32 torch, per pinned column,
+    on a shape that DOES run the ping-pong kernel (asserted through tfx_gemm_nt_plan)."""
+    import ctypes
     torch.manual_seed(12)
-    M, d, dip = 66000, 128, 128
+    M, d, dip = 65536 + 200, 128, 1408
     u = rnd(M, d)
     Wa, Wg = rnd(dip, d, scale=d ** -0.5), rnd(dip, d, scale=1e-3 * d ** -0.5)
     ba = torch.randn(dip, device=DEV)
@@ -210,28 +229,37 @@ def test_geglu_table_range_ends():
     Wphys = torch.where(is_gate[:, None], Wg[feat], Wa[feat]).contiguous()
     bphys = torch.where(is_gate, bg[feat], ba[feat]).contiguous()
     ag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF); hm = torch.zeros(M, dip, device=DEV, dtype=BF)
-    gemm_nt(A=u, lda=d, B=Wphys, ldb=d, M=M, N=2 * dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU'], C=ag, ldc=2 * dip, C2=hm, ldc2=dip, bias=bphys)
+    kw = dict(A=u, lda=d, B=Wphys, ldb=d, M=M, N=2 * dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU'], C=ag, ldc=2 * dip, C2=hm, ldc2=dip, bias=bphys)
+    kind, grid = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    capi.lib().tfx_gemm_nt_plan(ctypes.byref(capi.make_args('tfx_gemm_nt_args', **kw)), ctypes.byref(kind), ctypes.byref(grid))
+    assert kind.value == 3, 'the shape must run on the ping-pong kernel (the one with the LDS grid)'
+    gemm_nt(**kw)
     a = u.float() @ Wa.float().T + ba
     g = u.float() @ Wg.float().T + bg
-    href = a * F.gelu(g)
-    for c in range(pins.numel()):                                # per pinned column: elementwise, relative to the column's own scale
-        cols = torch.arange(c, dip, pins.numel(), device=DEV)
-        e = (hm[:, cols].float() - href[:, cols]).abs().max().item()
-        sc = href[:, cols].abs().max().item()
-        assert e <= 8e-3 * sc + 1e-30, f'forward, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'
+    saved = torch.zeros(M, 2 * dip, device=DEV)
+    saved[:, ~is_gate] = F.gelu(g); saved[:, is_gate] = a * gelu_grad(g)
+    for nm, got, ref in (('h', hm.float(), a * F.gelu(g)), ('saved u = gelu(g)', ag.float()[:, ~is_gate], F.gelu(g)), ('saved v = a gelu\'(g)', ag.float()[:, is_gate], a * gelu_grad(g))):
+        for c in range(pins.numel()):                            # per pinned column: elementwise, relative to the column's own scale
+            cols = torch.arange(c, dip, pins.numel(), device=DEV)
+            e = (got[:, cols] - ref[:, cols]).abs().max().item()
+            sc = ref[:, cols].abs().max().item()
+            assert e <= 8e-3 * sc + 1e-9, f'forward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'
+    del saved
     dy, W2t = rnd(M, d), rnd(dip, d, scale=d ** -0.5)
     dag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF)
-    gemm_nt(A=dy, lda=d, B=W2t, ldb=d, M=M, N=dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip, aux=ag, ldaux=2 * dip)
+    kwb = dict(A=dy, lda=d, B=W2t, ldb=d, M=M, N=dip, K=d, epi=capi.ENUMS['TFX_EPI_GEGLU_BWD'], C=dag, ldc=2 * dip, aux=ag, ldaux=2 * dip)
+    capi.lib().tfx_gemm_nt_plan(ctypes.byref(capi.make_args('tfx_gemm_nt_args', **kwb)), ctypes.byref(kind), ctypes.byref(grid))
+    assert kind.value == 3
+    gemm_nt(**kwb)
     dh = dy.float() @ W2t.float().T
-    a_s, g_s = ag.float()[:, ~is_gate].requires_grad_(True), ag.float()[:, is_gate].requires_grad_(True)
-    (a_s * F.gelu(g_s)).backward(dh)
+    _, auto = geglu_bwd_refs(dh, ag, a, g, is_gate)
     da, dg = dag.float()[:, ~is_gate], dag.float()[:, is_gate]
     for c in range(pins.numel()):
         cols = torch.arange(c, dip, pins.numel(), device=DEV)
-        for nm, got, ref in (('da', da, a_s.grad), ('dg', dg, g_s.grad)):
+        for nm, got, ref in (('da', da, auto[:, ~is_gate]), ('dg', dg, auto[:, is_gate])):
             e = (got[:, cols] - ref[:, cols]).abs().max().item()
             sc = ref[:, cols].abs().max().item()
-            assert e <= 8e-3 * sc + 1e-30, f'backward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'
+            assert e <= 1.2e-2 * sc + 1e-9, f'backward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'   # two bf16 roundings (saved value, result)
 
 
 # ---------------------------------------------------------------------------------------------- GEMM TN

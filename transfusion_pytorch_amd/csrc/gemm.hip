@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <mutex>
 
 namespace tfx {
 
@@ -74,32 +75,27 @@ template <> struct Epilogue<EPI_RESID> {     // C(bf16) = acc + bias + R
 
 // GEGLU pair epilogues work on the wave's two 32-column halves (value half / gate half of one 64-column
 // interleave block, see tfx_kernels.h "GEGLU layout").
-struct GegluFwd {   // C(bf16, ld 2*dip) = [a|g] pre-activation (+bias) ; C2(bf16, ld dip) = a * gelu(g)
+struct GegluFwd {   // C(bf16, ld 2*dip) = [u|v] = [gelu(g) | a gelu'(g)] (a, g = pre-activation + bias; geglu_uvh) ; C2(bf16, ld dip) = a * gelu(g)
   static TFX_DEV void apply(const GemmNT& p, int m, int n_a, f32x4 a, f32x4 g) {
     // n_a = physical column of the value half inside the interleaved layout (multiple of 4, (n_a % 64) < 32)
     if (p.bias) { a += *(const f32x4*)(p.bias + n_a); g += *(const f32x4*)(p.bias + n_a + 32); }
     bf16* c = (bf16*)p.C + (size_t)m * p.ldc + n_a;
-    store_bf16x4(c, a); store_bf16x4(c + 32, g);
-    f32x4 h; for (int e = 0; e < 4; e++) h[e] = a[e] * gelu_erf(g[e]);
+    f32x4 u, v, h; for (int e = 0; e < 4; e++) { const GegluUVH t_ = geglu_uvh(a[e], g[e]); u[e] = t_.u; v[e] = t_.v; h[e] = t_.h; }
+    store_bf16x4(c, u); store_bf16x4(c + 32, v);
     int feat = (n_a >> 6) * 32 + (n_a & 31);
     store_bf16x4((bf16*)p.C2 + (size_t)m * p.ldc2 + feat, h);
   }
 };
 
-// dh -> d[a|g]:  acc = dh[m][feat..feat+3];  aux = saved [a|g] pre-activation (ld 2*dip)
+// dh -> d[a|g]:  acc = dh[m][feat..feat+3];  aux = the forward's saved [u|v] = [gelu(g) | a gelu'(g)] (ld 2*dip):  da = dh u, dg = dh v
 template <> struct Epilogue<EPI_GEGLU_BWD> {
   static TFX_DEV void apply(const GemmNT& p, int m, int mo, int n, f32x4 dh) {
     if (n >= p.N) return;                       // N (= dip) is a multiple of 64
     int col = (n >> 5) * 64 + (n & 31);
     const bf16* ag = p.aux + (size_t)m * p.ldaux + col;
-    bf16x4 a4 = *(const bf16x4*)ag, g4 = *(const bf16x4*)(ag + 32);
+    bf16x4 u4 = *(const bf16x4*)ag, v4 = *(const bf16x4*)(ag + 32);
     f32x4 da, dg;
-    for (int e = 0; e < 4; e++) {
-      const float a = bf2f(a4[e]), g = bf2f(g4[e]);
-      float E; const float cdf = gelu_cdf(g, E);                                    // one exponential serves Phi and phi
-      da[e] = dh[e] * g * cdf;
-      dg[e] = dh[e] * a * (cdf + g * 0.39894228040143267794f * E);
-    }
+    for (int e = 0; e < 4; e++) { da[e] = dh[e] * bf2f(u4[e]); dg[e] = dh[e] * bf2f(v4[e]); }
     bf16* c = (bf16*)p.C + (size_t)mo * p.ldc + col;
     store_bf16x4(c, da); store_bf16x4(c + 32, dg);
   }
@@ -168,10 +164,10 @@ TFX_DEV void fast_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         if (n_w + 8 * g + 4 * hi >= p.N) continue;
-        f32x4 a, gt, h;
+        f32x4 u, v, h;
 #pragma unroll
-        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e] + bias[0][g][e]; gt[e] = acc[i][1][4 * g + e] + bias[1][g][e]; h[e] = a[e] * gelu_erf(gt[e]); }
-        store_bf16x4(c + 8 * g, a); store_bf16x4(c + 32 + 8 * g, gt); store_bf16x4(c2 + 8 * g, h);
+        for (int e = 0; e < 4; e++) { const GegluUVH t_ = geglu_uvh(acc[i][0][4 * g + e] + bias[0][g][e], acc[i][1][4 * g + e] + bias[1][g][e]); u[e] = t_.u; v[e] = t_.v; h[e] = t_.h; }
+        store_bf16x4(c + 8 * g, u); store_bf16x4(c + 32 + 8 * g, v); store_bf16x4(c2 + 8 * g, h);
       }
     } else if constexpr (EPI == EPI_GEGLU_BWD) {
       bf16* c = (bf16*)p.C + (size_t)mo[i] * p.ldc + (n_w >> 5) * 64 + 4 * hi;
@@ -182,11 +178,10 @@ TFX_DEV void fast_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n
         for (int g = 0; g < 4; g++) {
           f32x4 da, dg;
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const float dh = acc[i][j][4 * g + e], a = bf2f(in.a[j][g][e]), gg = bf2f(in.g[j][g][e]);
-            float E; const float cdf = gelu_cdf(gg, E);                                   // one exponential serves Phi and phi
-            da[e] = dh * gg * cdf;
-            dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * E);
+          for (int e = 0; e < 4; e++) {                        // in.a / in.g hold the saved u = gelu(g) / v = a gelu'(g)
+            const float dh = acc[i][j][4 * g + e];
+            da[e] = dh * bf2f(in.a[j][g][e]);
+            dg[e] = dh * bf2f(in.g[j][g][e]);
           }
           store_bf16x4(c + j * 64 + 8 * g, da); store_bf16x4(c + j * 64 + 32 + 8 * g, dg);
         }
@@ -370,20 +365,9 @@ TFX_DEV void stage_put4_32(bf16* st, int row, int col, f32x4 v) {
 // GEGLU forward / backward with staged stores.  Forward: per 32-row block one [a|g] block (32x64) and one h block (32x32).
 // Backward: per 32-row block two [da|dg] blocks (one per 32 dh columns).  The saved-activation loads of the backward stay
 // per-lane 8-byte loads, issued one block ahead of their use (see fast_epilogue).
-// GELU table of the backward epilogue (ping-pong kernel).  The saved gate pre-activation g is a bf16 VALUE: gelu(g) = g Phi(g) and gelu'(g) = Phi(g) +
-// g phi(g) are functions of 16 bits, so the epilogue looks them up instead of evaluating an exponential, a reciprocal and a degree-5 polynomial per
-// element (~14 VALU issue slots of ~25 per element: at 128 elements per lane the GEGLU-backward epilogue took as long as the K = 512 loop it
-// follows - the kernel ran at 2.6 TB/s / 12 % of the MFMA roof, bound by neither).  4096 entries x {gelu, gelu'} fp32 = 32 KiB - exactly what the
-// 128 KiB operand ring leaves of the CU's 160 KiB - indexed by sign | (biased exponent - 114) | mantissa, i.e. every bf16 with 2^-13 <= |g| < 8;
-// smaller magnitudes clamp to the +-2^-13 entry (|error| <= 1.2e-4 x |g| on gelu, 2e-4 on gelu': below the bf16 output rounding), larger
-// ones to +-7.97 (Phi = 0 / 1 to 1e-15).  Entries are computed in double precision on the host: inside the range the result is the correctly
-// rounded function of the saved g, closer to the reference's erf than the polynomial it replaces.
-constexpr int GTAB_LO = 114 << 7, GTAB_HI = (130 << 7) - 1, GTAB_N = 4096;
-TFX_DEV f32x2_t gtab_lookup(const float* gtab, uint32_t bits16) {
-  const uint32_t mag = min(max(bits16 & 0x7fffu, (uint32_t)GTAB_LO), (uint32_t)GTAB_HI);
-  const uint32_t idx = mag - GTAB_LO + ((bits16 >> 15) << 11);
-  return *(const f32x2_t*)(gtab + 2 * idx);
-}
+// (Round 4 kept a second 32 KiB table here, indexed by the bits of the saved bf16 gate, for the backward epilogue; round 5 saves u = gelu(g) and
+// v = a gelu'(g) in the forward instead - geglu_uvh, tfx_common.h - so the backward epilogue has no function left to evaluate.)
+constexpr int GTAB_N = 4096;                                      // floats x 2: the forward grid's 32 KiB
 // Forward: g is an fp32 accumulator, so the table is a uniform GRID over g (step 2^-7 on [-8, 8): 2048 entries x {gelu, h gelu', h^2 gelu''/2, pad} = 32 KiB)
 // and gelu(g) is its second-order Taylor polynomial around the nearest node: |error| <= (2^-8)^3 |d3 gelu| / 6 < 1e-8, also relative to gelu near 0
 // (node 0 carries 0.5 g + 0.399 g^2 exactly); beyond +-8 the clamped end nodes extrapolate linearly to g / to 0.  6 index + 3 arithmetic VALU slots
@@ -394,6 +378,19 @@ TFX_DEV float gelu_grid(const float* gtab, float g) {
   const float d = x - xr;
   const f32x4 c = *(const f32x4*)(gtab + 4 * ((int)xr + 1024));
   return fmaf(fmaf(c[2], d, c[1]), d, c[0]);
+}
+// geglu_uvh on the grid: u = the polynomial above; gelu'(g) = its derivative (c1 + 2 c2 d) / h - first order around the node, |error| <= (2^-8)^2 max|d3 gelu| / 2
+// < 7e-6, three orders below the bf16 rounding of v; beyond +-8 the end nodes give gelu' = 1 / 0.  3 VALU slots more than gelu_grid.
+TFX_DEV GegluUVH geglu_uvh_grid(const float* gtab, float a, float g) {
+  const float x = g * 128.f;
+  const float xr = __builtin_amdgcn_fmed3f(__builtin_rintf(x), -1024.f, 1023.f);
+  const float d = x - xr;
+  const f32x4 c = *(const f32x4*)(gtab + 4 * ((int)xr + 1024));
+  const float t = fmaf(c[2], d, c[1]);
+  GegluUVH r; r.u = fmaf(t, d, c[0]);
+  r.h = a * r.u;
+  r.v = (a * 128.f) * fmaf(c[2], d, t);
+  return r;
 }
 template <int EPI, int NI>
 TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st, const float* gtab = nullptr, bool use_tab = false) {
@@ -433,17 +430,15 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const int nl = 8 * g + 4 * hi;
-        f32x4 a, gt, h;
+        f32x4 u, v, h;                                           // saved for the backward: u = gelu(g), v = a gelu'(g) (geglu_uvh)
+        if (use_tab) {                                           // (block-uniform) table form, see geglu_uvh_grid
 #pragma unroll
-        for (int e = 0; e < 4; e++) { a[e] = acc[i][0][4 * g + e] + ba[g][e]; gt[e] = acc[i][1][4 * g + e] + bg[g][e]; }
-        if (use_tab) {                                           // (block-uniform) table form, see gelu_grid
-#pragma unroll
-          for (int e = 0; e < 4; e++) h[e] = a[e] * gelu_grid(gtab, gt[e]);
+          for (int e = 0; e < 4; e++) { const GegluUVH t_ = geglu_uvh_grid(gtab, acc[i][0][4 * g + e] + ba[g][e], acc[i][1][4 * g + e] + bg[g][e]); u[e] = t_.u; v[e] = t_.v; h[e] = t_.h; }
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; e++) h[e] = a[e] * gelu_erf(gt[e]);
+          for (int e = 0; e < 4; e++) { const GegluUVH t_ = geglu_uvh(acc[i][0][4 * g + e] + ba[g][e], acc[i][1][4 * g + e] + bg[g][e]); u[e] = t_.u; v[e] = t_.v; h[e] = t_.h; }
         }
-        stage_put4(s, r, nl, a); stage_put4(s, r, 32 + nl, gt); stage_put4_32(s + 2048, r, nl, h);
+        stage_put4(s, r, nl, u); stage_put4(s, r, 32 + nl, v); stage_put4_32(s + 2048, r, nl, h);
       }
       flush64(s, i, n_w, p.N);
       bf16x8 hv[2];
@@ -486,28 +481,14 @@ TFX_DEV void staged_epilogue_geglu(const GemmNT& p, f32x16 (&acc)[NI][2], int m_
       for (int j = 0; j < 2; j++) {
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-          const bf16x4 a4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + g) ^ (r & 15)) << 3) + 4 * hi);
-          const bf16x4 g4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + 4 + g) ^ (r & 15)) << 3) + 4 * hi);
+          const bf16x4 u4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + g) ^ (r & 15)) << 3) + 4 * hi);          // saved u = gelu(g)
+          const bf16x4 v4 = *(const bf16x4*)(sag + r * 128 + (((j * 8 + 4 + g) ^ (r & 15)) << 3) + 4 * hi);      // saved v = a gelu'(g)
           f32x4 da, dg;
-          if (use_tab) {                                                                  // (block-uniform) table form, see gtab_lookup
-            const u32x2 gb = __builtin_bit_cast(u32x2, g4);
-            f32x2_t t[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) t[e] = gtab_lookup(gtab, (e & 1) ? (gb[e >> 1] >> 16) : (gb[e >> 1] & 0xffffu));
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              const float dh = acc[i][j][4 * g + e];
-              da[e] = dh * t[e][0];
-              dg[e] = dh * bf2f(a4[e]) * t[e][1];
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              const float dh = acc[i][j][4 * g + e], a = bf2f(a4[e]), gg = bf2f(g4[e]);
-              float E; const float cdf = gelu_cdf(gg, E);                                   // one exponential serves Phi and phi
-              da[e] = dh * gg * cdf;
-              dg[e] = dh * a * (cdf + gg * 0.39894228040143267794f * E);
-            }
+          for (int e = 0; e < 4; e++) {
+            const float dh = acc[i][j][4 * g + e];
+            da[e] = dh * bf2f(u4[e]);
+            dg[e] = dh * bf2f(v4[e]);
           }
           stage_put4(st, r, 8 * g + 4 * hi, da); stage_put4(st, r, 32 + 8 * g + 4 * hi, dg);
         }
@@ -1483,13 +1464,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 #endif
   PP_STAMP(0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // retire the row-map loads before the counted waits
-  // GEGLU forward / backward: the 32 KiB GELU table (gelu_grid / gtab_lookup) goes into the LDS the operand ring leaves free, 4 KiB per wave, issued AHEAD of the first
+  // GEGLU forward: the 32 KiB GELU table (geglu_uvh_grid) goes into the LDS the operand ring leaves free, 4 KiB per wave, issued AHEAD of the first
   // K-tile - the DMAs retire in order, so the prologue's wait for K-tile 0 covers the table as well
   if constexpr (EPI == EPI_QKNR) {                                 // the layer's soft-cap plan (tfx.h), by the first wave of the first block
     if (p.qk_plan && blockIdx.x == 0 && w == 0) softcap_plan_write(p.qk_gamma_q, p.qk_gamma_k, p.qk_norm_scale, p.qk_q_scale, p.qk_softcap, p.qk_plan);
   }
   const float* gtab_lds = (const float*)(smem_raw + 8 * HALF * 2);  // (only dereferenced when the launch reserved it: gtab != nullptr)
-  if constexpr (EPI == EPI_GEGLU_BWD || EPI == EPI_GEGLU) {
+  if constexpr (EPI == EPI_GEGLU) {
     if (gtab) {                                                   // kernel argument: block-uniform
 #pragma unroll
       for (int j = 0; j < 4; j++) glds16_asm((const bf16*)gtab + (size_t)(w * 4 + j) * 512 + l * 8, (const bf16*)gtab_lds + (w * 4 + j) * 512);
@@ -1562,7 +1543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 #undef PP_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();
   PP_STAMP(2)
-  nt_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 8192, gtab_lds, (EPI == EPI_GEGLU_BWD || EPI == EPI_GEGLU) && gtab != nullptr);   // all of the ring is free after the last barrier: 16 KiB per wave
+  nt_epilogue<EPI, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + w * 8192, gtab_lds, EPI == EPI_GEGLU && gtab != nullptr);   // all of the ring is free after the last barrier: 16 KiB per wave
   PP_STAMP(3)
 #ifdef TFX_PP_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1829,44 +1810,46 @@ static bool use_glds() {             // TFX_GEMM_GLDS=0 forces the register-stag
 //   0 register-staged fallback: N % 4 != 0 (the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups) or TFX_GEMM_GLDS=0
 enum { NT_FALLBACK = 0, NT_GLDS = 1, NT_MID = 2, NT_PP = 3, NT_SKINNY = 4, NT_DECODE = 5 };
 
-// device copy of the GELU table of the GEGLU-backward epilogue (gtab_lookup): built once per process and device in double precision.
-// TFX_GELU_TABLE = bit mask (1 forward, 2 backward; default 3), 0 keeps the polynomial form (A/B, tests).  Returns nullptr when disabled or when the allocation fails (the epilogue then
-// evaluates the polynomial: same results to ~1e-7).
-static const float* gelu_table(int kind) {           // kind 1: backward, indexed by the bits of the saved bf16 g (gtab_lookup); kind 0: forward grid (gelu_grid)
-  static const float* tab[2][16] = {{nullptr}};
-  static bool tried[2][16] = {{false}};
+// device copy of the GELU grid of the GEGLU-forward epilogue (geglu_uvh_grid): built once per process and device in double precision.
+// TFX_GELU_TABLE=0 keeps the polynomial form (A/B, tests).  Returns nullptr when disabled or when the allocation fails (the epilogue then evaluates the
+// polynomial: same results to ~1e-7).  Guarded by a mutex: two host threads (or two devices driven from one process) may reach the first launch together.
+static const float* gelu_table() {
+  static const float* tab[16] = {nullptr};
+  static bool tried[16] = {false};
+  static std::mutex mu;
   static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("TFX_GELU_TABLE"); enabled = e ? atoi(e) : 3; }     // bit 0: forward, bit 1: backward
-  if (!((enabled >> kind) & 1)) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (enabled < 0) { const char* e = getenv("TFX_GELU_TABLE"); enabled = e ? atoi(e) : 1; }
+  if (!(enabled & 1)) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!tried[kind][dev]) {
-    tried[kind][dev] = true;
+  if (!tried[dev]) {
+    tried[dev] = true;
     std::vector<float> h(2 * GTAB_N);
     auto Phi = [](double g) { return 0.5 * erfc(-g * 0.70710678118654752440); };
     auto phi = [](double g) { return 0.39894228040143267794 * exp(-0.5 * g * g); };
-    if (kind == 1) {
-      for (int i = 0; i < GTAB_N; i++) {
-        const uint32_t bits = ((uint32_t)(i >> 11) << 15) | (uint32_t)(GTAB_LO + (i & 2047));
-        const uint32_t f32 = bits << 16;
-        float gf; memcpy(&gf, &f32, 4);
-        const double g = gf;
-        h[2 * i] = (float)(g * Phi(g)); h[2 * i + 1] = (float)(Phi(g) + g * phi(g));
-      }
-    } else {
-      const double st = 1.0 / 128.0;
-      for (int i = 0; i < 2048; i++) {
-        const double g = (i - 1024) * st;
-        h[4 * i] = (float)(g * Phi(g));                                   // gelu
-        h[4 * i + 1] = (float)((Phi(g) + g * phi(g)) * st);               // h x first derivative
-        h[4 * i + 2] = (float)(0.5 * phi(g) * (2.0 - g * g) * st * st);   // h^2 x half the second derivative (= phi (2 - g^2))
-        h[4 * i + 3] = 0.f;
-      }
+    const double st = 1.0 / 128.0;
+    for (int i = 0; i < 2048; i++) {
+      const double g = (i - 1024) * st;
+      h[4 * i] = (float)(g * Phi(g));                                   // gelu
+      h[4 * i + 1] = (float)((Phi(g) + g * phi(g)) * st);               // h x first derivative
+      h[4 * i + 2] = (float)(0.5 * phi(g) * (2.0 - g * g) * st * st);   // h^2 x half the second derivative (= phi (2 - g^2))
+      h[4 * i + 3] = 0.f;
     }
     float* d = nullptr;
-    if (hipMalloc(&d, h.size() * 4) == hipSuccess && hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess) tab[kind][dev] = d;
+    if (hipMalloc(&d, h.size() * 4) == hipSuccess && hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess) tab[dev] = d;
   }
-  return tab[kind][dev];
+  return tab[dev];
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one flag bit per device (a process may drive several), set under a lock
+// so that a second host thread cannot launch between another thread's flag write and its attribute call.
+static void ensure_smem_attr(const void* fn, int bytes, uint32_t& done_mask) {
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint32_t bit = 1u << (dev & 31);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!(done_mask & bit)) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done_mask |= bit; }
 }
 struct NtPlan { int kind, grid; };
 static NtPlan nt_plan(const GemmNT& p) {
@@ -1887,10 +1870,10 @@ static NtPlan nt_plan(const GemmNT& p) {
 }
 
 template <int EPI> static void launch_pp(const GemmNT& p, int grid, hipStream_t s) {
-  static bool attr_pp = false;
-  const float* gtab = EPI == EPI_GEGLU_BWD ? gelu_table(1) : EPI == EPI_GEGLU ? gelu_table(0) : nullptr;
+  static uint32_t attr_pp = 0;
+  const float* gtab = EPI == EPI_GEGLU ? gelu_table() : nullptr;
   const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2 + (gtab ? GTAB_N * 8 : 0);       // GEGLU forward / backward: + the 32 KiB GELU table = all 160 KiB of the CU
-  if (!attr_pp) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8); attr_pp = true; }
+  ensure_smem_attr((const void*)gemm_nt_pp_kernel<EPI>, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8, attr_pp);
   static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
   if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
   hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), smem2, s, p, stagger, gtab);
@@ -1900,24 +1883,24 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const int smem = 2 * (BM * BK + BN * BK) * 2;
   switch (pl.kind) {
     case NT_DECODE: {
-      static bool attr_sd = false;
+      static uint32_t attr_sd = 0;
       const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
-      if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }
+      ensure_smem_attr((const void*)gemm_nt_decode_kernel<EPI>, smem_sd, attr_sd);
       hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sd, s, p);
       break;
     }
     case NT_SKINNY: {
-      static bool attr_sk = false;
+      static uint32_t attr_sk = 0;
       const int smem_sk = SK_ST * SK_STAGE * 2;
-      if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_nt_skinny_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk); attr_sk = true; }
+      ensure_smem_attr((const void*)gemm_nt_skinny_kernel<EPI>, smem_sk, attr_sk);
       hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sk, s, p);
       break;
     }
     case NT_PP: launch_pp<EPI>(p, pl.grid, s); break;
     case NT_MID: {
-      static bool attr_md = false;
+      static uint32_t attr_md = 0;
       const int smem_md = MD_ST * MD_STAGE * 2;
-      if (!attr_md) { (void)hipFuncSetAttribute((const void*)gemm_nt_mid_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_md); attr_md = true; }
+      ensure_smem_attr((const void*)gemm_nt_mid_kernel<EPI>, smem_md, attr_md);
       hipLaunchKernelGGL(gemm_nt_mid_kernel<EPI>, dim3(pl.grid), dim3(256), smem_md, s, p);
       break;
     }
@@ -1951,9 +1934,9 @@ static int gemm_nt_qknr(const GemmNT& p, hipStream_t s) {
   if (qknr_fusable(p)) {
     const NtPlan pl = nt_plan(p);
     if (pl.kind == NT_PP) { launch_pp<EPI_QKNR>(p, pl.grid, s); return (int)hipGetLastError(); }
-    static bool attr_sd = false;
+    static uint32_t attr_sd = 0;
     const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
-    if (!attr_sd) { (void)hipFuncSetAttribute((const void*)gemm_nt_decode_kernel<EPI_QKNR>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sd); attr_sd = true; }
+    ensure_smem_attr((const void*)gemm_nt_decode_kernel<EPI_QKNR>, smem_sd, attr_sd);
     hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI_QKNR>, dim3(pl.grid), dim3(256), smem_sd, s, p);
     return (int)hipGetLastError();
   }
@@ -1986,8 +1969,8 @@ int gemm_nt(const GemmNT& p, hipStream_t s) {
 
 template <bool SUM, int FA, int FB, int WN, int WK, int NST> static void launch_tn_wide(const GemmTN& q, int grid, hipStream_t s) {
   constexpr int smem = NST * (FA * WN + FB * WK) / 4 * MW_ROWS * 128 * 2;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  static uint32_t attr = 0;
+  ensure_smem_attr((const void*)gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST>, smem, attr);
   hipLaunchKernelGGL((gemm_tn_wide_kernel<SUM, FA, FB, WN, WK, NST>), dim3(grid), dim3(64 * WN * WK), smem, s, q);
 }
 
@@ -2021,12 +2004,9 @@ int gemm_tn_plan(const GemmTN& p, int* kind, int* tiles, int* splits, int* grid)
 int gemm_tn(const GemmTN& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 0) return -1;
   if ((p.lda | p.ldb | p.a_cols | p.b_cols) & 7) return -2;
-  static bool attr_set = false;
+  static uint32_t attr_set = 0;
   const int smem = 2 * 2 * TN_BMK * TN_LD * 2;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  ensure_smem_attr((const void*)gemm_tn_kernel, smem, attr_set);
   GemmTN q = p;
   const TnPlan pl = tn_plan(q);
   q.splits = pl.splits;

@@ -162,6 +162,17 @@ TFX_DEV float gelu_cdf(float g, float& E) {
   return 0.5f + __builtin_copysignf(half_erf, g);
 }
 TFX_DEV float gelu_erf(float x) { float E; return x * gelu_cdf(x, E); }
+// What the GEGLU forward SAVES for its backward (round 5): u = gelu(g) and v = a gelu'(g), in the value / gate slots of the interleaved buffer, instead of the
+// pre-activations a and g.  d(a gelu(g)) = dh u da' + dh v dg', so the backward epilogue is two multiplies per element pair - no exponential, no table,
+// no conversion of a second stream - and the forward pays 3 more FMAs on values it holds in fp32 anyway (u, v come from the fp32 accumulator: one
+// rounding to bf16 each, where the round-4 form rounded a and g first and evaluated gelu / gelu' on the rounded g).  h = a u is the product itself.
+struct GegluUVH { float u, v, h; };
+TFX_DEV GegluUVH geglu_uvh(float a, float g) {
+  float E; const float cdf = gelu_cdf(g, E);
+  GegluUVH r; r.u = g * cdf; r.h = a * r.u;
+  r.v = a * fmaf(g * 0.39894228040143267794f, E, cdf);
+  return r;
+}
 TFX_DEV float gelu_erf_grad(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }

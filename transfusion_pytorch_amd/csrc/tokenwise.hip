@@ -105,6 +105,13 @@ template <int NC> TFX_DEV void flush_col_partials(const Row<NC>& part, float* ou
     else { constexpr int NC = 4; CALL; }         \
   } while (0)
 
+#define DISPATCH_NC_LE1024(d, CALL)              \
+  do {                                           \
+    if ((d) % 8 != 0 || (d) > 1024) return -1;   \
+    if ((d) <= 512) { constexpr int NC = 1; CALL; } \
+    else { constexpr int NC = 2; CALL; }         \
+  } while (0)
+
 static inline int grid_tokens(int T) { return (T + WAVES - 1) / WAVES; }
 static inline int grid_capped(int T) { int g = grid_tokens(T); return g < MAXB ? g : MAXB; }
 
@@ -923,8 +930,10 @@ template <int NC> TFX_DEV float row_dot(const Row<NC>& a, const Row<NC>& b) {
 TFX_DEV float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 // register form, kept for A/B (TFX_PULL_VARIANT=1): at most NJ sources, d w partials in registers, w rows in LDS, every row of a token requested
-// at once and held in registers until used (255 registers: two waves per SIMD, bytes in flight only while a wave waits)
-template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_reg_k(tfx_attnres_pull_args p, tfx_adaln_post_args q, int has_post) {
+// at once and held in registers until used (two waves per SIMD, bytes in flight only while a wave waits).  DB: the wrapper's bias gradient (column sums
+// of dy) is accumulated here - 8 more registers per lane, which at NJ = 8 is what made hipcc spill 9 of them into the token loop; the training
+// plans take that gradient from the weight-gradient GEMM that reads dy anyway (tfx_gemm_tn colsum) and run the DB = false instantiation
+template <int NC, int NJ, bool DB> __global__ __launch_bounds__(512) void attnres_pull_reg_k(tfx_attnres_pull_args p, tfx_adaln_post_args q, int has_post) {
   extern __shared__ float dyn[];                            // [n_src][d]
   __shared__ float smem[SEG_WAVES * NC * 512];
   __shared__ tfx_attnres_src srcs[PULL_MAX_SRC];
@@ -950,7 +959,7 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
   for (int i = 0; i < NC; i++)
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      pl.v[i][e] = 0.f; pb.v[i][e] = 0.f;
+      pl.v[i][e] = 0.f; if constexpr (DB) pb.v[i][e] = 0.f;
 #pragma unroll
       for (int j = 0; j < (REG ? NJ : 1); j++) pw[j].v[i][e] = 0.f;
     }
@@ -959,14 +968,22 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
   for (int s = blockIdx.x * SEG_WAVES + (threadIdx.x >> 6); s < n_items; s += gridDim.x * SEG_WAVES) {
     const int t0 = tok_mode ? s : p.seg_start[s], len = tok_mode ? 1 : p.seg_len[s];
     const int inst = has_post ? q.tok_inst[t0] : -1;
-    Row<NC> sc, az;
+    // the segment's scale row (1 + layerscale | sigmoid z) lives in the wave's own 2 KiB of `smem` (free until the closing flush, which every wave enters
+    // only after its last token), as [half][lane][4] so that the two 16-byte reads per token are conflict-free: 8 registers less across the token loop,
+    // where the NJ = 8 form had 9 / 3 spilled registers
+    float* scl = smem + (threadIdx.x >> 6) * NC * 512;
+    Row<NC> az;
     if (has_post) {
+      Row<NC> sc;
       if (inst < 0) load_vec(sc, q.layerscale, d, lane);
       else load_vec(sc, q.table + (size_t)inst * q.ld_table + 2 * d, d, lane);
 #pragma unroll
-      for (int i = 0; i < NC; i++)
+      for (int i = 0; i < NC; i++) {
+        f32x4 s0, s1;
 #pragma unroll
-        for (int e = 0; e < 8; e++) { sc.v[i][e] = inst < 0 ? 1.f + sc.v[i][e] : sigmoidf_(sc.v[i][e]); az.v[i][e] = 0.f; }
+        for (int e = 0; e < 8; e++) { const float v = inst < 0 ? 1.f + sc.v[i][e] : sigmoidf_(sc.v[i][e]); if (e < 4) s0[e] = v; else s1[e - 4] = v; az.v[i][e] = 0.f; }
+        *(f32x4*)(scl + (i * 2) * 256 + lane * 4) = s0; *(f32x4*)(scl + (i * 2 + 1) * 256 + lane * 4) = s1;
+      }
     }
     const int tend = t0 + len;
     for (int t = t0; t < tend; t++) {
@@ -1053,16 +1070,19 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
       store_row(G, p.dh + (size_t)t * d, d, lane);
       if (has_post) {
         Row<NC> yy; widen(yy, yr);
+        asm volatile("" ::: "memory");                            // (keeps the scale-row reads inside the loop: hoisted, they are 8 live registers again)
 #pragma unroll
         for (int i = 0; i < NC; i++) {
           const int c = lane + 64 * i;
           if (c * 8 >= d) continue;
+          const f32x4 s0 = *(const f32x4*)(scl + (i * 2) * 256 + lane * 4), s1 = *(const f32x4*)(scl + (i * 2 + 1) * 256 + lane * 4);
 #pragma unroll
           for (int e = 0; e < 8; e++) {
+            const float sce = e < 4 ? s0[e & 3] : s1[e & 3];
             const float gy = G.v[i][e] * yy.v[i][e];
-            if (tok_mode && inst >= 0) atomicAdd(q.dtable + (size_t)inst * q.ld_table + 2 * d + c * 8 + e, gy * sc.v[i][e] * (1.f - sc.v[i][e]));
+            if (tok_mode && inst >= 0) atomicAdd(q.dtable + (size_t)inst * q.ld_table + 2 * d + c * 8 + e, gy * sce * (1.f - sce));
             else az.v[i][e] += gy;
-            G.v[i][e] *= sc.v[i][e]; pb.v[i][e] += G.v[i][e];
+            G.v[i][e] *= sce; if constexpr (DB) pb.v[i][e] += G.v[i][e];
           }
         }
         store_row(G, q.dy + (size_t)t * d, d, lane);
@@ -1080,11 +1100,12 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
         for (int i = 0; i < NC; i++) {
           int c = lane + 64 * i;
           if (c * 8 >= d) continue;
+          const f32x4 s0 = *(const f32x4*)(scl + (i * 2) * 256 + lane * 4), s1 = *(const f32x4*)(scl + (i * 2 + 1) * 256 + lane * 4);
           f32x4 a0, a1;
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            a0[e] = az.v[i][e] * sc.v[i][e] * (1.f - sc.v[i][e]);
-            a1[e] = az.v[i][4 + e] * sc.v[i][4 + e] * (1.f - sc.v[i][4 + e]);
+            a0[e] = az.v[i][e] * s0[e] * (1.f - s0[e]);
+            a1[e] = az.v[i][4 + e] * s1[e] * (1.f - s1[e]);
           }
           *(f32x4*)(dt + c * 8) = a0; *(f32x4*)(dt + c * 8 + 4) = a1;
         }
@@ -1093,7 +1114,7 @@ template <int NC, int NJ> __global__ __launch_bounds__(512) void attnres_pull_re
   }
   if (has_post) {
     flush_col_partials<NC>(pl, q.dlayerscale, d, smem);
-    if (q.dbias) flush_col_partials<NC>(pb, q.dbias, d, smem);
+    if constexpr (DB) { if (q.dbias) flush_col_partials<NC>(pb, q.dbias, d, smem); }
   }
   if constexpr (REG) {
 #pragma unroll
@@ -2061,8 +2082,11 @@ template <int NC, int NJ> static int pull_dma(const tfx_attnres_pull_args& a, co
 extern "C" {
 
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
+// d > 1024 (NC = 4, outside every BASELINE width): the segment forms of the input side keep a 32-column register tile per lane plus its partials and
+// spilled 52 / 233 registers (tools/check_spills.sh, flagged three rounds running) - such widths take the per-token forms, which do not spill (the
+// table gradients then arrive by atomics on the zeroed buffer instead of one plain store per segment: same sums)
 int tfx_adaln_pre_bwd(const tfx_adaln_pre_args* a, void* s) {
-  if (a->seg_start && a->n_seg > 0) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(seg_grid(adaln_pre_bwd_seg_k<NC>, a->n_seg)), dim3(512), 0, ST(s), *a)); }
+  if (a->seg_start && a->n_seg > 0 && a->d <= 1024) { DISPATCH_NC_LE1024(a->d, hipLaunchKernelGGL(adaln_pre_bwd_seg_k<NC>, dim3(seg_grid(adaln_pre_bwd_seg_k<NC>, a->n_seg)), dim3(512), 0, ST(s), *a)); }
   else { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_bwd_k<NC>, dim3(grid_capped(a->T)), dim3(256), 0, ST(s), *a)); }
   RET();
 }
@@ -2092,12 +2116,12 @@ int tfx_attnres_bwd(const tfx_attnres_args* a, void* s) {
 }
 int tfx_adaln_pre_post_bwd(const tfx_adaln_pre_args* a, const tfx_adaln_post_args* b, void* s) {
   if (!a || !b || a->T != b->T || a->d != b->d || a->tok_inst != b->tok_inst || (const void*)a->dx != (const void*)b->g) return -2;
-  if (!a->seg_start || a->n_seg <= 0) {             // no segments: the two per-token launches
+  if (!a->seg_start || a->n_seg <= 0 || a->d > 1024) {   // no segments (or a width whose fused segment form would spill): the two launches
     int rc = tfx_adaln_pre_bwd(a, s);
     return rc ? rc : tfx_adaln_post_bwd(b, s);
   }
   if (a->dx_add || b->dbias) return -3;
-  DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_post_bwd_seg_k<NC>, dim3(seg_grid(adaln_pre_post_bwd_seg_k<NC>, a->n_seg)), dim3(512), 0, ST(s), *a, *b)); RET();
+  DISPATCH_NC_LE1024(a->d, hipLaunchKernelGGL(adaln_pre_post_bwd_seg_k<NC>, dim3(seg_grid(adaln_pre_post_bwd_seg_k<NC>, a->n_seg)), dim3(512), 0, ST(s), *a, *b)); RET();
 }
 int tfx_attnres_prep(const tfx_attnres_src* src, int32_t n, int32_t d, void* s) {
   if (n <= 0) return 0;
@@ -2133,7 +2157,7 @@ int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_ar
   }
   if (small) {
     // few sources, narrow rows: d w partials in registers, every row of the token in flight at once
-    auto fn = attnres_pull_reg_k<1, 8>;
+    auto fn = (b && b->dbias) ? attnres_pull_reg_k<1, 8, true> : attnres_pull_reg_k<1, 8, false>;
     const int items = a->n_seg > 0 ? a->n_seg : a->T;
     static int forced = -1;                 // TFX_PULL_GRID (A/B): block count of the register form
     if (forced < 0) { const char* e = getenv("TFX_PULL_GRID"); forced = e ? atoi(e) : 0; }
