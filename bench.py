@@ -406,6 +406,7 @@ def time_other_config(c, dev, batch=64, steps=3, warmup=2):
     from transfusion_pytorch_amd.optim import FusedAdam
     cfg = CONFIGS[c]
     torch.manual_seed(0)
+    torch.cuda.reset_peak_memory_stats()
     m = build_model(cfg['dim'], cfg['depth'], cfg['two'], dev).train()
     opt = FusedAdam(m, lr=3e-4, max_grad_norm=0.5)
     gen = torch.Generator(device=dev).manual_seed(1234)

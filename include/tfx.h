@@ -128,7 +128,12 @@ typedef struct {
   tfx_bf16* dgate; int32_t ld_dgate;         /* grad wrt gate logits */
   tfx_bf16 *dq, *dk, *dv; int32_t ld_dq, ld_dk, ld_dv;
   int32_t order;              /* set by the library (block order of the launch); callers leave it 0 */
-  const float* sc_plan;       /* optional, forward and backward: the layer's soft-cap plan (tfx_qk_norm_rope_args.sc_plan); NULL = decide from the scores */
+  const float* sc_plan;       /* optional, forward and backward: the layer's soft-cap plan (tfx_qk_norm_rope_args.sc_plan); NULL = decide from the scores.
+                               * PRECONDITION: a plan of mode 0 / 1 is a polynomial fitted on [-B, B] and the kernels do NOT check the scores
+                               * against B - every q and k row of this call (KV-cache rows included) must have been produced by tfx_qk_norm_rope_fwd (or the
+                               * fused projection epilogue) under the SAME gammas / scales the plan was written from.  Rows from other gains, or without
+                               * QK-norm, make the polynomial diverge silently outside [-B, B]: pass NULL for such inputs.  tfx_decode_attn (the
+                               * matrix-core-free decode kernel) ignores the plan and evaluates the data-dependent form. */
   /* forward with a KV cache, optional (compacted decode steps): sample s of the launch owns the query rows q_row0[s] .. q_row0[s] + q_cnt[s] - 1 of the
    * token arrays (q, gate, kv_end, out) instead of rows s * n .. (`n` stays the per-sample maximum and sizes the grid; q_cnt[s] = 0: nothing to do);
    * keys / values are still the sample's n_kv cache rows.  Device arrays of `b` int32 each; NULL = the dense layout. */
@@ -459,7 +464,8 @@ int tfx_graph_destroy(void* graph);
  * fingerprint the graph was captured under and re-captures (or replays the list) when a scalar / pointer of the step has changed. */
 int tfx_list_fingerprint(const tfx_launch* list, int32_t n, int64_t* out);
 /* on != 0: replay every item on the caller's stream (FORK / JOIN become no-ops) - same results, kernels one at a time (used to time a
- * kernel family without its side-stream neighbours); returns the previous setting */
+ * kernel family without its side-stream neighbours); returns the previous setting.  The switch belongs to the CALLING HOST THREAD (thread_local):
+ * another thread's replays and fingerprints keep their own setting. */
 int tfx_set_single_stream(int32_t on);
 
 const char* tfx_version(void);

@@ -243,7 +243,7 @@ def test_geglu_table_range_ends():
             cols = torch.arange(c, dip, pins.numel(), device=DEV)
             e = (got[:, cols] - ref[:, cols]).abs().max().item()
             sc = ref[:, cols].abs().max().item()
-            assert e <= 8e-3 * sc + 1e-9, f'forward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'
+            assert e <= 8e-3 * sc + 1e-7, f'forward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'
     del saved
     dy, W2t = rnd(M, d), rnd(dip, d, scale=d ** -0.5)
     dag = torch.zeros(M, 2 * dip, device=DEV, dtype=BF)
@@ -259,7 +259,7 @@ def test_geglu_table_range_ends():
         for nm, got, ref in (('da', da, auto[:, ~is_gate]), ('dg', dg, auto[:, is_gate])):
             e = (got[:, cols] - ref[:, cols]).abs().max().item()
             sc = ref[:, cols].abs().max().item()
-            assert e <= 1.2e-2 * sc + 1e-9, f'backward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'   # two bf16 roundings (saved value, result)
+            assert e <= 1.2e-2 * sc + 1e-7, f'backward {nm}, gate ~ {pins[c].item():g}: max err {e:.3e} at scale {sc:.3e}'   # two bf16 roundings (saved value, result)
 
 
 # ---------------------------------------------------------------------------------------------- GEMM TN

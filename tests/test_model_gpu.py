@@ -668,7 +668,7 @@ def test_overlapped_exchange_world1_default_gates_and_accumulation_rccl():
     """ `torchrun --nproc-per-node 1`: torch.distributed is initialised at world size 1 and `always_sync` keeps its
     default - the backward still takes the overlapped path, so `step()` must wait for its handles and re-arm the reducer: two consecutive steps
     run.  Then gradient accumulation: micro-batches under `opt.no_sync()` only accumulate, the last backward exchanges - the step equals the
-    plain exchange's two-backward step; without `no_sync` the second backward is refused.  Also the public-API fallback (TFX_DP_COALESCE=0)."""
+    plain exchange's two-backward step; without `no_sync` the second backward is refused.  Also the coalesced exchange (TFX_DP_COALESCE=1)."""
     import torch.distributed as dist
     from transfusion_pytorch_amd.optim import FusedAdam
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29542')
@@ -698,7 +698,7 @@ def test_overlapped_exchange_world1_default_gates_and_accumulation_rccl():
                 model(batch, times=times).backward()
             loss = model(batch, times=times); loss.backward()
             if overlap:
-                assert opt.reducer.exchanged and opt.reducer.launches == 2                  # depth 4 in groups of 2 layers: only the LAST backward sent them
+                assert opt.reducer.exchanged and opt.reducer.launches == 4                  # depth 4 in groups of 2 layers, two ranges per group on the (default) public-API exchange: only the LAST backward sent them
             g = model.store.grad.clone()
             opt.step(); torch.cuda.synchronize()
             res.append((g, model.store.flat.clone()))
@@ -707,12 +707,13 @@ def test_overlapped_exchange_world1_default_gates_and_accumulation_rccl():
         model(batch, times=times).backward()
         with pytest.raises(RuntimeError, match='no_sync'):
             model(batch, times=times).backward()
-        # public-API exchange (no private coalescing manager): two launches per group, same sums
-        os.environ['TFX_DP_COALESCE'] = '0'
+        # the coalesced exchange (torch's private `_coalescing_manager`, TFX_DP_COALESCE=1; the default is the public API since round 5): one launch per
+        # group, same sums
+        os.environ['TFX_DP_COALESCE'] = '1'
         try:
             model, opt = fresh(True)
             loss = model(batch, times=times); loss.backward()
-            assert opt.reducer.launches == 4
+            assert opt.reducer.launches == 2
             g = model.store.grad.clone(); opt.step(); torch.cuda.synchronize()
         finally:
             del os.environ['TFX_DP_COALESCE']

@@ -8,7 +8,7 @@ cd $R
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 > gpurun_out/ev_${TAG}_bench_line.json 2> gpurun_out/ev_${TAG}_bench.err; cut -c1-300 gpurun_out/ev_${TAG}_bench_line.json
-(cd /tmp && TFX_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_prof -o p -- python $R/bench.py --steps 4 --warmup 2 --family-steps 0 --no-cpu-baseline --ragged-steps 0 --no-sample > /tmp/ev_prof.log 2>&1)
+(cd /tmp && TFX_SIDE_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/ev_prof -o p -- python $R/bench.py --steps 4 --warmup 2 --family-steps 0 --no-cpu-baseline --ragged-steps 0 --no-sample --no-other-configs --no-parity > /tmp/ev_prof.log 2>&1)
 python tools/prof_summary.py /tmp/ev_prof/p_kernel_trace.csv --steady > gpurun_out/ev_${TAG}_cfg2_kernel_summary.txt
 python tools/prof_gaps.py /tmp/ev_prof/p_kernel_trace.csv --steps 2 > gpurun_out/ev_${TAG}_cfg2_gaps.txt 2>&1
 for C in 3 4; do

@@ -2,7 +2,7 @@
 # sample socket power / shader clock with rocm-smi while the training-step bench runs: is the step power-limited?
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 rocm-smi --showmaxpower --showpowerprofile 2>/dev/null | grep -iv "^$\|====" | head -12
-(python bench.py --steps 500 --warmup 5 --no-cpu-baseline --ragged-steps 0 --no-sample > /tmp/pw.json 2>/dev/null) &
+(python bench.py --steps 500 --warmup 5 --no-cpu-baseline --ragged-steps 0 --no-sample --no-other-configs --no-parity > /tmp/pw.json 2>/dev/null) &
 BP=$!
 sleep 9
 for i in $(seq 16); do

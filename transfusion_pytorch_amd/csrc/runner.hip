@@ -103,7 +103,9 @@ struct SideStream {
 // set for each; the list is replayed on the device that is current when tfx_run_list is called (the caller's stream lives there)
 constexpr int kMaxDevices = 16;
 SideStream g_sides[kMaxDevices];
-bool g_single_stream = false;
+// per HOST THREAD: the switch is flipped around a graph capture (engine.replay_auto) and by bench.py's bracketed steps - a second thread that
+// replays a list or fingerprints one in that window must keep seeing its own setting
+thread_local bool g_single_stream = false;
 inline SideStream* side_of_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;

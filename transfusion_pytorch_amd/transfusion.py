@@ -1039,7 +1039,12 @@ class Transfusion(nn.Module):
                 if torch.is_tensor(part) and part.is_floating_point():
                     part = (0, part)
                 if isinstance(part, tuple):
-                    tt = times[bi, min(m, times.shape[1] - 1)] if (times is not None and times.ndim == 2 and times.shape[1]) else torch.ones((), device=self.device)
+                    #  the closure divides (embed - tokens) by max(1 - t, eps): without the caller's times it would silently run at t = 1,
+                    # i.e. multiply by 1 / eps - the un-cached forward always has times here (drawn like the reference's, T:3075-3082); a cached
+                    # text step that asks for clean flows of its prefix must pass them
+                    assert times is not None and times.ndim == 2 and times.shape[1] > 0, \
+                        '`model_output_clean` with `return_embed`: pass `times` (one column per modality instance) - the clean-to-flow closures need each instance\'s time'
+                    tt = times[bi, min(m, times.shape[1] - 1)]
                     out.append((int(part[0]), part[1], tt.to(self.device, torch.float32)))
                     m += 1
         return out
