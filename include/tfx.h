@@ -457,6 +457,10 @@ int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int32_t* faile
  * size).  `tfx_graph_create` captures the list on a library-owned stream (nothing executes) and instantiates it; `tfx_graph_launch`
  * replays it on `stream`.  Kernel arguments are frozen at capture time: re-create the graph when an args struct of the list changes. */
 int tfx_graph_create(const tfx_launch* list, int32_t n, void** graph_out);
+/* the same capture with every item on ONE stream (FORK / JOIN items become no-ops, side-stream items run in list order): the chain form the training
+ * lists are captured in (engine.replay_auto, TFX_TRAIN_GRAPH=1).  The single-stream mode holds for this call on this thread only - it does not touch
+ * the process-wide switch of tfx_set_single_stream, so other threads' replays and fingerprints are unaffected. */
+int tfx_graph_create_single(const tfx_launch* list, int32_t n, void** graph_out);
 int tfx_graph_launch(void* graph, void* stream);
 int tfx_graph_destroy(void* graph);
 /* 64-bit fingerprint of everything a capture of the list would freeze: ops, stream tags, the bytes of every args struct (and of the host structs
@@ -464,8 +468,8 @@ int tfx_graph_destroy(void* graph);
  * fingerprint the graph was captured under and re-captures (or replays the list) when a scalar / pointer of the step has changed. */
 int tfx_list_fingerprint(const tfx_launch* list, int32_t n, int64_t* out);
 /* on != 0: replay every item on the caller's stream (FORK / JOIN become no-ops) - same results, kernels one at a time (used to time a
- * kernel family without its side-stream neighbours); returns the previous setting.  The switch belongs to the CALLING HOST THREAD (thread_local):
- * another thread's replays and fingerprints keep their own setting. */
+ * kernel family without its side-stream neighbours); returns the previous setting.  PROCESS-wide: `loss.backward()` replays its list on PyTorch's
+ * autograd thread, which must see what the main thread set. */
 int tfx_set_single_stream(int32_t on);
 
 const char* tfx_version(void);

@@ -1,6 +1,7 @@
 // Launch-list replay (include/tfx.h "launch lists"): the training / decode step is a static list of kernel launches over persistent
 // buffers, so the host hands the whole list to the library once per step instead of paying one FFI round trip per kernel.
 // Host code only; every case forwards to the public entry point of the same name.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstdint>
@@ -103,9 +104,14 @@ struct SideStream {
 // set for each; the list is replayed on the device that is current when tfx_run_list is called (the caller's stream lives there)
 constexpr int kMaxDevices = 16;
 SideStream g_sides[kMaxDevices];
-// per HOST THREAD: the switch is flipped around a graph capture (engine.replay_auto) and by bench.py's bracketed steps - a second thread that
-// replays a list or fingerprints one in that window must keep seeing its own setting
-thread_local bool g_single_stream = false;
+// the switch of tfx_set_single_stream is PROCESS-wide on purpose: PyTorch runs `loss.backward()` on its autograd worker thread, so a caller that
+// sets it on the main thread (bench.py's bracketed steps, the one-stream parity test) must reach the replay of the backward list on another thread (a
+// thread_local switch, tried first in round 5, silently left the weight-gradient GEMMs on the side stream there).  What must NOT leak to other threads
+// is the temporary single-stream mode of a graph capture (engine.replay_auto used to flip the global around tfx_graph_create): that one is
+// the thread-local override below, set only inside tfx_graph_create_single.
+std::atomic<bool> g_single_stream{false};
+thread_local int t_force_single = 0;
+inline bool single_stream() { return t_force_single > 0 || g_single_stream.load(std::memory_order_relaxed); }
 inline SideStream* side_of_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
@@ -130,7 +136,7 @@ extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int
     if (!l.args) rc = -2;
     else if (l.op >= TFX_OP_FORK && l.op <= TFX_OP_JOIN_WAIT) {
       if (l.stream < 0 || l.stream >= 64) rc = -3;
-      else if (g_single_stream) rc = 0;
+      else if (single_stream()) rc = 0;
       else if (SideStream* gs = side(rc)) {
         SideStream& g_side = *gs;
         if (l.op == TFX_OP_FORK) {
@@ -141,7 +147,7 @@ extern "C" int tfx_run_list(const tfx_launch* list, int32_t n, void* stream, int
           if (rc == 0 && l.op != TFX_OP_JOIN_RECORD) rc = (int)hipStreamWaitEvent(main_s, g_side.join_ev[l.stream], 0);
         }
       }
-    } else if (l.stream == 1 && !g_single_stream) {
+    } else if (l.stream == 1 && !single_stream()) {
       if (SideStream* gs = side(rc)) rc = run_one(l, (void*)gs->stream);
     } else if (l.stream == 1) {
       rc = run_one(l, stream);
@@ -178,6 +184,12 @@ extern "C" int tfx_graph_create(const tfx_launch* list, int32_t n, void** graph_
   if (ei != hipSuccess || !exec) return -123;
   *graph_out = (void*)exec;
   return 0;
+}
+extern "C" int tfx_graph_create_single(const tfx_launch* list, int32_t n, void** graph_out) {
+  ++t_force_single;                      // this thread's capture only: other threads keep replaying / fingerprinting in their own mode
+  const int rc = tfx_graph_create(list, n, graph_out);
+  --t_force_single;
+  return rc;
 }
 extern "C" int tfx_graph_launch(void* graph, void* stream) {
   if (!graph) return -1;
@@ -220,7 +232,7 @@ inline uint64_t mix(uint64_t h, const void* p, size_t n) {           // FNV-1a o
 }  // namespace
 extern "C" int tfx_list_fingerprint(const tfx_launch* list, int32_t n, int64_t* out) {
   if (!out || n < 0 || (n > 0 && !list)) return -1;
-  uint64_t h = 1469598103934665603ull ^ (g_single_stream ? 0x9e3779b97f4a7c15ull : 0ull);
+  uint64_t h = 1469598103934665603ull ^ (g_single_stream.load(std::memory_order_relaxed) ? 0x9e3779b97f4a7c15ull : 0ull);
   for (int32_t i = 0; i < n; ++i) {
     const tfx_launch& l = list[i];
     h = mix(h, &l.op, 4); h = mix(h, &l.stream, 4);
@@ -247,7 +259,6 @@ extern "C" int tfx_list_fingerprint(const tfx_launch* list, int32_t n, int64_t* 
 }
 
 extern "C" int tfx_set_single_stream(int32_t on) {
-  const int prev = g_single_stream ? 1 : 0;
-  g_single_stream = on != 0;
+  const int prev = g_single_stream.exchange(on != 0) ? 1 : 0;
   return prev;
 }

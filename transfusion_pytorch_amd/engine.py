@@ -139,11 +139,8 @@ class LaunchList(list):
             # captured as ONE chain (the side-stream launches in list order on the capture stream): with the weight-gradient GEMMs as parallel
             # branches the replay measured 34.5 ms per step against 28.5 for the chain and 28.7 for the two-stream list (config 2, same box,
             # ROCm 7.2: the graph executor does not overlap the branches, it stalls at their joins)
-            prev = lib.tfx_set_single_stream(1)
-            try:
-                rc = lib.tfx_graph_create(ctypes.byref(arr, lo * ctypes.sizeof(_LAUNCH)), hi - lo, ctypes.byref(out))
-            finally:
-                lib.tfx_set_single_stream(prev)
+            # (tfx_graph_create_single: the one-stream mode belongs to this capture on this thread - the process-wide switch is not touched)
+            rc = lib.tfx_graph_create_single(ctypes.byref(arr, lo * ctypes.sizeof(_LAUNCH)), hi - lo, ctypes.byref(out))
             if rc != 0 or not out.value:
                 st[2] = -(1 << 30)                                   # this range does not capture (never retried): the list path keeps running it
                 return False
