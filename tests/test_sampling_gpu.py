@@ -254,3 +254,50 @@ def test_sample_many_at_the_config5_model_size_matches_reference_golden():
             assert e <= 5e-2
     print(f'[big] {tot_dec} of {tot_all} decisive steps compared ({tot_dec / max(tot_all, 1):.1%}), {n_mod} decoded modalities')
     assert n_mod >= 8 and tot_dec >= BIG_MIN_COMPARED * tot_all
+
+
+def test_sample_many_keeps_its_decode_plans_between_calls():
+    """round 5: the KV-cache buffer and the decode plans built on it (launch lists, captured graphs, per-plan AdaLN tables of the
+    solver grid) stay on the model between `sample_many` calls of the same geometry - a second call reuses them and returns the same samples; anything
+    they froze that changes (solver grid, a parameter) rebuilds them; TFX_DECODE_KEEP=0 and `model.train()` drop them."""
+    m, prompts, noise = native_model()
+    kw = dict(max_length=10, text_temperature=0., init_modality_noise=noise, modality_steps=4, fixed_modality_shape=(4,), cfg_scale=3., force_modality_at_start=0)
+    ps = [prompts[0], prompts[1]]
+    def same(x, y):
+        for sa, sb in zip(x, y):
+            for a, b in zip(plain(sa), plain(sb)):
+                assert a[0] == b[0] and (torch.equal(a[1], b[1]) if a[0] == 'text' else torch.equal(a[2], b[2]))
+    first = m.sample_many(ps, **kw)
+    kept = m._decode_keep
+    assert kept is not None and len(kept['plans']) > 0
+    ids = {k: id(p) for k, p in kept['plans'].items()}
+    second = m.sample_many(ps, **kw)
+    assert m._decode_keep is not None and m._decode_keep['joint'] is kept['joint']
+    assert all(id(m._decode_keep['plans'][k]) == v for k, v in ids.items()), 'the second call must run on the plans of the first'
+    same(first, second)
+    # a different solver grid: other conditioning times -> other per-plan tables -> nothing may be reused
+    third = m.sample_many(ps, **{**kw, 'modality_steps': 3})
+    assert m._decode_keep['joint'] is not kept['joint']
+    os.environ['TFX_DECODE_KEEP'] = '0'
+    try:
+        cold = m.sample_many(ps, **{**kw, 'modality_steps': 3})
+        assert m._decode_keep is None
+    finally:
+        del os.environ['TFX_DECODE_KEEP']
+    same(third, cold)
+    # a changed parameter: the kept plans' shadows / tables are stale - the call must notice (params_version) and give the new model's samples
+    again = m.sample_many(ps, **kw)
+    kept2 = m._decode_keep
+    with torch.no_grad():
+        m.to_text_logits.weight.mul_(-1.)
+    changed = m.sample_many(ps, **kw)
+    assert m._decode_keep['joint'] is not kept2['joint']
+    os.environ['TFX_DECODE_KEEP'] = '0'
+    try:
+        changed_cold = m.sample_many(ps, **kw)
+    finally:
+        del os.environ['TFX_DECODE_KEEP']
+    same(changed, changed_cold)
+    same(first, again)
+    m.train()
+    assert m._decode_keep is None

@@ -241,12 +241,28 @@ class Sampler:
         n0 = S['n']
         Lcap = max([math.prod(sh) for sh in m.modality_default_shape if sh is not None] + [math.prod(fixed_modality_shape or (1,)), 16])
         maxlen = (max(s.cache_len for s in states) + max_length + 2 * Lcap + 80) // 64 * 64
-        m._decode_plans = {}
         # classifier-free guidance evaluates every ODE step twice - against the real history and against the null-text one (T:2468-2525).  Both
         # evaluations share the weights and a decode step is launch-bound, so they run as ONE forward over 2 B rows: the two KV caches are the halves
         # of one buffer (the text steps use the first half through a view)
         use_cfg = cfg_scale != 1.
-        joint = self._alloc_cache(2 * B if use_cfg else B, max(maxlen, n0))
+        # Decode plans - launch lists, their captured graphs, per-plan AdaLN tables of the solver's time grid - are bound to the cache buffer they were
+        # built on.  A serving process calls sample_many over and over with the same geometry: the buffer and its plans are KEPT on the model between
+        # calls (plan build + graph capture were ~30 ms of every call) and reused while everything they froze still holds - rows,
+        # capacity, solver grid, guidance on / off, the parameter version (shadows and cond tables are functions of the weights).  TFX_DECODE_KEEP=0
+        # turns it off; TFX_DECODE_KEEP_GB bounds the kept cache (default 16); `model.train()` drops it.
+        rows, need = (2 * B if use_cfg else B), max(maxlen, n0)
+        keep_on = os.environ.get('TFX_DECODE_KEEP', '1') != '0'
+        keep_key = (rows, int(modality_steps), bool(use_cfg), m.store.params_version(), tuple(fixed_modality_shape or ()), bool(pos_emb_in_decode))
+        ent = getattr(m, '_decode_keep', None) if keep_on else None
+        self._grew = False
+        if ent is not None and ent['key'] == keep_key and ent['joint'].shape[2] >= need:
+            joint, m._decode_plans = ent['joint'], ent['plans']
+            joint.zero_()
+        else:
+            m._decode_keep = None
+            m._decode_plans = {}
+            joint = self._alloc_cache(rows, need)
+        joint0 = joint
         cache = joint[:, :B]
         self._fill_cache(cache, plan, B, n0)
         logits0 = plan.logits.view(B, n0, md.vp)[..., :md.vocab]
@@ -284,6 +300,11 @@ class Sampler:
         else:
             self._loop_phased(states, joint, use_cfg, stream, max_length, text_temperature, text_min_p, fixed_modality_shape,
                               init_modality_noise, modality_steps, cfg_scale)
+        gib = joint0.numel() * joint0.element_size() / 2 ** 30
+        if keep_on and not self._grew and gib <= float(os.environ.get('TFX_DECODE_KEEP_GB', '16')):
+            m._decode_keep = {'key': keep_key, 'joint': joint0, 'plans': m._decode_plans}      # (a run that had to grow its cache rebuilt its plans: not kept)
+        else:
+            m._decode_keep = None
         m._decode_plans = {}
         return [[(p if isinstance(p, tuple) else torch.tensor(p, dtype=torch.long, device=dev)) for p in st.parts] for st in states]
 
@@ -770,6 +791,7 @@ class Sampler:
         new = self._alloc_cache(cache.shape[1], (need + 63) // 64 * 64)
         new[:, :, :cache.shape[2]].copy_(cache)
         self.m._decode_plans = {}
+        self._grew = True
         return new
 
     def _load(self, p, ids, pos, kve, rot, tok_inst, units=None):

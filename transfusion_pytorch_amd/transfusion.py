@@ -546,6 +546,13 @@ class Transfusion(nn.Module):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def train(self, mode: bool = True):
+        """nn.Module.train; switching INTO training drops the decode cache + plans `sample_many` keeps between calls (sampling.py: up to
+        TFX_DECODE_KEEP_GB of KV cache stays allocated for a serving process; a training process gets the memory back)"""
+        if mode:
+            self._decode_keep = None
+        return super().train(mode)
+
     def _require_gpu(self):
         if self.device.type != 'cuda':
             raise capi.TfxError('the Transfusion hot path only runs on an MI355X (model.cuda()); there is no CPU fallback')
