@@ -198,6 +198,8 @@ def _worker_plan_overlap(rank, world, port, q):
     m, ps, plan = _cpu_plan()
     local = torch.randn(ps.numel, generator=torch.Generator().manual_seed(100 + rank))
     ok = True
+    os.environ['TFX_DP_COALESCE'] = '1'                         # this test counts the COALESCED exchange's launches (groups + 1); the public-API default (one
+                                                                # collective per range, round 5) is counted in the next test and in the bench dry run
     for dt in (None, torch.bfloat16):
         ps.grad.copy_(local)
         red = GradReducer(m, None, groups=3, exchange_dtype=dt)
@@ -309,8 +311,8 @@ def _worker_world1_gates(rank, world, port, q):
             ok &= red.defer
         ok &= red.defer
     ok &= not red.defer
-    # public API only (TFX_DP_COALESCE=0): one collective per range, every element still exactly once
-    os.environ['TFX_DP_COALESCE'] = '0'
+    # public API only (the default; TFX_DP_COALESCE unset or 0): one collective per range, every element still exactly once
+    os.environ.pop('TFX_DP_COALESCE', None)
     ps.grad.copy_(local)
     red.begin()
     for _, first, last in plan.bwd_cuts:

@@ -13,7 +13,7 @@ Tolerances (bf16 vs fp32; the reference's own bf16-autocast floor is rel-Frobeni
                                    weight-gradient GEMMs accumulate in a run-dependent order, and a slice of a small-norm gradient (zero-initialised
                                    ada-ln-zero weights deep in the 24-layer case) moves between 4.3e-2 and 6.5e-2 from run to run / build to build
                                    while the median over all 596 slices stays at 1.0e-2
-Tolerances are ~1.5x the worst value measured on MI355X (DESIGN.md section 3), so that a regression which doubles an error fails.
+Tolerances are ~1.5x the worst value measured on MI355X (DESIGN.md section 1), so that a regression which doubles an error fails.
 """
 import os
 

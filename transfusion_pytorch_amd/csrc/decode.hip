@@ -197,9 +197,9 @@ __global__ __launch_bounds__(256) void decode_attn_rows_k(tfx_attn_args p) {
 }
 
 template <int R> static int launch_decode_rows(const tfx_attn_args& a, hipStream_t s) {
-  static bool attr = false;
+  static uint32_t attr = 0;
   const int smem = R * 32 * 8 * 9 * 4;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)decode_attn_rows_k<R>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  ensure_smem_attr((const void*)decode_attn_rows_k<R>, smem, attr);
   hipLaunchKernelGGL(decode_attn_rows_k<R>, dim3((unsigned)(a.b * a.h)), dim3(256), smem, s, a);
   return (int)hipGetLastError();
 }

@@ -1841,16 +1841,6 @@ static const float* gelu_table() {
   }
   return tab[dev];
 }
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one flag bit per device (a process may drive several), set under a lock
-// so that a second host thread cannot launch between another thread's flag write and its attribute call.
-static void ensure_smem_attr(const void* fn, int bytes, uint32_t& done_mask) {
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  const uint32_t bit = 1u << (dev & 31);
-  std::lock_guard<std::mutex> lock(mu);
-  if (!(done_mask & bit)) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done_mask |= bit; }
-}
 struct NtPlan { int kind, grid; };
 static NtPlan nt_plan(const GemmNT& p) {
   const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -1864,7 +1854,9 @@ static NtPlan nt_plan(const GemmNT& p) {
   const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
   if (dma && p.M <= 1024 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) return {NT_DECODE, grid_sd};
   if (dma && (p.M <= 512 || (p.M <= 1024 && grid_sk <= 256))) return {NT_SKINNY, grid_sk};
-  if (dma && t256 >= 512) return {NT_PP, t256};
+  static int pp_min = -1;             // TFX_NT_PP_MIN: fewest 256 x 256 tiles that still take the ping-pong kernel (A/B; default 512 = two per CU)
+  if (pp_min < 0) { const char* e = getenv("TFX_NT_PP_MIN"); pp_min = e ? atoi(e) : 512; }
+  if (dma && t256 >= pp_min) return {NT_PP, t256};
   if (dma && mid && grid <= 256 && p.K >= 4 * BK) return {NT_MID, grid};
   return {dma ? NT_GLDS : NT_FALLBACK, grid};
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -177,3 +178,14 @@ TFX_DEV float gelu_erf_grad(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 TFX_DEV float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }   // v_rcp_f32: 1 ulp, no IEEE divide sequence
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one flag bit per device (a process may drive several), set under a lock so that
+// a second host thread cannot launch between another thread's flag write and its attribute call.  `done_mask`: a static of the launch site.
+inline std::mutex& smem_attr_mutex() { static std::mutex mu; return mu; }
+inline void ensure_smem_attr(const void* fn, int bytes, uint32_t& done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint32_t bit = 1u << (dev & 31);
+  std::lock_guard<std::mutex> lock(smem_attr_mutex());
+  if (!(done_mask & bit)) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done_mask |= bit; }
+}

@@ -931,8 +931,8 @@ TFX_DEV float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __bu
 
 // register form, kept for A/B (TFX_PULL_VARIANT=1): at most NJ sources, d w partials in registers, w rows in LDS, every row of a token requested
 // at once and held in registers until used (two waves per SIMD, bytes in flight only while a wave waits).  DB: the wrapper's bias gradient (column sums
-// of dy) is accumulated here - 8 more registers per lane, which at NJ = 8 is what made hipcc spill 9 of them into the token loop; the training
-// plans take that gradient from the weight-gradient GEMM that reads dy anyway (tfx_gemm_tn colsum) and run the DB = false instantiation
+// of dy) is accumulated here (8 more registers per lane; instantiated both ways so that a caller without a bias does not carry them).  Round 4's form
+// spilled 9 registers into the token loop at NJ = 8; with the segment's scale row in LDS (below) it is 246 (DB) / 238 registers, no spills
 template <int NC, int NJ, bool DB> __global__ __launch_bounds__(512) void attnres_pull_reg_k(tfx_attnres_pull_args p, tfx_adaln_post_args q, int has_post) {
   extern __shared__ float dyn[];                            // [n_src][d]
   __shared__ float smem[SEG_WAVES * NC * 512];
@@ -2051,8 +2051,8 @@ template <typename F> static int seg_grid(F fn, int n_seg) {
 }
 template <int NC, int AHEAD, bool W16, int NJ> static int launch_pull_dma(const tfx_attnres_pull_args& a, const tfx_adaln_post_args& b, int has_post, size_t dyn, hipStream_t s) {
   auto fn = attnres_pull_dma_k<NC, AHEAD, W16, NJ>;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024); attr = true; }
+  static uint32_t attr = 0;
+  ensure_smem_attr((const void*)fn, 156 * 1024, attr);
   const int items = a.n_seg > 0 ? a.n_seg : a.T;
   int grid = (items + 7) / 8;
   const int cap = resident_blocks(fn, 512, dyn);

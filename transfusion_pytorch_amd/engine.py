@@ -753,7 +753,7 @@ class Plan:
             G = self.dH[i + 1]
             a_postf = capi.make_args('tfx_adaln_post_args', T=T, d=d, y=self.yf[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                                      layerscale=pp(f'{p}.2.layerscale'), g=G, dy=dy_f, dtable=dtf, dlayerscale=gp(f'{p}.2.layerscale'),
-                                     seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)   # (the ff2 bias gradient = column sums of dy rides in net.3's weight-gradient GEMM below)
+                                     seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0, dbias=gp(f'{p}.2.fn.net.3.bias'))   # ff2 bias gradient = column sums of dy
             self._seg_args.append(a_postf)
             if pull:
                 # dH[i+1] = gradient of hidden i + 1 from the AttentionResiduals of layers i .. D-1 (all final), formed ONCE; the feed-forward
@@ -771,8 +771,9 @@ class Plan:
             # the weight gradients of this wrapper go to the side stream (dy_f and d[a|g] are final); net.0 carries its bias gradient
             # (column sums of d[a|g]) folded into the same GEMM
             sync('tfx_fork', 2 * i)
-            self._tn(L, T, d, di, side=side, A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di,
-                     colsum=gp(f'{p}.2.fn.net.3.bias'))      # + its bias gradient (column sums of dy_f): 8 registers less in the pull kernel, which spilled (round 5)
+            # (round 5 tried net.3's bias gradient as this GEMM's `colsum` to free 8 registers of the pull kernel: the SUM form of the GEMM is 13 us slower per
+            # launch (158 vs 145 us, profiles/r05_shapes.txt) - and with its scale row in LDS the pull kernel no longer spills WITH the bias partials)
+            self._tn(L, T, d, di, side=side, A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
             self._tn(L, T, 2 * dip, d, side=side, algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
                      C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias'))
             self._nt(L, algo_k=2 * di, A=dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
