@@ -138,6 +138,23 @@ typedef struct {
    * token arrays (q, gate, kv_end, out) instead of rows s * n .. (`n` stays the per-sample maximum and sizes the grid; q_cnt[s] = 0: nothing to do);
    * keys / values are still the sample's n_kv cache rows.  Device arrays of `b` int32 each; NULL = the dense layout. */
   const int32_t* q_row0; const int32_t* q_cnt;
+  /* backward, optional (round 5): the backward of QK-RMSNorm + RoPE (+ the q scale; reference T:950-952, T:965, T:998 backwards) in the epilogues of the dQ and
+   * dK/dV kernels.  With nr_qkv set, the kernels do not write d q~ / d k~ to dq / dk: each wave takes its 32 x 64 block through the staging image it stores
+   * from anyway - 8 lanes per row, 8 contiguous columns each, the token-wise kernel's own shape - loads the raw (pre-norm) q / k chunk, applies
+   * tfx_qk_norm_rope_bwd's arithmetic to the bf16-rounded d q~ / d k~ and writes d q | d k (raw) to nr_dqkv (q at column h*64, k at column h_total*64 + h*64,
+   * the layout of tfx_qk_norm_rope_args.dqkv); the gain gradients accumulate per block and leave as 64 atomics per block and kernel.  One write + one read of
+   * the [T, 2 h 64] d q~ | d k~ matrix and the tfx_qk_norm_rope_bwd launch drop out of a layer's backward.  All nr_* leading dimensions % 8 == 0, 16-byte
+   * aligned bases; nr_norm_scale 0 = 8. */
+  const tfx_bf16* nr_qkv; int32_t nr_ld_qkv;
+  tfx_bf16* nr_dqkv; int32_t nr_ld_dqkv;
+  const float* nr_gamma_q; const float* nr_gamma_k;
+  const int32_t* nr_rot_pos; const float* nr_cos; const float* nr_sin;
+  float nr_q_scale, nr_norm_scale;
+  float* nr_dgamma_q; float* nr_dgamma_k;
+  /* optional scratch, fp32 [2][h * b * ceil(n / 128)][64]: with it every block of the dQ / dK/dV kernel WRITES its gain-gradient partials to its own row and a
+   * small reduction launch behind the two kernels adds them into nr_dgamma_q / nr_dgamma_k - instead of 64 atomics per block onto the same 64 addresses
+   * (4096 blocks: ~60 us of serialised same-address atomics per kernel, measured as +26 us per kernel in the step).  NULL = the atomics. */
+  float* nr_scratch;
 } tfx_attn_args;
 int tfx_attn_fwd(const tfx_attn_args* a, void* stream);
 int tfx_attn_bwd(const tfx_attn_args* a, void* stream);   /* prep + dK/dV kernel + dQ kernel */

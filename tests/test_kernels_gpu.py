@@ -392,6 +392,66 @@ def test_attention_fwd_bwd(b, h, n, qs, ks):
         assert (sim > 0.45).any(), 'this case must reach the exact-tanh branch'
 
 
+@pytest.mark.parametrize('b,h,n', [(2, 2, 200), (1, 3, 128), (3, 1, 333), (1, 8, 1024), (2, 2, 64)])
+def test_attention_bwd_with_fused_qk_norm_rope_bwd(b, h, n):
+    """round 5: the backward of QK-RMSNorm + RoPE in the epilogues of the dQ and dK/dV kernels (tfx_attn_args.nr_*) against the two launches it replaces
+    (tfx_attn_bwd writing d q~ | d k~, then tfx_qk_norm_rope_bwd): same d q | d k (raw) up to one bf16 rounding of the same arithmetic, same gain
+    gradients, d v / d gate untouched; n = 200 / 333 / 64 leave wave blocks partly or wholly past a sample's end (no read or write there: the
+    output buffer is poisoned)."""
+    torch.manual_seed(23)
+    T, HD = b * n, h * 64
+    ld = 3 * HD + 8
+    qkv = rnd(T, ld, scale=1.0)                                   # raw q | k | v | gates
+    gq = (torch.rand(64, device=DEV) * 2 - 1) * 0.2; gk = (torch.rand(64, device=DEV) * 2 - 1) * 0.2
+    pos = torch.randint(0, 50, (T,), device=DEV, dtype=torch.int32)
+    ang = torch.arange(50, device=DEV)[:, None] * (10000. ** (-torch.arange(32, device=DEV) / 32.))[None, :]
+    cos_t, sin_t = ang.cos().contiguous(), ang.sin().contiguous()
+    qk = torch.zeros(T, 2 * HD, device=DEV, dtype=BF)
+    fa = capi.make_args('tfx_qk_norm_rope_args', T=T, H=h, qkv=qkv, ld_qkv=ld, qk=qk, ld_qk=2 * HD, gamma_q=gq, gamma_k=gk,
+                        rot_pos=pos, cos_tab=cos_t, sin_tab=sin_t, q_scale=0.125)
+    capi.call('tfx_qk_norm_rope_fwd', fa, stream())
+    kv_end, q_start = make_kv_end(b, n)
+    kv_end, q_start = kv_end.to(DEV), q_start.to(DEV)
+    out = torch.zeros(T, HD, device=DEV, dtype=BF); lse = torch.zeros(b, h, n, device=DEV)
+    dout = rnd(T, HD)
+    res = []
+    for fused in (False, True, 'scratch'):                        # 'scratch': per-block partial rows + the reduction launch instead of same-address atomics
+        do_eff = torch.zeros(T, HD, device=DEV, dtype=BF); delta = torch.zeros(b, h, n, device=DEV)
+        dqk = torch.full((T, 2 * HD), float('nan'), device=DEV, dtype=BF)
+        dqkv = torch.full((T, ld), float('nan'), device=DEV, dtype=BF)
+        dgq, dgk = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+        kw = dict(q=qk, k=qk[:, HD:], v=qkv[:, 2 * HD:], ld_q=2 * HD, ld_k=2 * HD, ld_v=ld, gate=qkv[:, 3 * HD:], ld_gate=ld, kv_end=kv_end, q_start=q_start,
+                  out=out, ld_out=HD, lse=lse, b=b, h=h, n=n, softcap=50.0, dout=dout, ld_dout=HD, do_eff=do_eff, ld_do=HD, delta=delta,
+                  dgate=dqkv[:, 3 * HD:], ld_dgate=ld, dq=dqk, dk=dqk[:, HD:], dv=dqkv[:, 2 * HD:], ld_dq=2 * HD, ld_dk=2 * HD, ld_dv=ld)
+        if fused:
+            kw.update(nr_qkv=qkv, nr_ld_qkv=ld, nr_dqkv=dqkv, nr_ld_dqkv=ld, nr_gamma_q=gq, nr_gamma_k=gk, nr_rot_pos=pos, nr_cos=cos_t, nr_sin=sin_t,
+                      nr_q_scale=0.125, nr_norm_scale=8.0, nr_dgamma_q=dgq, nr_dgamma_k=dgk)
+            if fused == 'scratch':
+                scratch = torch.full((2 * h * b * ((n + 127) // 128) * 64,), float('nan'), device=DEV)      # every row must be written before it is summed
+                kw.update(nr_scratch=scratch)
+        a = capi.make_args('tfx_attn_args', **kw)
+        if not fused:
+            capi.call('tfx_attn_fwd', a, stream())
+        capi.call('tfx_attn_bwd', a, stream())
+        if not fused:
+            ba = capi.make_args('tfx_qk_norm_rope_args', T=T, H=h, qkv=qkv, ld_qkv=ld, gamma_q=gq, gamma_k=gk, rot_pos=pos, cos_tab=cos_t, sin_tab=sin_t,
+                                q_scale=0.125, norm_scale=8.0, dqk=dqk, ld_dqk=2 * HD, dqkv=dqkv, ld_dqkv=ld, dgamma_q=dgq, dgamma_k=dgk)
+            capi.call('tfx_qk_norm_rope_bwd', ba, stream())
+        else:
+            assert torch.isnan(dqk.float()).all(), 'the fused form must not write d q~ / d k~'
+        torch.cuda.synchronize()
+        res.append((dqkv.clone(), dgq.clone(), dgk.clone()))
+    (d0, gq0, gk0) = res[0]
+    for tag, (d1, gq1, gk1) in zip(('atomics', 'scratch rows'), res[1:]):
+        assert torch.isfinite(d1[:, :3 * HD + h].float()).all(), 'every d q | d k | d v | d gate element must have been written'
+        check(f'fused ({tag}): d q (raw)', d1[:, :HD], d0[:, :HD].float(), 2e-3)
+        check(f'fused ({tag}): d k (raw)', d1[:, HD:2 * HD], d0[:, HD:2 * HD].float(), 2e-3)
+        assert torch.equal(d1[:, 2 * HD:3 * HD + h], d0[:, 2 * HD:3 * HD + h]), 'd v / d gate must not change'
+        check(f'fused ({tag}): d gamma_q', gq1, gq0, 2e-3)
+        check(f'fused ({tag}): d gamma_k', gk1, gk0, 2e-3)
+    assert torch.equal(res[1][0][:, :3 * HD + h], res[2][0][:, :3 * HD + h])        # (columns past the gates stay poisoned in every run)
+
+
 @pytest.mark.parametrize('gscale,want_mode', [(0.04, 0), (0.22, 1), (1.0, 2)])
 def test_attention_softcap_plan_from_qk_norm_bound(gscale, want_mode):
     """round 4: the soft-cap polynomial's degree is a property of the LAYER - QK-RMSNorm bounds |q~ . k~| by

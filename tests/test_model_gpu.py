@@ -517,6 +517,26 @@ def test_side_stream_weight_gradients_equal_single_stream():
             assert rel(o['grads'][k], ref['grads'][k]) <= 2e-3, k
 
 
+@pytest.mark.parametrize('name', ['small2', 'canon512'])
+def test_fused_qk_norm_rope_backward_equals_the_separate_launch(name, monkeypatch):
+    """round 5: with TFX_ATTN_QKNR=1 (default) a layer's backward runs QK-RMSNorm + RoPE backwards inside the attention-backward epilogues; TFX_ATTN_QKNR=0
+    is the round-4 list (attention backward writes d q~ | d k~, tfx_qk_norm_rope_bwd reads them back).  Same loss, every gradient equal to the rounding of
+    one bf16 intermediate (`small2`: ragged lengths - wave blocks past a sample's end; `canon512`: the bench's model)."""
+    outs = []
+    for mode in ('0', '1'):
+        monkeypatch.setenv('TFX_ATTN_QKNR', mode)
+        cfg, model, out = run_native(name)
+        n_sep = sum(1 for it in model._live[0].bwd if it[0] == 'tfx_qk_norm_rope_bwd')
+        assert n_sep == (cfg.depth if mode == '0' else 0), 'the switch must change the backward list'
+        outs.append(out)
+    ref, fus = outs
+    assert abs(fus['loss'] - ref['loss']) <= 1e-6 * max(1., abs(ref['loss']))
+    worst = max(rel(fus['grads'][k], ref['grads'][k]) for k in ref['grads'])
+    print(f'  fused vs separate QK-norm / RoPE backward: worst gradient rel difference {worst:.2e}')
+    for k in ref['grads']:
+        assert rel(fus['grads'][k], ref['grads'][k]) <= 3e-3, k
+
+
 def test_training_lists_replay_as_graphs_while_their_fingerprint_holds(monkeypatch):
     """TFX_TRAIN_GRAPH=1: the forward / backward launch lists of a fixed-shape training loop run as ONE hipGraph launch each from the third step
     on (LaunchList.replay_auto: captured once `tfx_list_fingerprint` - every byte a capture freezes - has repeated), the side-stream

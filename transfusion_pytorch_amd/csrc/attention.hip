@@ -223,6 +223,109 @@ TFX_DEV void wave_block_store(bf16* st, const bf16x4 (&v)[2][4], bf16* g0, int l
   }
 }
 
+// wave_block_store with the backward of QK-RMSNorm + RoPE applied on the way out (tfx.h tfx_attn_args.nr_*; arithmetic of tokenwise.hip qk_norm_rope_bwd_k on
+// the same bf16-rounded d q~ / d k~ chunk).  The read-back shape of the staging image IS that kernel's: lane = (row q * 8 + (l >> 3), chunk l & 7), the 8 lanes
+// of a row hold one 64-wide head vector, so both of its reductions are group8_sum.  `tok` = token index of the block's first row, `colq` = column of this head
+// in the raw / output matrices (WHICH = 1: the k half).  Rows past the end are computed on the last valid row and not stored (the cross-lane sums need
+// every lane).  pg: this lane's gain-gradient partials of columns (l & 7) * 8 .. + 7.
+template <int WHICH>
+TFX_DEV void wave_block_store_nr(bf16* st, const bf16x4 (&v)[2][4], const tfx_attn_args& p, size_t tok, int colq, int rows_valid, float (&pg)[8]) {
+  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+  if (rows_valid <= 0) return;                                    // (wave-uniform) the whole block lies past the sample's end: nothing to read or write
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int col = db * 32 + 8 * rg + 4 * hi;
+      *(bf16x4*)(st + r * 64 + (((col >> 3) ^ ((r >> 1) & 7)) << 3) + (col & 7)) = v[db][rg];
+    }
+  const float sc = (WHICH == 0 ? p.nr_q_scale : 1.f) * (p.nr_norm_scale > 0.f ? p.nr_norm_scale : 8.f);
+  const float* gmp = (WHICH == 0 ? p.nr_gamma_q : p.nr_gamma_k) + ch * 8;
+  const f32x4 g0 = *(const f32x4*)gmp, g1 = *(const f32x4*)(gmp + 4);
+  // every global request of the block ahead of the first use: raw chunk, rotary position -> cos / sin rows
+  bf16x8 x8[4], t[4];
+  f32x4 cs[4], sn[4];
+  const int last = max(rows_valid - 1, 0);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = min(q * 8 + (l >> 3), last);
+    const size_t tt = tok + row;
+    x8[q] = *(const bf16x8*)(p.nr_qkv + tt * p.nr_ld_qkv + colq + ch * 8);
+    const int pos = p.nr_rot_pos[tt];
+    cs[q] = *(const f32x4*)(p.nr_cos + (size_t)pos * 32 + ch * 4);
+    sn[q] = *(const f32x4*)(p.nr_sin + (size_t)pos * 32 + ch * 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = min(q * 8 + (l >> 3), last);
+    t[q] = *(const bf16x8*)(st + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int row = q * 8 + (l >> 3);
+    const bool live = row < rows_valid;
+    float xv[8], qq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) { xv[e] = bf2f(x8[q][e]); qq += xv[e] * xv[e]; }
+    qq = group8_sum(qq);
+    const float nrm = fmaxf(sqrtf(qq), 1e-12f), inv = 1.f / nrm;
+    float dyn[8], S = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float da = bf2f(t[q][2 * i]), db = bf2f(t[q][2 * i + 1]);
+      const float ga = da * cs[q][i] + db * sn[q][i];                // inverse rotation
+      const float gb = db * cs[q][i] - da * sn[q][i];
+      const float gma = i < 2 ? g0[2 * i] : g1[2 * i - 4], gmb = i < 2 ? g0[2 * i + 1] : g1[2 * i - 3];
+      const float ca = sc * (1.f + gma), cb = sc * (1.f + gmb);
+      if (live) { pg[2 * i] += ga * xv[2 * i] * (inv * sc); pg[2 * i + 1] += gb * xv[2 * i + 1] * (inv * sc); }
+      dyn[2 * i] = ga * ca; dyn[2 * i + 1] = gb * cb;
+      S += dyn[2 * i] * xv[2 * i] + dyn[2 * i + 1] * xv[2 * i + 1];
+    }
+    S = group8_sum(S);
+    const float k = S * inv * inv * inv;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = f2bf(dyn[e] * inv - xv[e] * k);
+    if (live) *(bf16x8*)(p.nr_dqkv + (tok + row) * p.nr_ld_dqkv + colq + ch * 8) = o;
+  }
+}
+// gain gradients of a block: the 8 lanes of a wave that own the same 8 columns are summed by three exchanges, the four waves through LDS, 64 atomics
+TFX_DEV void nr_flush_dgamma(float (&pg)[8], float* sg /* [4][64] */, float* dgamma, float* scratch_row /* this block's [64] row of tfx_attn_args.nr_scratch, or null */) {
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) pg[e] += __shfl_xor(pg[e], m, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) sg[wv * 64 + lane * 8 + e] = pg[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float s4 = sg[threadIdx.x] + sg[64 + threadIdx.x] + sg[128 + threadIdx.x] + sg[192 + threadIdx.x];
+    if (scratch_row) scratch_row[threadIdx.x] = s4;                 // one 256-byte row per block; summed by attn_nr_reduce_kernel
+    else if (s4 != 0.f) atomicAdd(dgamma + threadIdx.x, s4);
+  }
+}
+TFX_DEV size_t linear_block() { return blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z); }
+// sums the per-block gain-gradient rows of the dQ (which = 0) and dK/dV (1) kernels: block (chunk, which) takes 256 rows - wave w 64 of them, lane = column
+// (coalesced 256-byte reads) -, the four waves meet in LDS, 64 atomics per block (2 x 16 blocks at the bench size instead of 2 x 4096)
+__global__ __launch_bounds__(256) void attn_nr_reduce_kernel(const float* scratch, int nblocks, float* dgq, float* dgk) {
+  __shared__ float sg[4 * 64];
+  const int which = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* src = scratch + (size_t)which * nblocks * 64;
+  const int r0 = blockIdx.x * 256 + w * 64, r1 = min(r0 + 64, nblocks);
+  float s = 0.f;
+  for (int r = r0; r < r1; r++) s += src[(size_t)r * 64 + lane];
+  sg[w * 64 + lane] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float s4 = sg[threadIdx.x] + sg[64 + threadIdx.x] + sg[128 + threadIdx.x] + sg[192 + threadIdx.x];
+    if (s4 != 0.f) atomicAdd((which == 0 ? dgq : dgk) + threadIdx.x, s4);
+  }
+}
+
 struct BlockId { int tile, h, b; };
 TFX_DEV BlockId decode_block(int order, int ntile, bool heavy_last_tile) {     // (scalars only: no reference to the kernel-argument struct)
   BlockId o;
@@ -685,6 +788,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
 #pragma unroll
         for (int e = 0; e < 4; e++) ov[db][rg][e] = f2bf(dq[db][rg * 4 + e]);
     __syncthreads();                                            // the K / V tiles are free: staging area of the coalesced stores
+    if (p.nr_qkv) {                                             // (kernel argument: block-uniform) QK-norm + RoPE backward on the way out
+      __shared__ float sg[4 * 64];
+      float pg[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) pg[e] = 0.f;
+      wave_block_store_nr<0>((w < 2 ? Ks : Vs) + (w & 1) * 2048, ov, p, tok0 + q0 + w * 32, h * DH, n - (q0 + w * 32), pg);
+      nr_flush_dgamma(pg, sg, p.nr_dgamma_q, p.nr_scratch ? p.nr_scratch + linear_block() * 64 : nullptr);
+    } else
     wave_block_store((w < 2 ? Ks : Vs) + (w & 1) * 2048, ov, p.dq + (tok0 + q0 + w * 32) * p.ld_dq + h * DH, p.ld_dq, n - (q0 + w * 32));
   }
 }
@@ -833,8 +944,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
     __syncthreads();                                            // the Q / dO tiles are free: staging area of the coalesced stores
     bf16* st = (w < 2 ? Qs : Ds) + (w & 1) * 2048;
     const int rows = n - (k0 + w * 32);
-    wave_block_store(st, kv, p.dk + (tok0 + k0 + w * 32) * p.ld_dk + h * DH, p.ld_dk, rows);
-    wave_block_store(st, vv, p.dv + (tok0 + k0 + w * 32) * p.ld_dv + h * DH, p.ld_dv, rows);
+    if (p.nr_qkv) {                                             // (kernel argument: block-uniform) QK-norm + RoPE backward of d k~ on the way out
+      __shared__ float sg[4 * 64];
+      float pg[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) pg[e] = 0.f;
+      wave_block_store_nr<1>(st, kv, p, tok0 + k0 + w * 32, (p.h + h) * DH, rows, pg);
+      wave_block_store(st, vv, p.dv + (tok0 + k0 + w * 32) * p.ld_dv + h * DH, p.ld_dv, rows);
+      nr_flush_dgamma(pg, sg, p.nr_dgamma_k,
+                      p.nr_scratch ? p.nr_scratch + ((size_t)gridDim.x * gridDim.y * gridDim.z + linear_block()) * 64 : nullptr);
+    } else {
+      wave_block_store(st, kv, p.dk + (tok0 + k0 + w * 32) * p.ld_dk + h * DH, p.ld_dk, rows);
+      wave_block_store(st, vv, p.dv + (tok0 + k0 + w * 32) * p.ld_dv + h * DH, p.ld_dv, rows);
+    }
   }
 }
 
@@ -867,10 +989,19 @@ int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
   if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;
   long long nthreads = (long long)p.b * p.n * p.h * 8;
   if (nthreads >= (1ll << 31)) return -4;
+  if (p.nr_qkv) {                                               // fused QK-norm / RoPE backward: complete argument set, 16-byte rows
+    if (!p.nr_dqkv || !p.nr_gamma_q || !p.nr_gamma_k || !p.nr_rot_pos || !p.nr_cos || !p.nr_sin || !p.nr_dgamma_q || !p.nr_dgamma_k) return -5;
+    if (((p.nr_ld_qkv | p.nr_ld_dqkv) & 7) || (((uintptr_t)p.nr_qkv | (uintptr_t)p.nr_dqkv) & 15)) return -5;
+  }
   tfx_attn_args q = p; q.order = attn_order();
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, q);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, attn_grid(q), dim3(256), 0, s, q);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, attn_grid(q), dim3(256), 0, s, q);
+  if (p.nr_qkv && p.nr_scratch) {
+    const dim3 g = attn_grid(q);
+    const int nblocks = (int)(g.x * g.y * g.z);
+    hipLaunchKernelGGL(attn_nr_reduce_kernel, dim3((nblocks + 255) / 256, 2), dim3(256), 0, s, (const float*)p.nr_scratch, nblocks, p.nr_dgamma_q, p.nr_dgamma_k);
+  }
   return (int)hipGetLastError();
 }
 

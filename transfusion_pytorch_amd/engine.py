@@ -582,6 +582,15 @@ class Plan:
             a[1] = lt['q'].data_ptr() if mode == 'model' else lt['x'].data_ptr()
             a[2] = None if mode == 'model' else self.noise_args[t].eps
 
+    def _nr_scratch(self):
+        """per-block gain-gradient rows of the fused QK-norm / RoPE backward (tfx.h tfx_attn_args.nr_scratch): fp32 [2][heads x samples x ceil(n / 128)][64],
+        one buffer for all layers (the backward runs them one after the other)"""
+        if getattr(self, '_nr_scr', None) is None:
+            blocks = self.md.heads * self.b * ((self.n + 127) // 128)
+            self._nr_scr = torch.zeros(2 * blocks * 64, device=self.ps.device, dtype=torch.float32)
+            self.nbytes += self._nr_scr.numel() * 4
+        return self._nr_scr
+
     def _attn_kw(self, i, bwd=False):
         md, hd, ldq = self.md, self.md.hdk, self.md.ldq
         li, lkv = self._li(i), self._lkv(i)
@@ -610,6 +619,8 @@ class Plan:
             a.cos_tab, a.sin_tab = cos_tab.data_ptr(), sin_tab.data_ptr()
         for a in getattr(self, '_rope_nt_args', []):                      # projections with the fused QK-norm / RoPE epilogue
             a.qk_cos, a.qk_sin = cos_tab.data_ptr(), sin_tab.data_ptr()
+        for a in getattr(self, '_rope_attn_args', []):                    # attention backward with the fused QK-norm / RoPE backward
+            a.nr_cos, a.nr_sin = cos_tab.data_ptr(), sin_tab.data_ptr()
 
     def set_segments(self, seg_start, seg_len):
         n_seg = int(seg_start.numel())
@@ -794,14 +805,26 @@ class Plan:
                 L.append(('tfx_adaln_pre_bwd', a_pref))
                 L.append(('tfx_adaln_post_bwd', a_posta))
             self._nt(L, algo_n=md.hd, A=dy_a, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
-            self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
-            self._k(L, 'tfx_qk_norm_rope_bwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, gamma_q=gam('q'),
-                    gamma_k=gam('k'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5,
-                    dqk=self.dqk, ld_dqk=2 * hd, dqkv=dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
-            self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
-            L.meta = L.meta or {}
-            L.meta[len(L) - 1] = ('hbm', 3 * 2 * T * hd * 2)                # q, k (raw) in; d q~, d k~ in; d q, d k out
+            if os.environ.get('TFX_ATTN_QKNR', '1') != '0':
+                # round 5: the backward of QK-RMSNorm + RoPE rides in the epilogues of the dQ and dK/dV kernels (tfx.h tfx_attn_args.nr_*): d q~ | d k~ are never
+                # written out and read back, and the token-wise launch below drops out of the layer
+                self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True), nr_qkv=self.qkvg[i], nr_ld_qkv=ldq, nr_dqkv=dqkvg, nr_ld_dqkv=ldq,
+                        nr_gamma_q=gam('q'), nr_gamma_k=gam('k'), nr_rot_pos=self.rot_pos, nr_cos=0, nr_sin=0, nr_q_scale=md.dim_head ** -0.5,
+                        nr_norm_scale=md.dim_head ** 0.5, nr_dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), nr_dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'),
+                        nr_scratch=self._nr_scratch() if os.environ.get('TFX_ATTN_QKNR') == '2' else None)
+                # (TFX_ATTN_QKNR=2: per-block partial rows + a reduction launch instead of 64 same-address atomics per block - measured SLOWER, attention
+                # backward 4.19 vs 4.05 ms per step: the atomics were not what the fused epilogue costs, its ~400 vector instructions per wave in two
+                # VALU-bound kernels are)
+                self._rope_attn_args = getattr(self, '_rope_attn_args', []) + [L[-1][1]]
+            else:
+                self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
+                self._k(L, 'tfx_qk_norm_rope_bwd', 'tfx_qk_norm_rope_args', T=T, H=H, qkv=self.qkvg[i], ld_qkv=ldq, gamma_q=gam('q'),
+                        gamma_k=gam('k'), rot_pos=self.rot_pos, cos_tab=0, sin_tab=0, q_scale=md.dim_head ** -0.5, norm_scale=md.dim_head ** 0.5,
+                        dqk=self.dqk, ld_dqk=2 * hd, dqkv=dqkvg, ld_dqkv=ldq, dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
+                self._rope_args = getattr(self, '_rope_args', []) + [L[-1][1]]
+                L.meta = L.meta or {}
+                L.meta[len(L) - 1] = ('hbm', 3 * 2 * T * hd * 2)                # q, k (raw) in; d q~, d k~ in; d q, d k out
             self._nt(L, algo_k=md.nq, A=dqkvg, lda=ldq, B=S[f'qkvg_t{i}'], ldb=ldq, M=T, N=d, K=ldq, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             # (pull form: the gradient a U-Net skip hands to this layer's input joins here, so that G ends up as the TOTAL gradient of xres[i])
             self._k(L, 'tfx_adaln_pre_bwd', 'tfx_adaln_pre_args', T=T, d=d, x=x_a, tok_inst=self.tok_inst, table=ta, ld_table=nt3,
