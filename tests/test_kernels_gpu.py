@@ -3,6 +3,8 @@ Tolerances: bf16 outputs rel-Frobenius <= 1e-2 (bf16 eps = 3.9e-3); fp32 outputs
 import ctypes
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -450,6 +452,17 @@ def test_attention_bwd_with_fused_qk_norm_rope_bwd(b, h, n):
         check(f'fused ({tag}): d gamma_q', gq1, gq0, 2e-3)
         check(f'fused ({tag}): d gamma_k', gk1, gk0, 2e-3)
     assert torch.equal(res[1][0][:, :3 * HD + h], res[2][0][:, :3 * HD + h])        # (columns past the gates stay poisoned in every run)
+
+
+def test_attention_bwd_with_the_preparation_fused_into_the_dq_kernel():
+    """round 5, TFX_ATTN_PREP=1 (off by default: measured neutral): delta, do_eff and dgate computed by the dQ kernel for its own rows, dK/dV behind it.  The
+    library reads the switch once per process, so the attention backward tests run again in a child process with it set."""
+    import subprocess, sys
+    env = dict(os.environ, TFX_ATTN_PREP='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                        'test_attention_fwd_bwd or test_attention_bwd_with_fused_qk_norm_rope_bwd'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-1500:]
 
 
 @pytest.mark.parametrize('gscale,want_mode', [(0.04, 0), (0.22, 1), (1.0, 2)])
