@@ -635,6 +635,9 @@ def main():
                               'frac': ach / (8.0 if hbm else PEAK_BF16_TFLOPS), 'ms_per_step': tsec / args.family_steps * 1e3,
                               'launches_per_step': cnt / args.family_steps,
                               ('algorithmic_gbyte_per_step' if hbm else 'algorithmic_gflop_per_step'): work / args.family_steps / 1e9})
+            if fam == 'tfx_attn_bwd' and os.environ.get('TFX_ATTN_QKNR', '1') != '0':
+                by_family[-1]['note'] = ('since round 5 these launches also run the backward of QK-RMSNorm + RoPE in their epilogues (token-wise work, ~0.6 ms per step as its '
+                                         'own launches through round 4: +0.4 ms here, -0.65 ms in the token-wise family); the algorithmic flops are the attention\'s alone')
         if os.environ.get('TFX_BENCH_SHAPES'):                   # per GEMM shape (M, N, K, epilogue): launches / step, us / launch, TFLOP/s -> stderr
             bys = {}
             for e0, e1, work, fam, shape in events:
@@ -696,7 +699,7 @@ def main():
         # profiles/ (tools/pmc_traffic.sh; FETCH_SIZE x2 gfx950 correction applied there) - counters cannot be read in-process
         traffic, traffic_src = None, None
         pdir = os.path.join(ROOT, 'profiles')
-        for tname in ('r04_traffic.json', 'r03_traffic.json'):
+        for tname in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json'):
             tj = os.path.join(pdir, tname)
             if os.path.exists(tj) and (args.batch, args.dim, args.depth, args.two) == (64, 512, 8, False):
                 tr = json.load(open(tj))
