@@ -266,26 +266,29 @@ TFX_DEV void wave_block_store_nr(bf16* st, const bf16x4 (&v)[2][4], const tfx_at
     const bool live = row < rows_valid;
     float xv[8], qq = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; e++) { xv[e] = bf2f(x8[q][e]); qq += xv[e] * xv[e]; }
+    for (int e = 0; e < 8; e++) { xv[e] = bf2f(x8[q][e]); qq = fmaf(xv[e], xv[e], qq); }
     qq = group8_sum(qq);
-    const float nrm = fmaxf(sqrtf(qq), 1e-12f), inv = 1.f / nrm;
+    // (v_rsq / v_rcp forms: the epilogue runs inside two VALU-bound kernels - an IEEE divide is a ten-instruction sequence; 1 ulp against the token-wise kernel)
+    const float inv = qq > 1e-24f ? __builtin_amdgcn_rsqf(qq) : 1e12f;
+    const float isc = live ? inv * sc : 0.f;                        // rows past the end add nothing to the gain gradients
     float dyn[8], S = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const float da = bf2f(t[q][2 * i]), db = bf2f(t[q][2 * i + 1]);
-      const float ga = da * cs[q][i] + db * sn[q][i];                // inverse rotation
-      const float gb = db * cs[q][i] - da * sn[q][i];
+      const float ga = fmaf(db, sn[q][i], da * cs[q][i]);            // inverse rotation
+      const float gb = fmaf(-da, sn[q][i], db * cs[q][i]);
       const float gma = i < 2 ? g0[2 * i] : g1[2 * i - 4], gmb = i < 2 ? g0[2 * i + 1] : g1[2 * i - 3];
       const float ca = sc * (1.f + gma), cb = sc * (1.f + gmb);
-      if (live) { pg[2 * i] += ga * xv[2 * i] * (inv * sc); pg[2 * i + 1] += gb * xv[2 * i + 1] * (inv * sc); }
+      const float ta = ga * xv[2 * i], tb = gb * xv[2 * i + 1];     // shared by the gain gradient and by S = sum dyn x
+      pg[2 * i] = fmaf(ta, isc, pg[2 * i]); pg[2 * i + 1] = fmaf(tb, isc, pg[2 * i + 1]);
+      S = fmaf(ta, ca, S); S = fmaf(tb, cb, S);
       dyn[2 * i] = ga * ca; dyn[2 * i + 1] = gb * cb;
-      S += dyn[2 * i] * xv[2 * i] + dyn[2 * i + 1] * xv[2 * i + 1];
     }
     S = group8_sum(S);
     const float k = S * inv * inv * inv;
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = f2bf(dyn[e] * inv - xv[e] * k);
+    for (int e = 0; e < 8; e++) o[e] = f2bf(fmaf(dyn[e], inv, -(xv[e] * k)));
     if (live) *(bf16x8*)(p.nr_dqkv + (tok + row) * p.nr_ld_dqkv + colq + ch * 8) = o;
   }
 }
