@@ -446,11 +446,11 @@ def test_attention_bwd_with_fused_qk_norm_rope_bwd(b, h, n):
     (d0, gq0, gk0) = res[0]
     for tag, (d1, gq1, gk1) in zip(('atomics', 'scratch rows'), res[1:]):
         assert torch.isfinite(d1[:, :3 * HD + h].float()).all(), 'every d q | d k | d v | d gate element must have been written'
-        check(f'fused ({tag}): d q (raw)', d1[:, :HD], d0[:, :HD].float(), 2e-3)
-        check(f'fused ({tag}): d k (raw)', d1[:, HD:2 * HD], d0[:, HD:2 * HD].float(), 2e-3)
+        check(f'fused ({tag}): d q (raw)', d1[:, :HD], d0[:, :HD].float(), 2e-4)               # measured 0 ... 1e-5: a handful of one-ulp bf16 flips
+        check(f'fused ({tag}): d k (raw)', d1[:, HD:2 * HD], d0[:, HD:2 * HD].float(), 2e-4)       # measured 0 ... 2.4e-5
         assert torch.equal(d1[:, 2 * HD:3 * HD + h], d0[:, 2 * HD:3 * HD + h]), 'd v / d gate must not change'
-        check(f'fused ({tag}): d gamma_q', gq1, gq0, 2e-3)
-        check(f'fused ({tag}): d gamma_k', gk1, gk0, 2e-3)
+        check(f'fused ({tag}): d gamma_q', gq1, gq0, 2e-5)                                       # measured 1e-7 ... 3e-7 (summation order)
+        check(f'fused ({tag}): d gamma_k', gk1, gk0, 2e-5)
     assert torch.equal(res[1][0][:, :3 * HD + h], res[2][0][:, :3 * HD + h])        # (columns past the gates stay poisoned in every run)
 
 

@@ -531,9 +531,10 @@ def test_fused_qk_norm_rope_backward_equals_the_separate_launch(name, monkeypatc
         outs.append(out)
     ref, fus = outs
     assert abs(fus['loss'] - ref['loss']) <= 1e-6 * max(1., abs(ref['loss']))
-    # two runs of the SAME list already differ by up to ~2e-3 on small-norm gradients (fp32 atomics in the weight-gradient GEMMs, see the side-stream test);
-    # the fused form rounds d q~ | d k~ at the same point but takes 1 / |x| from v_rsq: measured worst 3e-3 ... 5.5e-3 (a layer-0 LayerNorm gain gradient of
-    # norm 2e-3, downstream of every layer's attention backward), norm-weighted mean 0.6e-3 ... 1.3e-3 - the size of the run-to-run spread itself
+    # At kernel level the two forms agree to 0 ... 2.4e-5 on d q | d k (tests/test_kernels_gpu.py: a handful of one-ulp bf16 flips).  What this test sees is what
+    # those flips and a different launch timing (fp32 atomics of the weight-gradient GEMMs and column sums arrive in another order; the side-stream test allows the
+    # same 2e-3 for IDENTICAL launches) do to small-norm gradients after 8 layers: worst 2.5e-3 (`small2`) / 5.5e-3 (`canon512`: a layer-0 LayerNorm gain gradient
+    # of norm 2e-3), norm-weighted mean 4.6e-4 / 1.2e-3
     errs = {k: rel(fus['grads'][k], ref['grads'][k]) for k in ref['grads']}
     norms = {k: float(ref['grads'][k].double().norm()) for k in ref['grads']}
     worst = max(errs.values())
