@@ -192,6 +192,17 @@ def test_bench_workload_matches_the_survey_definition():
     P = scan_batch(batch, num_modalities=1, dim_latents=(384,), sos_id=m.sos_id, eos_id=m.eos_id, meta_id=m.meta_id, som_ids=m.som_ids,
                    eom_ids=m.eom_ids, add_sos_eos=True)
     assert P.n_full == 1025 and P.total_tokens == 2 * 1025 and P.positions[0][0] == (0, 28, 4)
+    # BASELINE config 4 (`bench.py --config 4`): two modality types, even instances (0, (4,384)), odd ones (1, (2,192)), text fillers 25 (last 24):
+    # packs to 1025 tokens with positions [(0,29,4), (1,62,2), (0,93,4), ...] (the survey's probe), V = 392; mask-aware F_core = 670.7 GFLOP per sample
+    batch4 = bench.two_modality_batch(2, 'cpu', gen)
+    assert len(batch4[0]) == 64 and batch4[0][1][0] == 0 and batch4[0][1][1].shape == (4, 384) and batch4[0][3][0] == 1 and batch4[0][3][1].shape == (2, 192)
+    m4 = bench.build_model(64, 1, True)
+    assert m4.md.vocab == 392
+    P4 = scan_batch(batch4, num_modalities=2, dim_latents=(384, 192), sos_id=m4.sos_id, eos_id=m4.eos_id, meta_id=m4.meta_id, som_ids=m4.som_ids,
+                    eom_ids=m4.eom_ids, add_sos_eos=True)
+    assert P4.n_full == 1025 and P4.total_tokens == 2 * 1025 and list(P4.positions[0][:3]) == [(0, 29, 4), (1, 62, 2), (0, 93, 4)]
+    assert abs(bench.f_core_per_sample(768, 16, inst_lens=bench.inst_lens_of(True)) / 1e9 - 670.7) < 0.05
+    assert bench.CONFIGS[4] == dict(dim=768, depth=16, two=True) and bench.CONFIGS[3] == dict(dim=1024, depth=24, two=False)
 
 
 def test_default_times_match_reference_golden():
