@@ -1505,12 +1505,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
   __builtin_amdgcn_s_setprio(0);                                                                              \
   asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));   /* pin: LLVM may sink pure MFMAs past the barrier */
 
+#ifndef TFX_PP_BAL
+#define TFX_PP_BAL 0
+#endif
+  // TFX_PP_BAL=1 (round 5 experiment, `tools/build_variant.sh <name> WORK -DTFX_PP_BAL=1`; OFF): fragment reads balanced over the phases.  The schedule reads
+  // 12 / 4 / 8 / 0 fragments in phases 1 .. 4 - phase 1's 48 KiB per wave group is 384 LDS clocks against the partner group's 256-clock MFMA block.  With the
+  // switch B0 of the NEXT K-tile is read in phase 4 (8 / 4 / 8 / 4): it was issued a whole K-tile earlier, a counted wait ahead of phase 2's closing barrier
+  // (`vmcnt(4)`) certifies every wave's pieces of it, and phase 4's read segment lies two barriers behind that wait for both wave groups.  Correct (45 GEMM /
+  // golden tests), 244-251 registers, no spills - and SLOWER: NT family 10.55-10.68 against 10.43-10.51 ms per step, 8192 x 4096^2 1188 against 1233 TFLOP/s
+  // (same box, gpurun_out/r05n_ab.txt): phase 1's reads are not the long pole; the second counted wait and the 16 moves per K-tile cost more than they return.
+#if TFX_PP_BAL
+  bf16x8 b0[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) b0[ks] = ldB(0, 0, ks);
+#endif
   for (int kt = 0; kt < nk; kt++) {
+#if TFX_PP_BAL
+    bf16x8 a[2][4], b1[4], b0n[4];
+#else
     bf16x8 a[2][4], b0[4], b1[4];
+#endif
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
-    // ---- phase 1: read a0, b0 ; MFMA (a0, b0) + DMA A1(kt+1)
+    // ---- phase 1: read a0 (, b0) ; MFMA (a0, b0) + DMA A1(kt+1)
+#if !TFX_PP_BAL
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) b0[ks] = ldB(kt, 0, ks);
+#endif
 #pragma unroll
     for (int il = 0; il < 2; il++)
 #pragma unroll
@@ -1523,6 +1543,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
     for (int ks = 0; ks < 4; ks++) b1[ks] = ldB(kt, 1, ks);
     PP_BAR()
     PP_MFMA(0, 1, a, b1, if (n1) issueB1(kt + 1, 1, 0), if (n1) issueB1(kt + 1, 1, 1))
+#if TFX_PP_BAL
+    if (n1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // this wave's pieces of A0 / B0 of K-tile kt+1 have landed (issued in phases 3 / 4 of kt-1)
+#endif
     PP_BAR()
     // ---- phase 3: read a1 ; MFMA (a1, b1) + DMA A0(kt+2)
 #pragma unroll
@@ -1532,12 +1555,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
     PP_BAR()
     PP_MFMA(2, 1, a, b1, if (n2) issueA1(kt + 2, 0, 0), if (n2) issueA1(kt + 2, 0, 1))
     PP_BAR()
-    // ---- phase 4: certify K-tile kt+1 (only A0(kt+2) may still be outstanding) ; MFMA (a1, b0) + DMA B0(kt+2)
+    // ---- phase 4: (read B0 of K-tile kt+1 ;) certify K-tile kt+1 (only A0(kt+2) may still be outstanding) ; MFMA (a1, b0) + DMA B0(kt+2)
+#if TFX_PP_BAL
+    if (n1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) b0n[ks] = ldB(kt + 1, 0, ks);
+    }
+#endif
     if (n2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR()
     PP_MFMA(2, 0, a, b0, if (n2) issueB1(kt + 2, 0, 0), if (n2) issueB1(kt + 2, 0, 1))
     PP_BAR()
+#if TFX_PP_BAL
+    if (n1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) b0[ks] = b0n[ks];
+    }
+#endif
   }
 #undef PP_BAR
 #undef PP_MFMA
