@@ -1587,6 +1587,98 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
 #undef PP_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-wave-per-SIMD 256 x 256 x 64 NT kernel ("ow", round 5): 4 waves, each owns 128 x 128 of the tile = 16 accumulators of 32 x 32 in 256 AGPRs,
+// the shape of the vendor library's kernel for these GEMMs (8 fragment reads per 16 MFMAs instead of the ping-pong kernel's 12, no phase
+// barriers).  Round 4 built this shape under hipcc twice and landed on the ping-pong kernel's speed; here the K loop is ONE hand-scheduled
+// inline-asm block (gemm_nt_ow_loop.inc, written by tools/gen_nt_ow_loop.py - the schedule is documented there):
+//   * operands travel by LDS-DMA (`buffer_load_dwordx4 ... offen lds`): one lane offset per operand, the piece (16 rows further down) in a scalar
+//     offset, the LDS target in M0 - no vector address arithmetic in the loop (the ping-pong kernel forms a 64-bit address per piece);
+//   * the fragments of a WHOLE K-tile sit in registers (128 VGPRs), so an LDS buffer is free a quarter into its K-tile and K-tile kt+2 is
+//     fetched into it: two K-tiles in flight with two 64 KiB buffers;
+//   * two barriers per K-tile, each behind a wait whose operations were issued 100+ clocks earlier.
+// Same LDS layout (128-byte rows, 16-byte slot index XOR ((row >> 1) & 7)), same per-accumulator k order and same epilogues as the ping-pong
+// kernel: results are bit-identical to it (tests/test_kernels_gpu.py).  Not for row-gathered A, split A or the fused QK-norm epilogue (launch_ow).
+// ------------------------------------------------------------------------------------------------
+#define OW_ACC(n) "+a"(acc[(n) >> 3][((n) >> 1) & 3][(n) & 1])
+#define OW_ACC8(b) OW_ACC(b), OW_ACC(b + 1), OW_ACC(b + 2), OW_ACC(b + 3), OW_ACC(b + 4), OW_ACC(b + 5), OW_ACC(b + 6), OW_ACC(b + 7)
+#define OW_FR(n) "=&v"(fr[n])
+#define OW_FR8(b) OW_FR(b), OW_FR(b + 1), OW_FR(b + 2), OW_FR(b + 3), OW_FR(b + 4), OW_FR(b + 5), OW_FR(b + 6), OW_FR(b + 7)
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_ow_kernel(GemmNT p, int stagger, const float* gtab) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* lds = (bf16*)smem_raw;                                    // [2 K-tiles][A 256 rows x 64 | B 256 rows x 64], then (GEGLU forward) the 32 KiB GELU grid
+  dephase_first_round(stagger, 256);
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int ntn = (p.N + BN2 - 1) / BN2;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / ntn) * BM2, n0 = (bid % ntn) * BN2;
+
+  const float* gtab_lds = (const float*)(smem_raw + 2 * (BM2 + BN2) * BK * 2);      // (only dereferenced when the launch reserved it: gtab != nullptr)
+  if constexpr (EPI == EPI_GEGLU) {
+    if (gtab) {                                                   // issued ahead of K-tile 0: the DMAs retire in order, the loop's first wait covers the table
+#pragma unroll
+      for (int j = 0; j < 8; j++) glds16_asm((const bf16*)gtab + (size_t)(w * 8 + j) * 512 + l * 8, (const bf16*)gtab_lds + (w * 8 + j) * 512);
+    }
+  }
+  // DMA pieces: operand tile rows 16 j + 8 (w & 1) + (l >> 3) of the wave pair's half (w >> 1), j = 0 .. 7 - the slot swizzle ((row >> 1) & 7) is then the
+  // same for all eight pieces of a lane: ONE lane offset per operand.  Raw buffer resources: rows past M / N lie past num_records and read as zeros.
+  const uint32_t rowp = (uint32_t)((w >> 1) * 128 + 8 * (w & 1) + (l >> 3));
+  const uint32_t chunk = (uint32_t)((l & 7) ^ ((4 * (w & 1) + (l >> 4)) & 7));
+  uint32_t voA = (((uint32_t)m0 + rowp) * (uint32_t)p.lda + chunk * 8u) * 2u;
+  uint32_t voB = (((uint32_t)n0 + rowp) * (uint32_t)p.ldb + chunk * 8u) * 2u;
+  const uint64_t baseA = (uint64_t)(uintptr_t)p.A, baseB = (uint64_t)(uintptr_t)p.B;
+  u32x4 rsA, rsB;
+  rsA[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseA); rsA[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseA >> 32) & 0xffffu);
+  rsA[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 2u); rsA[3] = 0x00020000u;
+  rsB[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseB); rsB[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseB >> 32) & 0xffffu);
+  rsB[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.N - 1) * (uint32_t)p.ldb + (uint32_t)p.K) * 2u); rsB[3] = 0x00020000u;
+  const uint32_t stA = __builtin_amdgcn_readfirstlane(32u * (uint32_t)p.lda), stB = __builtin_amdgcn_readfirstlane(32u * (uint32_t)p.ldb);
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void_t*)lds;
+  uint32_t sM = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((w >> 1) * 16384 + (w & 1) * 1024));
+  uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)(p.K / BK)), so, delta = 65536u;
+  // fragment reads: row (l & 31) of 32-row block i, k-step ks -> slot (2 ks + hi) ^ ((l >> 1) & 7); block i is an immediate offset of 4 KiB
+  uint32_t raA[4], raB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    const uint32_t slot = (uint32_t)(((2 * ks + hi) ^ ((l >> 1) & 7)) << 4);
+    raA[ks] = lds0 + (uint32_t)((wr * 128 + (l & 31)) * 128) + slot;
+    raB[ks] = lds0 + (uint32_t)(BM2 * BK * 2 + (wc * 128 + (l & 31)) * 128) + slot;
+  }
+  if constexpr (EPI == EPI_QKNR) {                                 // (never launched: launch_ow)
+    if (p.qk_plan && blockIdx.x == 0 && w == 0) softcap_plan_write(p.qk_gamma_q, p.qk_gamma_k, p.qk_norm_scale, p.qk_q_scale, p.qk_softcap, p.qk_plan);
+  }
+
+  f32x16 acc[2][4][2];                                             // [column half][row block][column block of the half]: acc[h] is what nt_epilogue<EPI, 4> takes
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[h][i][j][r] = 0.f;
+  u32x4 fr[32];
+  asm volatile(
+#include "gemm_nt_ow_loop.inc"
+      : OW_ACC8(0), OW_ACC8(8), OW_FR8(0), OW_FR8(8), OW_FR8(16), OW_FR8(24),
+        "+v"(raA[0]), "+v"(raA[1]), "+v"(raA[2]), "+v"(raA[3]), "+v"(raB[0]), "+v"(raB[1]), "+v"(raB[2]), "+v"(raB[3]),
+        "+v"(voA), "+v"(voB), "+s"(sM), "+s"(cnt), "=&s"(so), "+s"(delta)
+      : "s"(rsA), "s"(rsB), "s"(stA), "s"(stB)
+      : "memory", "scc");
+
+  __builtin_amdgcn_s_barrier();                                     // every wave is done with the operand tiles: 16 KiB of staging space per call below
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+    nt_epilogue<EPI, 4>(p, acc[h], m0 + wr * 128, n0 + wc * 128 + h * 64, lds + (w * 2 + h) * 8192, gtab_lds, EPI == EPI_GEGLU && gtab != nullptr);
+}
+#undef OW_ACC
+#undef OW_ACC8
+#undef OW_FR
+#undef OW_FR8
+
 // TN with LDS-DMA (round 3: one template for every tiling).  A wave owns (32 FA) x (32 FB) of the output, WN x WK waves share a block tile
 // of (32 FA WN) x (32 FB WK); operands arrive as 32-row slabs of 128-column sub-slabs (swizzled [32][128] layout above) in an NST-slot ring,
 // NST - 1 slabs in flight, one barrier per slab.  Instantiated as
@@ -1905,6 +1997,29 @@ template <int EPI> static void launch_pp(const GemmNT& p, int grid, hipStream_t 
   if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
   hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), smem2, s, p, stagger, gtab);
 }
+// TFX_NT_OW: which shapes of the 256 x 256 family run on the one-wave-per-SIMD kernel: 0 none, 1 all of them, K (>= 64) = those with K >= that value.
+// Its loop reads both operands through raw buffer resources with 32-bit offsets and takes neither a row-gathered nor a split A.
+static int nt_ow_mode() {
+  static int ow = -1;
+  if (ow < 0) { const char* e = getenv("TFX_NT_OW"); ow = e ? atoi(e) : 0; }
+  return ow;
+}
+static bool nt_ow_takes(const GemmNT& p) {
+  const int ow = nt_ow_mode();
+  if (ow == 0 || (ow > 1 && p.K < ow) || p.a_rowmap || p.A2 || p.epi == EPI_QKNR) return false;
+  if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) != 0) return false;
+  const long long lim = 1ll << 32;
+  return ((long long)p.M + 2 * BM2) * p.lda * 2 < lim && ((long long)p.N + 2 * BN2) * p.ldb * 2 < lim;
+}
+template <int EPI> static void launch_ow(const GemmNT& p, int grid, hipStream_t s) {
+  static uint32_t attr_ow = 0;
+  const float* gtab = EPI == EPI_GEGLU ? gelu_table() : nullptr;
+  const int smem = 2 * (BM2 * BK + BN2 * BK) * 2 + (gtab ? GTAB_N * 8 : 0);
+  ensure_smem_attr((const void*)gemm_nt_ow_kernel<EPI>, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8, attr_ow);
+  static int stagger = -1;
+  if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
+  hipLaunchKernelGGL(gemm_nt_ow_kernel<EPI>, dim3(grid), dim3(256), smem, s, p, stagger, gtab);
+}
 template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const NtPlan pl = nt_plan(p);
   const int smem = 2 * (BM * BK + BN * BK) * 2;
@@ -1923,7 +2038,7 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
       hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sk, s, p);
       break;
     }
-    case NT_PP: launch_pp<EPI>(p, pl.grid, s); break;
+    case NT_PP: if (nt_ow_takes(p)) launch_ow<EPI>(p, pl.grid, s); else launch_pp<EPI>(p, pl.grid, s); break;
     case NT_MID: {
       static uint32_t attr_md = 0;
       const int smem_md = MD_ST * MD_STAGE * 2;
