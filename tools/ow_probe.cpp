@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdint>
+#include <cmath>
 #include <string>
 #include <vector>
 #include "../include/tfx.h"
@@ -106,7 +107,11 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("[run %s] TFX_NT_OW=%s\n", tag, getenv("TFX_NT_OW") ? getenv("TFX_NT_OW") : "(unset)");
   for (const Case& c : CASES) {
-    if (only && !strstr(c.name, only)) continue;
+    if (only) {                                              // comma-separated substrings
+      bool hit = false; std::string o(only); size_t b = 0;
+      while (b <= o.size()) { size_t e = o.find(',', b); if (e == std::string::npos) e = o.size(); if (e > b && strstr(c.name, o.substr(b, e - b).c_str())) hit = true; b = e + 1; }
+      if (!hit) continue;
+    }
     const int lda = c.K + c.lda_pad, ldb = c.K;
     std::vector<uint16_t> hA((size_t)c.M * lda), hB((size_t)c.N * ldb);
     fill_bf16(hA, 1 + c.M + c.K, 1.f); fill_bf16(hB, 7 + c.N + c.K, 0.05f);

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include <mutex>
 
 namespace tfx {
@@ -112,9 +113,10 @@ template <int EPI> struct EpiIn { };
 template <> struct EpiIn<EPI_RESID> { bf16x4 r[2][4]; };
 template <> struct EpiIn<EPI_GEGLU_BWD> { bf16x4 a[2][4], g[2][4]; };
 
+// (lane: the persistent kernel hands in an opaque copy of the lane id, so that hipcc does not hoist the lane-derived values out of its tile loop - and spill them)
 template <int EPI, int NI>
-TFX_DEV void fast_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w) {
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31;
+TFX_DEV void fast_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63), hi = l >> 5, r = l & 31;
   int mo[NI];
 #pragma unroll
   for (int i = 0; i < NI; i++) {
@@ -236,16 +238,19 @@ TFX_DEV void stage_put4(bf16* st, int row, int col, f32x4 v) {
   *(bf16x4*)(st + row * 64 + (((col >> 3) ^ ((row >> 1) & 7)) << 3) + (col & 7)) = o;
 }
 // C(bf16)[mo][n_w .. n_w+63] = acc + bias for the NI 32-row blocks of a wave; needs ldc % 8 == 0, N % 8 == 0, C 16-byte aligned
-template <int NI>
-TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st) {
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+// PLAIN (no row map, no bias): no load at all - and therefore no wait: hipcc puts the `s_waitcnt vmcnt(0)` of the (conditional) side loads on the common path, where it
+// drains whatever is in flight: the stores of a wave's previous 64-column half (one-wave-per-SIMD kernels: two calls per wave), the next tile's DMAs (persistent kernel)
+template <int NI, bool PLAIN = false>
+TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st, int lane = -1) {
+  const int l = lane >= 0 ? lane : (int)(threadIdx.x & 63), hi = l >> 5, r = l & 31, ch = l & 7;
   int mo[NI][4];                                               // output row of (block i, flush pass q): row q * 8 + (l >> 3)
 #pragma unroll
   for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int m = m_w + i * 32 + q * 8 + (l >> 3);
-      mo[i][q] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
+      if constexpr (PLAIN) mo[i][q] = m < p.M ? m : -1;
+      else mo[i][q] = m < p.M ? (p.rowmap ? p.rowmap[m] : m) : -1;
     }
   f32x4 bias[2][4];                                            // one branch around the eight loads (see fast_epilogue)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -253,11 +258,13 @@ TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w
   for (int j = 0; j < 2; j++)
 #pragma unroll
     for (int g = 0; g < 4; g++) bias[j][g] = zero4;
-  if (p.bias) {
+  if constexpr (!PLAIN) {
+    if (p.bias) {
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 2; j++)
 #pragma unroll
-      for (int g = 0; g < 4; g++) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
+        for (int g = 0; g < 4; g++) bias[j][g] = *(const f32x4*)(p.bias + min(n_w + j * 32 + 8 * g + 4 * hi, p.N - 4));
+    }
   }
   const bool col_ok = n_w + ch * 8 < p.N;
 #ifdef TFX_PP_TIMING
@@ -273,7 +280,7 @@ TFX_DEV void staged_epilogue_bf16(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w
       for (int g = 0; g < 4; g++) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] + bias[j][g][e];
+        for (int e = 0; e < 4; e++) v[e] = PLAIN ? acc[i][j][4 * g + e] : acc[i][j][4 * g + e] + bias[j][g][e];
         stage_put4(s, r, j * 32 + 8 * g + 4 * hi, v);
       }
     bf16x8 v[4];                                               // all four LDS reads ahead of the (branch-guarded) stores: one LDS latency per block, not four
@@ -708,9 +715,13 @@ template <int EPI> TFX_DEV bool can_stage(const GemmNT& p) {
 // epilogue of the LDS-DMA kernels: staged stores where the layout allows, else the direct pipelined form.
 // `st` = this wave's private LDS staging area (>= 12 KiB), valid once every wave has left the K loop.
 template <int EPI, int NI>
-TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st, const float* gtab = nullptr, bool use_tab = false) {
+TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w, bf16* st, const float* gtab = nullptr, bool use_tab = false, int lane = -1) {
   if constexpr (EPI == EPI_BF16) {
-    if (can_stage<EPI>(p)) { staged_epilogue_bf16<NI>(p, acc, m_w, n_w, st); return; }
+    if (can_stage<EPI>(p)) {
+      if (!p.rowmap && !p.bias) staged_epilogue_bf16<NI, true>(p, acc, m_w, n_w, st, lane);
+      else staged_epilogue_bf16<NI, false>(p, acc, m_w, n_w, st, lane);
+      return;
+    }
   } else if constexpr (EPI == EPI_F32) {
     if (((p.ldc | p.N) & 3) == 0 && (((uintptr_t)p.C) & 15) == 0) { staged_epilogue_f32<NI>(p, acc, m_w, n_w, st); return; }
   } else if constexpr (EPI == EPI_GEGLU || EPI == EPI_GEGLU_BWD) {
@@ -719,7 +730,7 @@ TFX_DEV void nt_epilogue(const GemmNT& p, f32x16 (&acc)[NI][2], int m_w, int n_w
     if (can_stage<EPI>(p)) { staged_epilogue_resid<NI>(p, acc, m_w, n_w, st); return; }
   }
   if constexpr (EPI == EPI_QKNR) staged_epilogue_qknr<NI>(p, acc, m_w, n_w, st);      // (the launcher only takes stageable layouts here: qknr_fusable)
-  else fast_epilogue<EPI, NI>(p, acc, m_w, n_w);
+  else fast_epilogue<EPI, NI>(p, acc, m_w, n_w, lane);
 }
 
 
@@ -1679,6 +1690,112 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_ow_kernel(GemmNT p, int stagge
 #undef OW_FR
 #undef OW_FR8
 
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the kernel above ("owp"): at most one block per CU walks its XCD's tiles, and the K-tile stream does not stop at a tile boundary -
+// the last two K-tiles of a tile fetch K-tiles 0 / 1 of the block's NEXT tile and the last one reads its first fragments, so the next tile's operands
+// travel (and its prologue's memory round trip passes) while this tile's epilogue runs; the accumulators of a tile start from the MFMA's inline-constant
+// zero (no zeroing pass).  What it removes per tile: the prologue (~3 k clocks of exposed latency), the block relaunch, the accumulator initialisation.
+// The operand buffers stay busy through the epilogue, so its staging area is the 32 KiB the two buffers leave of the CU's 160 KiB (8 KiB per wave):
+// epilogues that stage more (fp32, residual, GEGLU) run on the one-tile-per-block kernel.  Needs K >= 192 (three K-tiles).
+// ------------------------------------------------------------------------------------------------
+#define OWP_OPERANDS(ACC_C, F0_C)                                                                                                                  \
+      : OWP_A8(ACC_C, 0), OWP_A8(ACC_C, 8), OWP_F8(F0_C, 0), OWP_F8(F0_C, 8), OWP_F8("=&v", 16), OWP_F8("=&v", 24),                                 \
+        "+v"(raA[0]), "+v"(raA[1]), "+v"(raA[2]), "+v"(raA[3]), "+v"(raB[0]), "+v"(raB[1]), "+v"(raB[2]), "+v"(raB[3]),                             \
+        "+v"(voA), "+v"(voB), "+s"(sM), "+s"(cnt), "=&s"(so), "+s"(delta)                                                                           \
+      : "s"(rsA), "s"(rsB), "s"(stA), "s"(stB), "v"(voAn), "v"(voBn)                                                                                \
+      : "memory", "scc"
+#define OWP_A(C, n) C(acc[(n) >> 3][((n) >> 1) & 3][(n) & 1])
+#define OWP_A8(C, b) OWP_A(C, b), OWP_A(C, b + 1), OWP_A(C, b + 2), OWP_A(C, b + 3), OWP_A(C, b + 4), OWP_A(C, b + 5), OWP_A(C, b + 6), OWP_A(C, b + 7)
+#define OWP_F(C, n) C(fr[n])
+#define OWP_F8(C, b) OWP_F(C, b), OWP_F(C, b + 1), OWP_F(C, b + 2), OWP_F(C, b + 3), OWP_F(C, b + 4), OWP_F(C, b + 5), OWP_F(C, b + 6), OWP_F(C, b + 7)
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_owp_kernel(GemmNT p, int stagger, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* lds = (bf16*)smem_raw;                                    // [2 K-tiles][A 256 rows x 64 | B 256 rows x 64] + 4 x 8 KiB of epilogue staging
+  // block b runs on XCD b % 8 (private L2): every XCD owns a contiguous run of tile ids and deals them round-robin to its blocks, so the blocks
+  // of an XCD work on neighbouring tiles (shared operand panels) at any time
+  const int per = (int)gridDim.x >> 3, chunk = (ntiles + 7) >> 3;
+  int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  const int t_end = min(((int)(blockIdx.x & 7) + 1) * chunk, ntiles);
+  if (tile >= t_end) return;
+  dephase_first_round(stagger, 256);
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int ntn = (p.N + BN2 - 1) / BN2;
+  const uint64_t baseA = (uint64_t)(uintptr_t)p.A, baseB = (uint64_t)(uintptr_t)p.B;
+  u32x4 rsA, rsB;
+  rsA[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseA); rsA[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseA >> 32) & 0xffffu);
+  rsA[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 2u); rsA[3] = 0x00020000u;
+  rsB[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseB); rsB[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseB >> 32) & 0xffffu);
+  rsB[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.N - 1) * (uint32_t)p.ldb + (uint32_t)p.K) * 2u); rsB[3] = 0x00020000u;
+  const uint32_t stA = __builtin_amdgcn_readfirstlane(32u * (uint32_t)p.lda), stB = __builtin_amdgcn_readfirstlane(32u * (uint32_t)p.ldb);
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void_t*)lds;
+  uint32_t sM = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((w >> 1) * 16384 + (w & 1) * 1024));
+  const uint32_t nk = __builtin_amdgcn_readfirstlane((uint32_t)(p.K / BK));
+  uint32_t cnt = nk, so, delta = 65536u;
+  uint32_t raA[4], raB[4];
+  // fragment-read addresses in buffer `par` and the lane offsets of K-tile `kt` of tile (m0, n0): formed afresh for every asm statement (a dozen vector
+  // instructions) - kept alive across the epilogue they, and whatever else hipcc hoists above the K loop, spill and the reloads wait on the in-flight DMAs
+  auto lane_state = [&](int par, int m0_, int n0_, int kt, uint32_t& voA_, uint32_t& voB_) {
+    int lx = l;
+    asm volatile("" : "+v"(lx));                                    // opaque lane id: recomputed here, not carried (in scratch) around the tile loop
+    const int hx = lx >> 5;
+    const uint32_t rowx = (uint32_t)((w >> 1) * 128 + 8 * (w & 1) + (lx >> 3));      // (DMA pieces / lane offsets: see gemm_nt_ow_kernel)
+    const uint32_t chunkx = (uint32_t)((lx & 7) ^ ((4 * (w & 1) + (lx >> 4)) & 7)) * 8u;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const uint32_t slot = (uint32_t)(((2 * ks + hx) ^ ((lx >> 1) & 7)) << 4);
+      raA[ks] = lds0 + (uint32_t)(par * 65536 + (wr * 128 + (lx & 31)) * 128) + slot;
+      raB[ks] = lds0 + (uint32_t)(par * 65536 + BM2 * BK * 2 + (wc * 128 + (lx & 31)) * 128) + slot;
+    }
+    voA_ = (((uint32_t)m0_ + rowx) * (uint32_t)p.lda + chunkx + (uint32_t)(kt * BK)) * 2u;
+    voB_ = (((uint32_t)n0_ + rowx) * (uint32_t)p.ldb + chunkx + (uint32_t)(kt * BK)) * 2u;
+  };
+  bf16* stage = lds + 2 * (BM2 + BN2) * BK + w * 4096;             // this wave's 8 KiB behind the operand buffers
+  int m0 = (tile / ntn) * BM2, n0 = (tile % ntn) * BN2;
+  uint32_t voA, voB, voAn = 0, voBn = 0;
+  f32x16 acc[2][4][2];
+  u32x4 fr[32];
+  lane_state(0, m0, n0, 0, voA, voB);
+  asm volatile(
+#include "gemm_nt_owp_pro.inc"
+      OWP_OPERANDS("=&a", "=&v"));
+  // (scalar asm outputs that feed the next asm statement go through readfirstlane: the compiler's divergence analysis treats asm results as per-lane values)
+  sM = __builtin_amdgcn_readfirstlane(sM); delta = __builtin_amdgcn_readfirstlane(delta);
+  while (true) {
+    const int nxt = tile + per;
+    const bool has_next = nxt < t_end;                              // block-uniform
+    cnt = nk;
+    lane_state(delta == 65536u ? 0 : 1, m0, n0, 2, voA, voB);       // delta > 0: the tile's K-tile 0 sits in buffer 0
+    if (has_next) {
+      const int m1 = (nxt / ntn) * BM2, n1 = (nxt % ntn) * BN2;
+      voAn = voA + (uint32_t)((m1 - m0) * p.lda - 2 * BK) * 2u; voBn = voB + (uint32_t)((n1 - n0) * p.ldb - 2 * BK) * 2u;     // (voA / voB stand at K-tile 2 of this tile)
+      asm volatile(
+#include "gemm_nt_owp_next.inc"
+          OWP_OPERANDS("=&a", "=&v"));
+    } else {
+      voAn = voA; voBn = voB;                                       // (unused by this variant)
+      asm volatile(
+#include "gemm_nt_owp_last.inc"
+          OWP_OPERANDS("=&a", "=&v"));
+    }
+    sM = __builtin_amdgcn_readfirstlane(sM); delta = __builtin_amdgcn_readfirstlane(delta);
+    int me = m0, ne = n0, le = l;
+    asm volatile("" : "+s"(me), "+s"(ne), "+v"(le));                // opaque: nothing of the epilogue's address arithmetic moves above the K loop or out of the tile loop
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      nt_epilogue<EPI, 4>(p, acc[h], me + wr * 128, ne + wc * 128 + h * 64, stage, nullptr, false, le & 63);
+    if (!has_next) break;
+    tile = nxt; m0 = (tile / ntn) * BM2; n0 = (tile % ntn) * BN2;
+  }
+}
+#undef OWP_OPERANDS
+#undef OWP_A
+#undef OWP_A8
+#undef OWP_F
+#undef OWP_F8
+
 // TN with LDS-DMA (round 3: one template for every tiling).  A wave owns (32 FA) x (32 FB) of the output, WN x WK waves share a block tile
 // of (32 FA WN) x (32 FB WK); operands arrive as 32-row slabs of 128-column sub-slabs (swizzled [32][128] layout above) in an NST-slot ring,
 // NST - 1 slabs in flight, one barrier per slab.  Instantiated as
@@ -2011,6 +2128,25 @@ static bool nt_ow_takes(const GemmNT& p) {
   const long long lim = 1ll << 32;
   return ((long long)p.M + 2 * BM2) * p.lda * 2 < lim && ((long long)p.N + 2 * BN2) * p.ldb * 2 < lim;
 }
+// TFX_NT_OWP=0: every shape of the one-wave-per-SIMD family on the one-tile-per-block kernel (A/B)
+static bool nt_owp_takes(const GemmNT& p) {
+  static int owp = -1;
+  if (owp < 0) { const char* e = getenv("TFX_NT_OWP"); owp = e ? atoi(e) : 1; }
+  return owp != 0 && p.epi == EPI_BF16 && p.K >= 3 * BK && ((p.ldc | p.N) & 7) == 0 && (((uintptr_t)p.C) & 15) == 0;      // (the staged bf16 epilogue: 8 KiB per wave)
+}
+template <int EPI> static void launch_owp(const GemmNT& p, int tiles, hipStream_t s) {
+  static uint32_t attr_owp = 0;
+  const int smem = 2 * (BM2 * BK + BN2 * BK) * 2 + 4 * 8192;      // all 160 KiB of the CU
+  ensure_smem_attr((const void*)gemm_nt_owp_kernel<EPI>, smem, attr_owp);
+  static int stagger = -1;
+  if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
+  static int cus[16] = {0};
+  int dev = 0; (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (!cus[dev]) { hipDeviceProp_t pr; cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+  const int grid = std::min(cus[dev] / 8 * 8, (tiles + 7) / 8 * 8);
+  hipLaunchKernelGGL(gemm_nt_owp_kernel<EPI>, dim3(grid), dim3(256), smem, s, p, stagger, tiles);
+}
 template <int EPI> static void launch_ow(const GemmNT& p, int grid, hipStream_t s) {
   static uint32_t attr_ow = 0;
   const float* gtab = EPI == EPI_GEGLU ? gelu_table() : nullptr;
@@ -2038,7 +2174,11 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
       hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sk, s, p);
       break;
     }
-    case NT_PP: if (nt_ow_takes(p)) launch_ow<EPI>(p, pl.grid, s); else launch_pp<EPI>(p, pl.grid, s); break;
+    case NT_PP:
+      if (!nt_ow_takes(p)) launch_pp<EPI>(p, pl.grid, s);
+      else if constexpr (EPI == EPI_BF16) { if (nt_owp_takes(p)) launch_owp<EPI>(p, pl.grid, s); else launch_ow<EPI>(p, pl.grid, s); }
+      else launch_ow<EPI>(p, pl.grid, s);
+      break;
     case NT_MID: {
       static uint32_t attr_md = 0;
       const int smem_md = MD_ST * MD_STAGE * 2;
