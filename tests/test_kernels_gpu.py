@@ -63,6 +63,24 @@ def test_gemm_nt_bf16_bias(M, N, K):
     check(f'gemm_nt f32 {M}x{N}x{K}', C32, ref, 1e-5 * 50)
 
 
+def test_gemm_nt_one_wave_kernels_bit_identical_to_ping_pong():
+    """round 5: the one-wave-per-SIMD NT kernels (gemm_nt_ow_kernel: one tile per block; gemm_nt_owp_kernel: persistent, K-tile stream across tile boundaries;
+    hand-scheduled inline-asm K loops from tools/gen_nt_ow_loop.py) keep the ping-pong kernel's LDS layout, per-accumulator k order and epilogues: the same bits.
+    The library reads TFX_NT_OW once per process, so the cases run in two child processes (0 = ping-pong, 2 = every epilogue on the new kernels; TFX_NT_PP_MIN=1
+    sends the few-tile shapes to the 256 x 256 family) and the hashes of every output must agree."""
+    import subprocess, sys
+    outs = []
+    for mode in ('0', '2'):
+        env = dict(os.environ, TFX_NT_OW=mode, TFX_NT_PP_MIN='1')
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), '_nt_hash_child.py')], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith('CASE')])
+    assert len(outs[0]) == 12 and len(outs[0]) == len(outs[1])
+    for a, b in zip(*outs):
+        print(a)
+        assert a == b, f'ping-pong: {a}\none-wave:  {b}'
+
+
 def test_gemm_nt_asymmetric_identity():
     # transpose-detecting check: A = I, asymmetric B
     M = N = K = 128

@@ -8,7 +8,7 @@ tools/mfma_peak 2>/dev/null | grep -A2 "random" | head -3 >> $OUT
 export TFX_NT_PP_MIN=1
 for rep in 1 2; do
 for v in "$@"; do
-  if [ $v = pp ]; then L=transfusion_pytorch_amd/lib/libtfx_hip.so; OW=0; elif [ $v = base ]; then L=transfusion_pytorch_amd/lib/libtfx_hip.so; OW=1; else L=transfusion_pytorch_amd/lib/libtfx_$v.so; OW=1; fi
+  if [ $v = pp ]; then L=transfusion_pytorch_amd/lib/libtfx_hip.so; OW=0; elif [ $v = base ]; then L=transfusion_pytorch_amd/lib/libtfx_hip.so; OW=2; else L=transfusion_pytorch_amd/lib/libtfx_$v.so; OW=2; fi
   TFX_LIB=$L TFX_NT_OW=$OW timeout 200 tools/ow_probe run $v "$CASES" 2>&1 | grep -v "^\[run" | sed "s/^/rep$rep /" >> $OUT
 done
 done

@@ -2114,16 +2114,18 @@ template <int EPI> static void launch_pp(const GemmNT& p, int grid, hipStream_t 
   if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
   hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), smem2, s, p, stagger, gtab);
 }
-// TFX_NT_OW: which shapes of the 256 x 256 family run on the one-wave-per-SIMD kernel: 0 none, 1 all of them, K (>= 64) = those with K >= that value.
-// Its loop reads both operands through raw buffer resources with 32-bit offsets and takes neither a row-gathered nor a split A.
+// TFX_NT_OW: which launches of the 256 x 256 family run on the one-wave-per-SIMD kernels: 0 none (the ping-pong kernel), 1 (default) those that measured faster
+// there inside the training step (bf16 outputs; fp32 outputs from K = 1024), 2 every epilogue (A/B, tests).  Their loops read both operands through raw buffer resources with 32-bit offsets and take
+// neither a row-gathered nor a split A.
 static int nt_ow_mode() {
   static int ow = -1;
-  if (ow < 0) { const char* e = getenv("TFX_NT_OW"); ow = e ? atoi(e) : 0; }
+  if (ow < 0) { const char* e = getenv("TFX_NT_OW"); ow = e ? atoi(e) : 1; }
   return ow;
 }
 static bool nt_ow_takes(const GemmNT& p) {
   const int ow = nt_ow_mode();
-  if (ow == 0 || (ow > 1 && p.K < ow) || p.a_rowmap || p.A2 || p.epi == EPI_QKNR) return false;
+  if (ow == 0 || p.a_rowmap || p.A2 || p.epi == EPI_QKNR) return false;
+  if (ow == 1 && !(p.epi == EPI_BF16 || (p.epi == EPI_F32 && p.K >= 1024))) return false;
   if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) != 0) return false;
   const long long lim = 1ll << 32;
   return ((long long)p.M + 2 * BM2) * p.lda * 2 < lim && ((long long)p.N + 2 * BN2) * p.ldb * 2 < lim;
