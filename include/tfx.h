@@ -104,7 +104,8 @@ typedef struct {
 } tfx_gemm_tn_args;
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
 /* what tfx_gemm_tn would launch for these arguments, without launching (host logic only, no device needed): kernel form (-1 register-staged
- * fallback, 0 = 128 x 128 tiles / 4 waves, 2 = 256 x 256 / 8 waves), output tiles, row chunks (`splits`, chosen when a->splits == 0), grid. */
+ * fallback, 0 = 128 x 128 tiles / 4 waves, 2 = 256 x 256 / 8 waves, 3 = 256 x 256 / 4 waves of 128 x 128 (one wave per SIMD, round 5)), output tiles,
+ * row chunks (`splits`, chosen when a->splits == 0), grid. */
 int tfx_gemm_tn_plan(const tfx_gemm_tn_args* a, int32_t* kind, int32_t* tiles, int32_t* splits, int32_t* grid);
 
 /* ---- attention ------------------------------------------------------------------------------- */

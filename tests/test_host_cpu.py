@@ -365,15 +365,16 @@ def test_weight_gradient_gemm_plan_rule():
         return tuple(o.value for o in out)                    # kind, tiles, splits, grid
 
     T = 65536
-    assert plan(T, 2816, 512) == (2, 22, 11, 248)              # 242 blocks on 256 CUs (8 splits = 176, 12 = a second round)
-    assert plan(T, 1544, 512) == (2, 14, 17, 240)
-    assert plan(T, 512, 1408) == (2, 12, 20, 240)
+    # kind 3 (round 5) = the 256 x 256 tiling on the one-wave-per-SIMD kernel: same tiles, splits and grid as kind 2
+    assert plan(T, 2816, 512) == (3, 22, 11, 248)              # 242 blocks on 256 CUs (8 splits = 176, 12 = a second round)
+    assert plan(T, 1544, 512) == (3, 14, 17, 240)
+    assert plan(T, 512, 1408) == (3, 12, 20, 240)
     assert plan(T, 512, 512) == (0, 16, 16, 256)               # 4 tiles of 256 x 256: the 128 x 128 form at half of its 512 block slots
-    assert plan(T, 24576, 2048) == (2, 768, 1, 768)            # more tiles than slots: no split
-    assert plan(T, 5632, 1024) == (2, 88, 2, 176)              # 3 splits would open a second round
+    assert plan(T, 24576, 2048) == (3, 768, 1, 768)            # more tiles than slots: no split
+    assert plan(T, 5632, 1024) == (3, 88, 2, 176)              # 3 splits would open a second round
     assert plan(512, 512, 512)[2] == 2                         # chunks stay >= 256 rows
     assert plan(2112, 512, 512) == (0, 16, 8, 128)             # 8 chunks of 320 rows (264 rounded up to 64): the 8th starts at 2240 > M - tn_block clamps it to an empty range
-    assert plan(T, 1544, 512, splits=8) == (2, 14, 8, 112)     # explicit counts as given
+    assert plan(T, 1544, 512, splits=8) == (3, 14, 8, 112)     # explicit counts as given
     assert plan(1000, 200, 136)[0] == -1 and plan(T, 512, 512, a_rowmap=64)[0] == -1      # M % 64 != 0 / gathered rows: the register-staged kernel
     assert all(plan(T, n, k)[3] % 8 == 0 for n in (264, 520, 1544, 3080) for k in (384, 512, 768, 1024))
 

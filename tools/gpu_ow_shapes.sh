@@ -3,7 +3,7 @@
 TAG=$1; shift
 mkdir -p gpurun_out
 for m in "$@"; do
-  TFX_BENCH_SHAPES=1 TFX_NT_OW=$m python bench.py --steps 6 --warmup 3 --family-steps 3 --no-cpu-baseline --ragged-steps 0 --no-sample --no-other-configs --no-parity > /tmp/sh.log 2> /tmp/sh.err
-  grep "^\[shape\]" /tmp/sh.err | grep gemm_nt > gpurun_out/${TAG}_mode$m.txt
-  python -c "import json;d=json.loads(open('/tmp/sh.log').read().strip().splitlines()[-1]);print('mode $m', round(d['ms_per_step'],3),'ms/step', [ (f['kernel'][:12], round(f['ms_per_step'],2)) for f in d['roofline_by_family']])" | tee -a gpurun_out/${TAG}_mode$m.txt
+  env TFX_BENCH_SHAPES=1 $m python bench.py --steps 6 --warmup 3 --family-steps 3 --no-cpu-baseline --ragged-steps 0 --no-sample --no-other-configs --no-parity > /tmp/sh.log 2> /tmp/sh.err
+  grep "^\[shape\]" /tmp/sh.err > "gpurun_out/${TAG}_mode_${m// /_}.txt"
+  python -c "import json;d=json.loads(open('/tmp/sh.log').read().strip().splitlines()[-1]);print('mode $m', round(d['ms_per_step'],3),'ms/step', [ (f['kernel'][:12], round(f['ms_per_step'],2)) for f in d['roofline_by_family']])" | tee -a "gpurun_out/${TAG}_mode_${m// /_}.txt"
 done

@@ -2017,6 +2017,123 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
 #undef TN_CLK
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-wave-per-SIMD form of the 256 x 256 weight-gradient kernel ("tn ow", round 5): the plan of gemm_nt_ow_kernel - 4 waves x 128 x 128, 256 accumulator
+// AGPRs, the fragments of a whole 64-row step in registers (here FIXED registers v[64:191]: a fragment is two transposed 8-byte reads into the halves of
+// one MFMA operand), two 64 KiB LDS buffers fed by `buffer_load_dwordx4 ... lds` with two steps in flight, two barriers per step - in ONE generated
+// inline-asm block (gemm_tn_ow_loop.inc, tools/gen_tn_ow_loop.py).  Per MFMA it reads 0.5 KiB of fragments from LDS where the 8-wave kernel above reads
+// 0.75 KiB.  Same sub-slab layout, same accumulation order (rows in order, 16 per MFMA), same split-M atomics.  No dead-fragment skipping (ragged N / K
+// tiles compute on whatever the next rows hold and drop it at the store); the folded bias gradient is a second loop form (gemm_tn_ow_sum.inc) taken by
+// the waves of the first K columns.
+// Needs chunks of >= 192 rows in multiples of 64.
+// ------------------------------------------------------------------------------------------------
+#define OWT_OUT                                                                                                                                     \
+        "=&a"(acc[0][0]), "=&a"(acc[0][1]), "=&a"(acc[0][2]), "=&a"(acc[0][3]), "=&a"(acc[1][0]), "=&a"(acc[1][1]), "=&a"(acc[1][2]), "=&a"(acc[1][3]),    \
+        "=&a"(acc[2][0]), "=&a"(acc[2][1]), "=&a"(acc[2][2]), "=&a"(acc[2][3]), "=&a"(acc[3][0]), "=&a"(acc[3][1]), "=&a"(acc[3][2]), "=&a"(acc[3][3]),    \
+        "+v"(raA[0]), "+v"(raA[1]), "+v"(raA[2]), "+v"(raA[3]), "+v"(raB[0]), "+v"(raB[1]), "+v"(raB[2]), "+v"(raB[3]),                                     \
+        "+v"(voA), "+v"(voB), "+s"(sM), "+s"(cnt), "=&s"(so), "+s"(delta)
+#define OWT_IN "s"(rsA), "s"(rsB), "s"(stA), "s"(stB), "s"(ksA), "s"(ksB)
+#define OWT_CLOBBER                                                                                                                                 \
+        "memory", "scc",                                                                                                                            \
+        "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",                             \
+        "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",                             \
+        "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",                 \
+        "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",             \
+        "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143",             \
+        "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159",             \
+        "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175",             \
+        "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191"
+template <bool SUM>
+__global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* S = (bf16*)smem_raw;                                             // [2 steps][A sub-slabs 0, 1 | B sub-slabs 0, 1][64 rows x 128 columns]
+  const int t = threadIdx.x, l = t & 63, hi = l >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = w >> 1, wk = w & 1;
+  const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
+  const TnBlock blk = tn_block(p, ntn * ntk);
+  const int mbeg = blk.mbeg, mend = blk.mend;
+  const int n0 = (blk.tile / ntk) * 256, k0 = (blk.tile % ntk) * 256;
+  if (mend - mbeg < 192) return;                                         // (the launcher only sends chunks of >= 192 rows in multiples of 64)
+  // DMA pieces of a wave: sub-slab (w & 1) of each operand, rows 32 (w >> 1) + 4 j + (l >> 4), j = 0 .. 7; the lane fetches the 16-byte chunk its LDS slot holds
+  const uint32_t prow = (uint32_t)((w >> 1) * 32 + (l >> 4));
+  const uint32_t pchunk = (uint32_t)((l & 15) ^ (((l >> 4) & 3) << 2));
+  uint32_t voA = (((uint32_t)mbeg + prow) * (uint32_t)p.lda + (uint32_t)(n0 + (w & 1) * 128) + pchunk * 8u) * 2u;
+  uint32_t voB = (((uint32_t)mbeg + prow) * (uint32_t)p.ldb + (uint32_t)(k0 + (w & 1) * 128) + pchunk * 8u) * 2u;
+  const uint64_t baseA = (uint64_t)(uintptr_t)p.A, baseB = (uint64_t)(uintptr_t)p.B;
+  u32x4 rsA, rsB;
+  rsA[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseA); rsA[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseA >> 32) & 0xffffu);
+  rsA[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.a_cols) * 2u); rsA[3] = 0x00020000u;
+  rsB[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseB); rsB[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseB >> 32) & 0xffffu);
+  rsB[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * (uint32_t)p.ldb + (uint32_t)p.b_cols) * 2u); rsB[3] = 0x00020000u;
+  const uint32_t stA = __builtin_amdgcn_readfirstlane(8u * (uint32_t)p.lda), stB = __builtin_amdgcn_readfirstlane(8u * (uint32_t)p.ldb);          // 4 rows
+  const uint32_t ksA = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.lda), ksB = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ldb);     // 64 rows
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void_t*)S;
+  uint32_t sM = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((w & 1) * 16384 + (w >> 1) * 8192));
+  uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)((mend - mbeg) / 64)), so, delta = 65536u;
+  // fragment reads (lds_tr8_swz): 16-lane group g = l >> 4 reads the 4 rows x 16 columns block at rows 8 (g >> 1) + ..., columns 16 (g & 1) + ...; its lane
+  // q = l & 15 addresses row q >> 2, 4-column piece q & 3.  Column block i of the wave's sub-slab: chunk 4 i + 2 (g & 1) + ((q & 3) >> 1), XOR ((row & 3) << 2).
+  uint32_t raA[4], raB[4];
+  {
+    const int g = l >> 4, q = l & 15;
+    const int row = 8 * (g >> 1) + (q >> 2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int ch = (4 * i + 2 * (g & 1) + ((q & 3) >> 1)) ^ ((row & 3) << 2);
+      const uint32_t off = (uint32_t)(row * 256 + ch * 16 + (q & 1) * 8);
+      raA[i] = lds0 + (uint32_t)(wn * 16384) + off;
+      raB[i] = lds0 + 32768u + (uint32_t)(wk * 16384) + off;
+    }
+  }
+  f32x16 acc[4][4];
+  f32x16 accs[SUM ? 4 : 1];                                              // bias gradient: A^T x ones, on the waves of the first K columns
+  const bool do_sum = SUM && k0 == 0 && wk == 0;                         // wave-uniform; both loop forms pass the same barriers
+  if (do_sum) {
+    u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile(
+#include "gemm_tn_ow_sum.inc"
+        : OWT_OUT, "=&v"(accs[0]), "=&v"(accs[SUM ? 1 : 0]), "=&v"(accs[SUM ? 2 : 0]), "=&v"(accs[SUM ? 3 : 0])
+        : OWT_IN, "v"(ones)
+        : OWT_CLOBBER);
+  } else {
+    asm volatile(
+#include "gemm_tn_ow_loop.inc"
+        : OWT_OUT
+        : OWT_IN
+        : OWT_CLOBBER);
+  }
+
+  // output rows first, atomics after (see gemm_tn_wide_kernel): D[n][k], lane = column k, register r = row (r & 3) + 8 (r >> 2) + 4 hi
+  int out_col[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k = k0 + (wk * 4 + j) * 32 + (l & 31);
+    out_col[j] = k < p.k_valid ? tn_out_col(p, k) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int out_row[16];                                                     // (per 32-row block: 16 row-map loads in flight, then its 64 atomics)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int n = n0 + (wn * 4 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      out_row[r] = n >= p.N ? -1 : p.rowmap ? p.rowmap[n] : n;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int no = out_row[r];
+      if (no < 0) continue;
+      if (SUM && do_sum && (l & 31) == 0) atomicAdd(p.colsum + no, accs[SUM ? i : 0][r]);
+      float* crow = p.C + (size_t)no * p.ldc;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (out_col[j] >= 0) atomicAdd(crow + out_col[j], acc[i][j][r] * p.alpha);
+    }
+  }
+}
+#undef OWT_OUT
+#undef OWT_IN
+#undef OWT_CLOBBER
+
 // split count of a TN launch with `tiles` output tiles over M rows (tfx.h: splits == 0): the smallest count that puts `fill` x (resident block
 // slots) blocks on the chip, never more than one round of blocks.  Measured in the training step (profiles/r03_c_tn_splits.txt, one stream):
 // 256 x 256 tiles - 2816 x 512 (22 tiles) 256 / 225 / 220 / 215 us at 154 / 198 / 220 / 242 blocks and 341 us at 264 (a second round);
@@ -2276,6 +2393,17 @@ static TnPlan tn_plan(const GemmTN& q) {
   pl.tiles = pl.kind == 2 ? t44 : t22;
   pl.splits = q.splits == 0 ? tn_auto_splits(q.M, pl.tiles, pl.kind) : q.splits;
   pl.grid = (pl.tiles * pl.splits + 7) / 8 * 8;                   // tn_block: 8 equal runs of (chunk, tile) pairs, one per XCD
+  // kind 3: the 256 x 256 launches that the one-wave-per-SIMD kernel takes (TFX_TN_OW=0: none): 32-bit operand offsets, every chunk
+  // >= 192 rows in multiples of 64.  Ragged N / K tiles included: the kernel computes their dead fragments too and still measured 10-13 % faster on
+  // 1544 x 512 and 512 x 1408 (gpurun_out/ow9_tn.txt)
+  static int tnow = -1;
+  if (tnow < 0) { const char* e = getenv("TFX_TN_OW"); tnow = e ? atoi(e) : 1; }
+  if (tnow && pl.kind == 2 && q.M % 64 == 0 && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0) {
+    const int chunk = ((q.M + pl.splits - 1) / pl.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
+    const int last = q.M % chunk == 0 ? chunk : q.M % chunk;      // rows of the last non-empty chunk (trailing empty chunks: the kernel returns on them)
+    const long long lim = 1ll << 32;
+    if (chunk >= 192 && last >= 192 && (long long)(q.M + 64) * q.lda * 2 < lim && (long long)(q.M + 64) * q.ldb * 2 < lim && q.a_cols >= q.N && q.b_cols >= q.K) pl.kind = 3;
+  }
   return pl;
 }
 int gemm_tn_plan(const GemmTN& p, int* kind, int* tiles, int* splits, int* grid) {
@@ -2295,7 +2423,17 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   const TnPlan pl = tn_plan(q);
   q.splits = pl.splits;
   const int kind = pl.kind, grid = pl.grid;
-  if (kind == 2) {
+  if (kind == 3) {
+    static uint32_t attr_tnow = 0;
+    if (q.colsum) {
+      static uint32_t attr_tnows = 0;
+      ensure_smem_attr((const void*)gemm_tn_ow_kernel<true>, 131072, attr_tnows);
+      hipLaunchKernelGGL(gemm_tn_ow_kernel<true>, dim3(grid), dim3(256), 131072, s, q);
+    } else {
+      ensure_smem_attr((const void*)gemm_tn_ow_kernel<false>, 131072, attr_tnow);
+      hipLaunchKernelGGL(gemm_tn_ow_kernel<false>, dim3(grid), dim3(256), 131072, s, q);
+    }
+  } else if (kind == 2) {
     if (q.colsum) launch_tn_wide<true, 2, 4, 4, 2, 4>(q, grid, s);
     else launch_tn_wide<false, 2, 4, 4, 2, 4>(q, grid, s);
   } else if (kind == 0) {
