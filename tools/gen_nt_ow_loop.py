@@ -9,22 +9,26 @@ in the 32-clock gaps between the MFMAs of a lone wave (one wave per SIMD, 128 x 
 re-serialises such a loop (LAB_NOTEBOOK round 4: two hipcc-scheduled kernels of this shape landed on the ping-pong kernel's speed).
 
 Schedule of one K-tile (gap g = the slot behind MFMA g; P = the LDS buffer of K-tile kt, Q = the other one):
-   g 0..15   read the fragments of the K-tile's second half (k-steps 2, 3) from P            -> every read of P is issued
-   g 18/19   lgkmcnt(0) ; s_barrier                                                          -> nobody reads P any more
-   g 20..42  12 LDS-DMA pieces of K-tile kt+2 into P, one per two gaps (A pieces first: they come from HBM, B = weights from L2)
-   g 21..35  (odd) the 8 fragment-read addresses move from P to Q
-   g 43/44   vmcnt(12) ; s_barrier                                                           -> K-tile kt+1 has landed in Q, for every wave
-   g 45..60  read the fragments of K-tile kt+1's first half (k-steps 0, 1) from Q ; the last 4 DMA pieces at g 46 / 49 / 52 / 55
-   g 56..60  lane offsets, DMA target, K-tile counter
-   g 62      lgkmcnt(0)
+   g 0..7    read the A fragments of the K-tile's second half (k-steps 2, 3) from P
+   g 10/11   lgkmcnt(0) ; s_barrier                                                          -> nobody reads P's A tile any more
+   g 12..33  the 8 A pieces of K-tile kt+2 into P by LDS-DMA, one per three gaps (A first: it comes from HBM, B = weights from L2)
+   g 12..19  read the B fragments of the second half ; g 22/23 lgkmcnt(0) ; s_barrier        -> nobody reads P any more
+   g 25..39  (odd) the 8 fragment-read addresses move from P to Q
+   g 36..57  the 8 B pieces, one per three gaps
+   g 43/44   vmcnt(<pieces issued so far>) ; s_barrier                                       -> K-tile kt+1 has landed in Q, for every wave
+   g 45..60  read the fragments of K-tile kt+1's first half (k-steps 0, 1) from Q
+   g 58..62  lane offsets, DMA target, K-tile counter ; lgkmcnt(0)
+(`--nosplit`: one barrier behind all sixteen second-half reads, DMA pieces from g 20 on - the first form, 2-3 % slower on the long-K shapes.)
 Fragments of a whole K-tile live in registers (2 x 16 x 4 VGPRs), which is what frees P for the DMA of K-tile kt+2 a quarter into K-tile kt:
 two K-tiles stay in flight with two 64 KiB LDS buffers.
 """
 import argparse
 import os
 
-OPT = argparse.Namespace(nodma=False, noread=False, reads0_per_gap=1, reads1_per_gap=1, wait1=18, bar1=19, dma_start=20, dma_step=2, n_before=12,
-                         late_start=46, late_step=3, wait2=43, bar2=44, reads0_start=45, split=False, wait1b=22, bar1b=23, nobar=False, nosalu=False)
+# defaults = the schedule that measured best in the power-limited steady state (gpurun_out/ow20.txt, ow21.txt: the split form -2.6 % on K >= 1408 shapes, -3 % on
+# 1544 x 512 against one barrier behind all sixteen second-half reads; `--nosplit` restores that form)
+OPT = argparse.Namespace(nodma=False, noread=False, reads0_per_gap=1, reads1_per_gap=1, wait1=10, bar1=11, dma_start=20, dma_step=3, n_before=12,
+                         late_start=46, late_step=3, wait2=43, bar2=44, reads0_start=45, split=True, wait1b=22, bar1b=23, nobar=False, nosalu=False, nosplit=False)
 
 # ---- operand numbers (must match OW_ASM_OPERANDS in gemm.hip) ----
 def ACC(i, j):            # accumulator of row block i (A), column block j (B): acc[j >> 1][i][j & 1]
@@ -111,7 +115,7 @@ def body(kind, zero=False, loop="L_ow_steady_%=", nof0=False):
         fill[o.bar1b].append("s_barrier")
     else:
         put_reads(r1, 0, o.reads1_per_gap)
-        fill[o.wait1].append("s_waitcnt lgkmcnt(0)")         # second-half fragments landed (needed from MFMA 32 on)
+        fill[o.wait1 if not o.split else 18].append("s_waitcnt lgkmcnt(0)")      # ALL second-half fragments landed (needed from MFMA 32 on; the reads end at gap 15)
     tog0 = (o.bar1b if o.split else o.bar1) + 2
     if kind == 'steady':
         if not o.split: fill[o.bar1].append("s_barrier")     # every wave has read P for the last time
@@ -256,10 +260,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     for k, v in vars(OPT).items():
-        if isinstance(v, bool): ap.add_argument("--" + k.replace("_", "-"), action="store_true")
+        if isinstance(v, bool): ap.add_argument("--" + k.replace("_", "-"), action="store_true", default=v)
         else: ap.add_argument("--" + k.replace("_", "-"), type=int, default=v)
     a = ap.parse_args()
     for k in vars(OPT): setattr(OPT, k, getattr(a, k))
+    if OPT.nosplit: OPT.split, OPT.wait1, OPT.bar1, OPT.dma_step = False, 18, 19, 2
     here = os.path.dirname(os.path.abspath(__file__))
     out = a.out or os.path.join(here, "..", "transfusion_pytorch_amd", "csrc", "gemm_nt_ow_loop.inc")
     write_inc(out, program(), "one tile per block")

@@ -29,7 +29,9 @@ def FA(i, ks): return F0 + (ks >> 1) * 64 + (ks & 1) * 16 + i * 4          # v[F
 def FB(j, ks): return F0 + (ks >> 1) * 64 + 32 + (ks & 1) * 16 + j * 4
 def vr(a, n): return f"v[{a}:{a + n - 1}]"
 
-OPT = argparse.Namespace(wait1=18, bar1=19, dma_start=20, dma_step=2, n_before=12, late_start=46, late_step=3, wait2=43, bar2=44, reads0_start=45)
+# defaults: the split form of the NT loop (A sub-slabs released and re-filled before the B fragments are read; DMA pieces three gaps apart): +3 ... 4.6 % on the larger
+# products, neutral on the small ones (gpurun_out/ow22.txt); `--split 0 --wait1 18 --bar1 19 --dma-step 2` = one barrier behind all second-half reads
+OPT = argparse.Namespace(wait1=10, bar1=11, dma_start=20, dma_step=3, n_before=12, late_start=46, late_step=3, wait2=43, bar2=44, reads0_start=45, split=1, wait1b=22, bar1b=23)
 
 def mfma(m, zero=False):
     half, r = divmod(m, 32)
@@ -75,17 +77,39 @@ def body(kind, zero=False, loop=None):
     fill = [[] for _ in range(64)]
     def put_reads(reads, g0):
         for q, r in enumerate(reads): fill[g0 + q // 2].append(r)
-    put_reads(frag_reads(1), 0)
-    fill[o.wait1].append("s_waitcnt lgkmcnt(0)")
-    if kind == 'steady':
+    r1 = frag_reads(1)
+    split = o.split and kind == 'steady'
+    if split:            # (the NT loop's split form: the A sub-slabs are released - and re-filled - before the B fragments are read)
+        ra = [r for r in r1 if any(f"%{RA(i)}" in r.split(",")[1] for i in range(4))]
+        rb = [r for r in r1 if r not in ra]
+        assert len(ra) == 16 and len(rb) == 16
+        put_reads(ra, 0)
+        fill[o.wait1].append("s_waitcnt lgkmcnt(0)")
         fill[o.bar1].append("s_barrier")
-        gaps = [o.dma_start + o.dma_step * d if d < o.n_before else o.late_start + o.late_step * (d - o.n_before) for d in range(16)]
+        put_reads(rb, o.bar1 + 1)
+        fill[o.wait1b].append("s_waitcnt lgkmcnt(0)")
+        fill[o.bar1b].append("s_barrier")
+    else:
+        put_reads(r1, 0)
+        fill[18 if o.split else o.wait1].append("s_waitcnt lgkmcnt(0)")
+    tog0 = (o.bar1b if o.split else o.bar1) + 2
+    if kind == 'steady':
+        if not split: fill[o.bar1].append("s_barrier")
+        if split:
+            g, gaps = o.bar1 + 1, []
+            for d in range(16):
+                if d == 8: g = max(g, o.bar1b + 1)
+                gaps.append(g); g += o.dma_step
+        else:
+            gaps = [o.dma_start + o.dma_step * d if d < o.n_before else o.late_start + o.late_step * (d - o.n_before) for d in range(16)]
+        assert all(b > a for a, b in zip(gaps, gaps[1:])) and gaps[-1] <= 57, gaps
         for d, g in enumerate(gaps):
             prep, issue = dma(d)
             fill[g - 1] = prep + fill[g - 1] if g - 1 == o.bar1 else fill[g - 1] + prep
             fill[g].append(issue)
         for q, tg in enumerate(toggles()):
-            fill[o.bar1 + 2 + 2 * q].append(tg)
+            fill[tog0 + 2 * q].append(tg)
+        assert tog0 + 14 < o.reads0_start
         n_before = sum(1 for g in gaps if g <= o.wait2)
         fill[o.wait2].append(f"s_waitcnt vmcnt({n_before})")
         fill[o.bar2].append("s_barrier")
@@ -102,7 +126,7 @@ def body(kind, zero=False, loop=None):
             fill[63].append(f"s_cbranch_scc1 {loop}")
     elif kind == 't1':
         for q, tg in enumerate(toggles()):
-            fill[o.bar1 + 2 + 2 * q].append(tg)
+            fill[tog0 + 2 * q].append(tg)
         fill[o.wait2].append("s_waitcnt vmcnt(0)")
         fill[o.bar2].append("s_barrier")
         put_reads(frag_reads(0), o.reads0_start)
