@@ -75,7 +75,7 @@ def test_gemm_nt_one_wave_kernels_bit_identical_to_ping_pong():
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), '_nt_hash_child.py')], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith('CASE')])
-    assert len(outs[0]) == 12 and len(outs[0]) == len(outs[1])
+    assert len(outs[0]) == 13 and len(outs[0]) == len(outs[1])
     for a, b in zip(*outs):
         print(a)
         assert a == b, f'ping-pong: {a}\none-wave:  {b}'
