@@ -402,3 +402,29 @@ def test_nt_gemm_kernel_selection():
     assert plan(64, 5632, 128)[1] == SKINNY                    # K < 8 x 32: no K split
     assert plan(T, 1546, 512)[1] == FALLBACK                   # N % 4 != 0
     assert plan(T, 512, 500)[0] == -1                          # K % 64 != 0 is refused
+
+
+def test_generated_asm_loops_match_their_generators(tmp_path):
+    """round 5: the K loops of the one-wave-per-SIMD GEMM kernels are generated inline-asm text (tools/gen_nt_ow_loop.py, tools/gen_tn_ow_loop.py), committed under
+    csrc/ so that a build needs no generator run.  The committed files must be what the generators write today (an edit to one without the other would ship a
+    stale schedule), every body must hold its 64 MFMAs per K-tile, and the loop's back branch must be the LAST instruction of its body (the one bug of the
+    session: a bias-gradient MFMA emitted behind the branch)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, 'transfusion_pytorch_amd', 'csrc')
+    for gen, first in (('gen_nt_ow_loop.py', 'gemm_nt_ow_loop.inc'), ('gen_tn_ow_loop.py', 'gemm_tn_ow_loop.inc')):
+        subprocess.run([sys.executable, os.path.join(root, 'tools', gen), '--out', str(tmp_path / first)], check=True, capture_output=True)
+    made = sorted(os.listdir(tmp_path))
+    assert made == ['gemm_nt_ow_loop.inc', 'gemm_nt_owp_last.inc', 'gemm_nt_owp_next.inc', 'gemm_nt_owp_pro.inc', 'gemm_tn_ow_loop.inc', 'gemm_tn_ow_sum.inc']
+    for name in made:
+        new, old = open(tmp_path / name).read(), open(os.path.join(csrc, name)).read()
+        assert new == old, f'{name}: committed file differs from its generator\'s output'
+        lines = [ln.strip().strip('"').replace('\\n\\t', '') for ln in old.splitlines() if ln.startswith('"')]
+        n_mfma = sum(ln.startswith('v_mfma') for ln in lines)
+        if name != 'gemm_nt_owp_pro.inc':
+            per_body = 80 if name == 'gemm_tn_ow_sum.inc' else 64
+            assert n_mfma % per_body == 0 and n_mfma >= 3 * per_body, (name, n_mfma)
+        for i, ln in enumerate(lines):
+            if ln.startswith('s_cbranch_scc1') and ('_loop_' in ln or '_steady_' in ln):      # a back branch: nothing of the body may follow it
+                nxt = lines[i + 1]
+                assert nxt.endswith(':') , (name, ln, nxt)
