@@ -101,6 +101,10 @@ typedef struct {
                                  folded into the GEMM (one extra MFMA against a ones operand in the blocks of the first K tile) */
   int32_t k_group;            /* 0 = off; else the K columns come in groups of 64 of which the first k_group are written, compacted:
                                  C column = (k / 64) * k_group + k % 64  (per-head padded operand -> unpadded weight gradient) */
+  /* optional second B source for the product columns k >= K1 (round 5): C[N, K] = A^T [B | B2] - the weight gradient of the U-Net skip projection over
+   * cat(x, skip) (reference T:1214-1219) as ONE product with 8 tiles of 256 x 256 instead of two with 4 each.  B then holds K1 columns, B2 the other K - K1
+   * (ldb2 >= K - K1, % 8 == 0); K1 % 256 == 0, k_group == 0.  B2 == NULL: off. */
+  const tfx_bf16* B2; int32_t ldb2; int32_t K1;
 } tfx_gemm_tn_args;
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
 /* what tfx_gemm_tn would launch for these arguments, without launching (host logic only, no device needed): kernel form (-1 register-staged

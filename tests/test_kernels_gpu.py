@@ -332,6 +332,26 @@ def test_gemm_tn_folded_bias_gradient_and_head_compaction(M, N, K, splits, kg):
     check(f'gemm_tn colsum/k_group bias grad {M}x{N}x{K}', bias, bref, 5e-3)
 
 
+@pytest.mark.parametrize('M,N,K,K1,splits,want_kind', [(8192, 512, 1024, 512, 0, 3), (4096, 768, 1536, 768, 4, 3), (4096, 512, 1024, 512, 64, None),
+                                                        (1000, 200, 272, 136, 2, None), (2048, 384, 768, 384, 0, None)])
+def test_gemm_tn_split_b(M, N, K, K1, splits, want_kind):
+    """round 5: `B2` / `K1` - C[N, K] = A^T [B | B2], the weight gradient of the U-Net skip projection over cat(x, skip) (reference T:1214-1219) as ONE product.
+    K1 % 256 == 0 on the one-wave kernel (plan kind 3: a block picks its B source by its tile); every other case (chunks under 192 rows, K1 off the tile grid,
+    M % 64 != 0) runs as the two products inside the library - same result either way, against fp32 torch on the concatenated operand."""
+    torch.manual_seed(8)
+    A = rnd(M, N, scale=0.5); B = rnd(M, K1, scale=0.5); ld2 = K - K1 + 8; B2 = rnd(M, ld2, scale=0.5)
+    C = torch.zeros(N, K, device=DEV); bias = torch.zeros(N, device=DEV)
+    a = capi.make_args('tfx_gemm_tn_args', A=A, lda=N, a_cols=N, B=B, ldb=K1, b_cols=K1, B2=B2, ldb2=ld2, K1=K1, M=M, N=N, K=K, C=C, ldc=K, k_valid=K,
+                       splits=splits, accumulate=1, alpha=1.0, colsum=bias)
+    if want_kind is not None:
+        out = [ctypes.c_int32(-9) for _ in range(4)]
+        assert capi.lib().tfx_gemm_tn_plan(ctypes.byref(a), *[ctypes.byref(o) for o in out]) == 0 and out[0].value == want_kind, [o.value for o in out]
+    capi.call('tfx_gemm_tn', a, stream())
+    ref = A.float().T @ torch.cat([B, B2[:, :K - K1]], 1).float()
+    check(f'gemm_tn split-B {M}x{N}x{K} (K1 {K1})', C, ref, 5e-3)
+    check(f'gemm_tn split-B bias grad {M}x{N}x{K}', bias, A.float().sum(0), 5e-3)
+
+
 # ---------------------------------------------------------------------------------------------- attention
 def make_kv_end(b, n, seed=0):
     g = torch.Generator().manual_seed(seed)

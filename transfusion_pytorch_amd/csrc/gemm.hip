@@ -2059,15 +2059,18 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p) {
   const uint32_t prow = (uint32_t)((w >> 1) * 32 + (l >> 4));
   const uint32_t pchunk = (uint32_t)((l & 15) ^ (((l >> 4) & 3) << 2));
   uint32_t voA = (((uint32_t)mbeg + prow) * (uint32_t)p.lda + (uint32_t)(n0 + (w & 1) * 128) + pchunk * 8u) * 2u;
-  uint32_t voB = (((uint32_t)mbeg + prow) * (uint32_t)p.ldb + (uint32_t)(k0 + (w & 1) * 128) + pchunk * 8u) * 2u;
-  const uint64_t baseA = (uint64_t)(uintptr_t)p.A, baseB = (uint64_t)(uintptr_t)p.B;
+  // split B (tfx.h: B2 / K1): the tile's product columns come from ONE of the two sources (K1 % 256 == 0), a block-uniform choice of base, leading dimension and width
+  const bool second = p.B2 != nullptr && k0 >= p.K1;
+  const uint32_t ldb = (uint32_t)(second ? p.ldb2 : p.ldb), bcols = (uint32_t)(second ? p.K - p.K1 : p.b_cols), kb = (uint32_t)(second ? k0 - p.K1 : k0);
+  uint32_t voB = (((uint32_t)mbeg + prow) * ldb + kb + (uint32_t)((w & 1) * 128) + pchunk * 8u) * 2u;
+  const uint64_t baseA = (uint64_t)(uintptr_t)p.A, baseB = (uint64_t)(uintptr_t)(second ? p.B2 : p.B);
   u32x4 rsA, rsB;
   rsA[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseA); rsA[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseA >> 32) & 0xffffu);
   rsA[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.a_cols) * 2u); rsA[3] = 0x00020000u;
   rsB[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseB); rsB[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseB >> 32) & 0xffffu);
-  rsB[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * (uint32_t)p.ldb + (uint32_t)p.b_cols) * 2u); rsB[3] = 0x00020000u;
-  const uint32_t stA = __builtin_amdgcn_readfirstlane(8u * (uint32_t)p.lda), stB = __builtin_amdgcn_readfirstlane(8u * (uint32_t)p.ldb);          // 4 rows
-  const uint32_t ksA = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.lda), ksB = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ldb);     // 64 rows
+  rsB[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * ldb + bcols) * 2u); rsB[3] = 0x00020000u;
+  const uint32_t stA = __builtin_amdgcn_readfirstlane(8u * (uint32_t)p.lda), stB = __builtin_amdgcn_readfirstlane(8u * ldb);          // 4 rows
+  const uint32_t ksA = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.lda), ksB = __builtin_amdgcn_readfirstlane(128u * ldb);     // 64 rows
   const uint32_t lds0 = (uint32_t)(size_t)(lds_void_t*)S;
   uint32_t sM = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((w & 1) * 16384 + (w >> 1) * 8192));
   uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)((mend - mbeg) / 64)), so, delta = 65536u;
@@ -2402,7 +2405,10 @@ static TnPlan tn_plan(const GemmTN& q) {
     const int chunk = ((q.M + pl.splits - 1) / pl.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
     const int last = q.M % chunk == 0 ? chunk : q.M % chunk;      // rows of the last non-empty chunk (trailing empty chunks: the kernel returns on them)
     const long long lim = 1ll << 32;
-    if (chunk >= 192 && last >= 192 && (long long)(q.M + 64) * q.lda * 2 < lim && (long long)(q.M + 64) * q.ldb * 2 < lim && q.a_cols >= q.N && q.b_cols >= q.K) pl.kind = 3;
+    const bool b_ok = q.B2 ? (q.K1 % 256 == 0 && q.K1 > 0 && q.K1 < q.K && q.b_cols >= q.K1 && q.ldb2 >= q.K - q.K1 && (q.ldb2 & 7) == 0 && ((uintptr_t)q.B2 & 15) == 0 && q.k_group == 0 &&
+                                  (long long)(q.M + 64) * q.ldb2 * 2 < lim)
+                           : q.b_cols >= q.K;
+    if (chunk >= 192 && last >= 192 && (long long)(q.M + 64) * q.lda * 2 < lim && (long long)(q.M + 64) * q.ldb * 2 < lim && q.a_cols >= q.N && b_ok) pl.kind = 3;
   }
   return pl;
 }
@@ -2421,6 +2427,15 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   ensure_smem_attr((const void*)gemm_tn_kernel, smem, attr_set);
   GemmTN q = p;
   const TnPlan pl = tn_plan(q);
+  if (p.B2 && pl.kind != 3) {                                   // split B on the other kernels: the two products, one after the other
+    if (p.K1 <= 0 || p.K1 >= p.K || p.k_group != 0 || (p.ldb2 & 7)) return -6;
+    GemmTN a = p, b = p;
+    a.B2 = nullptr; a.K = p.K1; a.k_valid = std::min(p.k_valid, p.K1);
+    b.B2 = nullptr; b.B = p.B2; b.ldb = p.ldb2; b.b_cols = (p.K - p.K1 + 7) / 8 * 8 <= p.ldb2 ? (p.K - p.K1 + 7) / 8 * 8 : p.ldb2 / 8 * 8; b.K = p.K - p.K1;
+    b.k_valid = std::max(0, p.k_valid - p.K1); b.C = p.C + p.K1; b.colsum = nullptr;
+    const int rc = gemm_tn(a, s);
+    return rc ? rc : (b.k_valid > 0 ? gemm_tn(b, s) : 0);
+  }
   q.splits = pl.splits;
   const int kind = pl.kind, grid = pl.grid;
   if (kind == 3) {

@@ -841,8 +841,14 @@ class Plan:
                      rowmap=ps._maps['heads'] if md.dim_head != 64 else None)
             if md.has_skip(i):
                 sk = self.xres[src[i]]
-                self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
-                self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
+                # d W_skip [d, 2 d] = G^T [x | skip].  TFX_SKIP_TN_SPLIT=1: ONE product with a split B (tfx.h B2 / K1; 8 tiles of 256 x 256 on the one-wave kernel).
+                # Built, tested - and measured neutral on the GPU (117.6 us against 2 x 64 us: at 29 row chunks the 256 x 256 tiles push 58 MiB through the fp32
+                # atomics where the 128 x 128 blocks push 32) and +0.1 ms per step in two same-box rounds (gpurun_out/ow26_step.txt, ow27_*): off
+                if os.environ.get('TFX_SKIP_TN_SPLIT', '0') == '1':
+                    self._tn(L, T, d, 2 * d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, B2=sk, ldb2=d, K1=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
+                else:
+                    self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
+                    self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
             per = -(-D // self.dp_groups) if self.dp_groups > 0 else D
             if I > 0 and i % per == 0:
                 # AdaLN conditioning weights (6d table columns per layer, 63 % of all parameters) of the layer GROUP that ends here: their table
