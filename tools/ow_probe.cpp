@@ -114,7 +114,8 @@ static int tn_main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("[tn %s] TFX_TN_OW=%s\n", tag, getenv("TFX_TN_OW") ? getenv("TFX_TN_OW") : "(unset)");
-  for (const TnCase& c : TN_CASES) {
+  for (TnCase c : TN_CASES) {
+    if (getenv("OWP_TN_M") && c.splits == 0) c.M = atoi(getenv("OWP_TN_M"));        // (row count override: time(M) = a + b M separates the atomics / prologue from the row loop)
     std::vector<uint16_t> hA((size_t)c.M * c.N), hB((size_t)c.M * c.K);
     fill_bf16(hA, 3 + c.N, 1.f); fill_bf16(hB, 5 + c.K, 0.05f);
     uint16_t *dA, *dB; float* dC; CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dB, hB.size() * 2)); CK(hipMalloc(&dC, (size_t)c.N * c.K * 4));
