@@ -884,6 +884,27 @@ TFX_DEV TnBlock tn_block(const GemmTN& p, int ntile) {
   return b;
 }
 
+// Ramped row chunks (one-wave kernel; round 5): with equal chunks every block of a launch finishes its row loop at the same moment and the fp32 atomics of ALL of them
+// - tiles x chunks x 256 KiB, which the chip retires at ~1.25 TB/s whatever XCD they come from (tools/atomic_xcd_probe.hip): 48 us for the 60 MiB of a 2816 x 512
+// launch, 27-42 % of the config-2 weight-gradient kernels (profiles/r05b_tn_atomics_fixed_cost.txt) - queue up behind an idle matrix pipe.  Chunk s is therefore
+// c0 + d s steps of 64 rows long: the blocks of chunk 0 finish first and their atomics drain while the others still multiply; the last chunk's (tiles x 256 KiB)
+// is what stays exposed.  d = 0: equal chunks (the other kernels' tn_block, multiples of 64 rows).  M % 64 == 0.
+TFX_DEV TnBlock tn_block_ramp(const GemmTN& p, int ntile, int d) {
+  if (d <= 0) return tn_block(p, ntile);
+  const int per = gridDim.x >> 3;
+  const int g = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int S = p.splits, U = p.M / TN_BMK;
+  const int tri = d * S * (S - 1) / 2;
+  const int c0 = (U - tri) / S, rem = U - tri - c0 * S;                 // the remainder goes to the last (longest) chunk
+  TnBlock b;
+  const int split = g / ntile;
+  b.tile = g - split * ntile;
+  if (split >= S) { b.mbeg = b.mend = p.M; return b; }
+  const int start = c0 * split + d * split * (split - 1) / 2, len = c0 + d * split + (split == S - 1 ? rem : 0);
+  b.mbeg = start * TN_BMK; b.mend = (start + len) * TN_BMK;
+  return b;
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTN p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* As = (bf16*)smem_raw;                         // [2][64*160]
@@ -2044,14 +2065,14 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
         "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175",             \
         "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191"
 template <bool SUM>
-__global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p) {
+__global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p, int ramp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* S = (bf16*)smem_raw;                                             // [2 steps][A sub-slabs 0, 1 | B sub-slabs 0, 1][64 rows x 128 columns]
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = w >> 1, wk = w & 1;
   const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
-  const TnBlock blk = tn_block(p, ntn * ntk);
+  const TnBlock blk = tn_block_ramp(p, ntn * ntk, ramp);
   const int mbeg = blk.mbeg, mend = blk.mend;
   const int n0 = (blk.tile / ntk) * 256, k0 = (blk.tile % ntk) * 256;
   if (mend - mbeg < 192) return;                                         // (the launcher only sends chunks of >= 192 rows in multiples of 64)
@@ -2440,13 +2461,26 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   const int kind = pl.kind, grid = pl.grid;
   if (kind == 3) {
     static uint32_t attr_tnow = 0;
+    // ramp (tn_block_ramp): the finish times of the chunks should spread over about the time the launch's atomics take, tiles x chunks x 0.2 us (256 KiB at
+    // 1.25 TB/s), i.e. d = 0.2 us x tiles / (a step's 1.35 us) steps of 64 rows per chunk index.  TFX_TN_RAMP scales it (0 = equal chunks).  Measured
+    // (gpurun_out/ow31.txt, steady state): -3.5 ... -7.8 % on the 11-20-chunk launches of config 2 at factor 1, worse at 0.5 / 1.5 / 2, nothing to +1 % on the
+    // 2-5-chunk launches - so from 8 chunks on
+    static double ramp_f = -1;
+    if (ramp_f < 0) { const char* e = getenv("TFX_TN_RAMP"); ramp_f = e ? atof(e) : 1.0; }
+    int ramp = 0;
+    if (q.splits >= 8 && ramp_f > 0) {
+      const int S = q.splits, U = q.M / TN_BMK;
+      ramp = (int)(0.148 * pl.tiles * ramp_f + 0.5);
+      while (ramp > 0 && (U - ramp * S * (S - 1) / 2) / S < 8) ramp--;   // the shortest chunk keeps >= 8 steps
+      if (U * TN_BMK != q.M) ramp = 0;
+    }
     if (q.colsum) {
       static uint32_t attr_tnows = 0;
       ensure_smem_attr((const void*)gemm_tn_ow_kernel<true>, 131072, attr_tnows);
-      hipLaunchKernelGGL(gemm_tn_ow_kernel<true>, dim3(grid), dim3(256), 131072, s, q);
+      hipLaunchKernelGGL(gemm_tn_ow_kernel<true>, dim3(grid), dim3(256), 131072, s, q, ramp);
     } else {
       ensure_smem_attr((const void*)gemm_tn_ow_kernel<false>, 131072, attr_tnow);
-      hipLaunchKernelGGL(gemm_tn_ow_kernel<false>, dim3(grid), dim3(256), 131072, s, q);
+      hipLaunchKernelGGL(gemm_tn_ow_kernel<false>, dim3(grid), dim3(256), 131072, s, q, ramp);
     }
   } else if (kind == 2) {
     if (q.colsum) launch_tn_wide<true, 2, 4, 4, 2, 4>(q, grid, s);
