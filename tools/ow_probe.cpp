@@ -60,6 +60,7 @@ static const TnCase TN_CASES[] = {
   {"t_one",     4096,  512,  512, 1},          // one block per tile: deterministic
   {"t_2816",   65536, 2816,  512, 0}, {"t_1544", 65536, 1544, 512, 0}, {"t_1408", 65536, 512, 1408, 0}, {"t_1024", 65536, 1024, 1024, 0},
   {"t_5504",   65536, 5504, 1024, 0}, {"t_2752", 65536, 1024, 2752, 0}, {"t_4096", 65536, 1024, 4096, 0},
+  {"t_cond",    2048, 24576, 2048, 1},         // the AdaLN conditioning weights: more tiles than CUs, one block per tile
 };
 // tools/ow_probe tnsum: the folded bias gradient on an all-ones A (every column sum = M): which output rows miss how much
 static int tnsum_main() {
