@@ -105,6 +105,12 @@ typedef struct {
    * cat(x, skip) (reference T:1214-1219) as ONE product with 8 tiles of 256 x 256 instead of two with 4 each.  B then holds K1 columns, B2 the other K - K1
    * (ldb2 >= K - K1, % 8 == 0); K1 % 256 == 0, k_group == 0.  B2 == NULL: off. */
   const tfx_bf16* B2; int32_t ldb2; int32_t K1;
+  /* grouped launch (round 5): HOST pointer to the tfx_gemm_tn_args of another product over the same M rows (its own group_next continues the chain; at most 4
+   * products; `splits` of the chain's head applies).  The products of a transformer layer that are ready together - the FeedForward pair, to_out + to_qk/v/gates
+   * (+ the skip projection) - then run as ONE launch whose output tiles fill the chip at 7-13 row chunks instead of 11-20 per product: half the fp32 atomics of the
+   * split-M sums (which the chip retires at ~1.25 TB/s: 27-42 % of the ungrouped kernels) and 256 x 256 tiles for the 512 x 512 products.  Products the one-wave
+   * kernel does not take (row-gathered operands, M % 64 != 0, chunks under 192 rows) make the library run the chain one by one - same results.  NULL = single. */
+  const void* group_next;
 } tfx_gemm_tn_args;
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
 /* what tfx_gemm_tn would launch for these arguments, without launching (host logic only, no device needed): kernel form (-1 register-staged

@@ -428,3 +428,29 @@ def test_generated_asm_loops_match_their_generators(tmp_path):
             if ln.startswith('s_cbranch_scc1') and ('_loop_' in ln or '_steady_' in ln):      # a back branch: nothing of the body may follow it
                 nxt = lines[i + 1]
                 assert nxt.endswith(':') , (name, ln, nxt)
+
+
+def test_tn_grouped_launch_plan():
+    """`group_next` chains (host logic, no device): products over the same M rows that the one-wave kernel takes run as ONE launch - plan kind 3 with the chain's
+    summed tiles and the row chunks that fill the chip for THAT tile count; a member it does not take (gathered rows), different M or a chain of five fall back to the
+    head's own plan (the library then runs the chain product by product)."""
+    lib = capi.lib()
+
+    def args(M, N, K, **kw):
+        return capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, lda=(N + 7) // 8 * 8, a_cols=(N + 7) // 8 * 8, ldb=(K + 7) // 8 * 8, b_cols=(K + 7) // 8 * 8,
+                              ldc=K, k_valid=K, splits=0, accumulate=1, alpha=1.0, **kw)
+
+    def plan(chain):
+        for a, b in zip(chain, chain[1:]):
+            a.group_next = ctypes.addressof(b)
+        out = [ctypes.c_int32(-9) for _ in range(4)]
+        assert lib.tfx_gemm_tn_plan(ctypes.byref(chain[0]), *[ctypes.byref(o) for o in out]) == 0
+        return tuple(o.value for o in out)
+
+    T = 65536
+    assert plan([args(T, 512, 1408), args(T, 2816, 512)]) == (3, 34, 7, 240)            # the FeedForward pair: 12 + 22 tiles, 7 chunks instead of 20 and 11
+    assert plan([args(T, 512, 512), args(T, 1544, 512)]) == (3, 18, 13, 240)            # to_out + to_qk/v/gates: the 512 x 512 product on 256 x 256 tiles
+    assert plan([args(T, 512, 512), args(T, 1544, 512), args(T, 512, 512), args(T, 512, 512)]) == (3, 26, 9, 240)      # + the skip projection's two halves
+    assert plan([args(T, 512, 512), args(T, 1544, 512, a_rowmap=64)]) == (0, 16, 16, 256)          # a gathered member: the head's own plan
+    assert plan([args(T, 512, 512), args(T // 2, 1544, 512)])[0] == 0                              # different row counts
+    assert plan([args(T, 512, 512) for _ in range(5)])[0] == 0                                     # more than four members

@@ -352,6 +352,48 @@ def test_gemm_tn_split_b(M, N, K, K1, splits, want_kind):
     check(f'gemm_tn split-B bias grad {M}x{N}x{K}', bias, A.float().sum(0), 5e-3)
 
 
+@pytest.mark.parametrize('M,shapes,groupable', [(8192, [(512, 1408), (2816, 512)], True), (4096, [(512, 512), (1544, 512), (512, 512), (512, 512)], True),
+                                                 (1000, [(200, 136), (136, 200)], False), (16384, [(512, 512), (512, 1024)], True), (8192, [(512, 512), (512, 1024)], False)])
+def test_gemm_tn_grouped_launch(M, shapes, groupable):
+    """round 5: `group_next` - weight-gradient products over the same M rows as ONE launch (a transformer layer's FeedForward pair; to_out + to_qk/v/gates + the skip
+    projection).  The group's tiles share one grid of the one-wave kernel (plan kind 3, tiles = the sum); chains the kernel does not take run product by product inside
+    the library.  Each member against fp32 torch, with a row map + folded bias gradient on the second member and a split B on a member of the last case."""
+    torch.manual_seed(9)
+    structs, keep, refs = [], [], []
+    for idx, (N, K) in enumerate(shapes):
+        lda = (N + 7) // 8 * 8; ldb = (K + 7) // 8 * 8
+        A = rnd(M, lda, scale=0.5); C = torch.zeros(N, K, device=DEV)
+        kw = dict(A=A, lda=lda, a_cols=lda, M=M, N=N, K=K, C=C, ldc=K, k_valid=K, splits=0, accumulate=1, alpha=1.0)
+        if K == 1024 and idx == 1:                                   # split B: [B | B2]
+            B, B2 = rnd(M, 512, scale=0.5), rnd(M, 520, scale=0.5)
+            kw.update(B=B, ldb=512, b_cols=512, B2=B2, ldb2=520, K1=512); Bfull = torch.cat([B, B2[:, :512]], 1); keep += [B, B2]
+        else:
+            B = rnd(M, ldb, scale=0.5); kw.update(B=B, ldb=ldb, b_cols=ldb); Bfull = B[:, :K]; keep.append(B)
+        prod = A[:, :N].float().T @ Bfull.float()
+        if idx == 1:
+            rowmap = torch.randperm(N, device=DEV).to(torch.int32); bias = torch.zeros(N, device=DEV)
+            kw.update(rowmap=rowmap, colsum=bias)
+            ref = torch.zeros_like(prod); ref[rowmap.long()] = prod
+            bref = torch.zeros(N, device=DEV); bref[rowmap.long()] = A[:, :N].float().sum(0)
+            refs.append((C, ref, bias, bref)); keep += [rowmap, bias]
+        else:
+            refs.append((C, prod, None, None))
+        keep += [A, C]
+        structs.append(capi.make_args('tfx_gemm_tn_args', **kw))
+    for a, b in zip(structs, structs[1:]):
+        a.group_next = ctypes.addressof(b)
+    out = [ctypes.c_int32(-9) for _ in range(4)]
+    assert capi.lib().tfx_gemm_tn_plan(ctypes.byref(structs[0]), *[ctypes.byref(o) for o in out]) == 0
+    tiles = sum(((N + 255) // 256) * ((K + 255) // 256) for N, K in shapes)
+    if groupable:
+        assert out[0].value == 3 and out[1].value == tiles, [o.value for o in out]
+    capi.call('tfx_gemm_tn', structs[0], stream())
+    for i, (C, ref, bias, bref) in enumerate(refs):
+        check(f'grouped gemm_tn member {i} {M}x{shapes[i]}', C, ref, 5e-3)
+        if bias is not None:
+            check(f'grouped gemm_tn member {i} bias grad', bias, bref, 5e-3)
+
+
 # ---------------------------------------------------------------------------------------------- attention
 def make_kv_end(b, n, seed=0):
     g = torch.Generator().manual_seed(seed)

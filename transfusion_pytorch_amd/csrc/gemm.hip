@@ -2065,14 +2065,13 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
         "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175",             \
         "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191"
 template <bool SUM>
-__global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p, int ramp) {
+TFX_DEV void tn_ow_body(const GemmTN& p, const TnBlock& blk) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* S = (bf16*)smem_raw;                                             // [2 steps][A sub-slabs 0, 1 | B sub-slabs 0, 1][64 rows x 128 columns]
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = w >> 1, wk = w & 1;
-  const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
-  const TnBlock blk = tn_block_ramp(p, ntn * ntk, ramp);
+  const int ntk = (p.K + 255) / 256;
   const int mbeg = blk.mbeg, mend = blk.mend;
   const int n0 = (blk.tile / ntk) * 256, k0 = (blk.tile % ntk) * 256;
   if (mend - mbeg < 192) return;                                         // (the launcher only sends chunks of >= 192 rows in multiples of 64)
@@ -2111,7 +2110,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p, int ramp) 
   }
   f32x16 acc[4][4];
   f32x16 accs[SUM ? 4 : 1];                                              // bias gradient: A^T x ones, on the waves of the first K columns
-  const bool do_sum = SUM && k0 == 0 && wk == 0;                         // wave-uniform; both loop forms pass the same barriers
+  const bool do_sum = SUM && p.colsum != nullptr && k0 == 0 && wk == 0;  // wave-uniform; both loop forms pass the same barriers
   if (do_sum) {
     u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     asm volatile(
@@ -2153,6 +2152,24 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p, int ramp) 
         if (out_col[j] >= 0) atomicAdd(crow + out_col[j], acc[i][j][r] * p.alpha);
     }
   }
+}
+template <bool SUM>
+__global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p, int ramp) {
+  const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
+  tn_ow_body<SUM>(p, tn_block_ramp(p, ntn * ntk, ramp));
+}
+// grouped launch (tfx.h group_next): up to four products over the same M rows share one grid; the (row chunk, tile) pairs are numbered over the CONCATENATED tile
+// lists, so an XCD still walks all tiles of a chunk side by side; a block finds its product by its tile number (block-uniform) and runs the body on it
+struct TnGroup { int count; int tile_end[4]; GemmTN p[4]; };
+template <bool SUM>
+__global__ __launch_bounds__(256, 1) void gemm_tn_ow_group_kernel(TnGroup g, int ramp) {
+  TnBlock blk = tn_block_ramp(g.p[0], g.tile_end[g.count - 1], ramp);    // (M and splits of the head)
+  int pid = 0, first = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+    if (i + 1 < g.count && blk.tile >= g.tile_end[i]) { pid = i + 1; first = g.tile_end[i]; }
+  blk.tile -= first;
+  tn_ow_body<SUM>(g.p[__builtin_amdgcn_readfirstlane(pid)], blk);        // (uniform index into the kernel-argument segment: scalar loads)
 }
 #undef OWT_OUT
 #undef OWT_IN
@@ -2402,6 +2419,8 @@ template <bool SUM, int FA, int FB, int WN, int WK, int NST> static void launch_
 // what gemm_tn launches for a shape: kernel form (-1 register-staged fallback, 0 = 128 x 128 / 4 waves, 2 = 256 x 256 / 8 waves), output tiles,
 // row chunks, grid.  Pure host logic (tfx.h tfx_gemm_tn_plan: the CPU tests pin the split rule through it).
 struct TnPlan { int kind, tiles, splits, grid; };
+static int tn_ow_mode();
+static bool tn_ow_operands_ok(const GemmTN& q);
 static TnPlan tn_plan(const GemmTN& q) {
   static int tile = -2;               // TFX_TN_TILE: force 0 = 128 x 128 blocks or 2 = 256 x 256 (A/B, tests); unset: by tile count
   if (tile == -2) { const char* e = getenv("TFX_TN_TILE"); tile = e ? atoi(e) : -1; }
@@ -2420,21 +2439,72 @@ static TnPlan tn_plan(const GemmTN& q) {
   // kind 3: the 256 x 256 launches that the one-wave-per-SIMD kernel takes (TFX_TN_OW=0: none): 32-bit operand offsets, every chunk
   // >= 192 rows in multiples of 64.  Ragged N / K tiles included: the kernel computes their dead fragments too and still measured 10-13 % faster on
   // 1544 x 512 and 512 x 1408 (gpurun_out/ow9_tn.txt)
-  static int tnow = -1;
-  if (tnow < 0) { const char* e = getenv("TFX_TN_OW"); tnow = e ? atoi(e) : 1; }
-  if (tnow && pl.kind == 2 && q.M % 64 == 0 && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0) {
+  if (tn_ow_mode() && pl.kind == 2 && tn_ow_operands_ok(q)) {
     const int chunk = ((q.M + pl.splits - 1) / pl.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
     const int last = q.M % chunk == 0 ? chunk : q.M % chunk;      // rows of the last non-empty chunk (trailing empty chunks: the kernel returns on them)
-    const long long lim = 1ll << 32;
-    const bool b_ok = q.B2 ? (q.K1 % 256 == 0 && q.K1 > 0 && q.K1 < q.K && q.b_cols >= q.K1 && q.ldb2 >= q.K - q.K1 && (q.ldb2 & 7) == 0 && ((uintptr_t)q.B2 & 15) == 0 && q.k_group == 0 &&
-                                  (long long)(q.M + 64) * q.ldb2 * 2 < lim)
-                           : q.b_cols >= q.K;
-    if (chunk >= 192 && last >= 192 && (long long)(q.M + 64) * q.lda * 2 < lim && (long long)(q.M + 64) * q.ldb * 2 < lim && q.a_cols >= q.N && b_ok) pl.kind = 3;
+    if (chunk >= 192 && last >= 192) pl.kind = 3;
   }
   return pl;
 }
+// grouped launch (tfx.h group_next): the chain's products on ONE grid of the one-wave kernel when every one of them qualifies; `tiles` / `splits` / `grid` of the group
+struct TnGroupPlan { bool ok; int count, tiles, splits, grid; TnGroup g; };
+static int tn_ow_mode() {
+  static int tnow = -1;
+  if (tnow < 0) { const char* e = getenv("TFX_TN_OW"); tnow = e ? atoi(e) : 1; }
+  return tnow;
+}
+static bool tn_ow_operands_ok(const GemmTN& q) {        // what the one-wave kernel needs of a product, whatever its tile count
+  const long long lim = 1ll << 32;
+  const bool b_ok = q.B2 ? (q.K1 % 256 == 0 && q.K1 > 0 && q.K1 < q.K && q.b_cols >= q.K1 && q.ldb2 >= q.K - q.K1 && (q.ldb2 & 7) == 0 && ((uintptr_t)q.B2 & 15) == 0 && q.k_group == 0 &&
+                                (long long)(q.M + 64) * q.ldb2 * 2 < lim)
+                         : q.b_cols >= q.K;
+  return use_glds() && q.M % 64 == 0 && !q.a_rowmap && !q.b_rowmap && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0 && ((q.lda | q.ldb | q.a_cols | q.b_cols) & 7) == 0 &&
+         (long long)(q.M + 64) * q.lda * 2 < lim && (long long)(q.M + 64) * q.ldb * 2 < lim && q.a_cols >= q.N && b_ok && q.N > 0 && q.K > 0;
+}
+static TnGroupPlan tn_group_plan(const GemmTN& head) {
+  TnGroupPlan gp; memset(&gp, 0, sizeof(gp));
+  static int grp = -1;                // TFX_TN_GROUP=0: chains run product by product (A/B)
+  if (grp < 0) { const char* e = getenv("TFX_TN_GROUP"); grp = e ? atoi(e) : 1; }
+  const GemmTN* q = &head;
+  int n = 0, tiles = 0;
+  bool ok = grp != 0 && tn_ow_mode() != 0;
+  while (q && n < 4) {
+    ok = ok && q->M == head.M && tn_ow_operands_ok(*q);
+    tiles += ((q->N + 255) / 256) * ((q->K + 255) / 256);
+    gp.g.p[n] = *q; gp.g.p[n].group_next = nullptr; gp.g.tile_end[n] = tiles;
+    n++;
+    q = (const GemmTN*)q->group_next;
+  }
+  ok = ok && q == nullptr && n >= 2;                                 // (longer chains: one by one)
+  gp.count = n; gp.tiles = tiles; gp.g.count = n;
+  if (!ok) return gp;
+  gp.splits = head.splits == 0 ? tn_auto_splits(head.M, tiles, 2) : head.splits;
+  const int chunk = ((head.M + gp.splits - 1) / gp.splits + TN_BMK - 1) / TN_BMK * TN_BMK;
+  const int last = head.M % chunk == 0 ? chunk : head.M % chunk;
+  if (chunk < 192 || last < 192) return gp;
+  gp.grid = (tiles * gp.splits + 7) / 8 * 8;
+  for (int i = 0; i < n; i++) gp.g.p[i].splits = gp.splits;
+  gp.ok = true;
+  return gp;
+}
+static int tn_ramp(int M, int tiles, int splits) {   // tn_block_ramp's d for a launch (see the kind-3 branch of gemm_tn)
+  static double ramp_f = -1;
+  if (ramp_f < 0) { const char* e = getenv("TFX_TN_RAMP"); ramp_f = e ? atof(e) : 1.0; }
+  int ramp = 0;
+  if (splits >= 8 && ramp_f > 0 && M % TN_BMK == 0) {
+    const int S = splits, U = M / TN_BMK;
+    ramp = (int)(0.148 * tiles * ramp_f + 0.5);
+    while (ramp > 0 && (U - ramp * S * (S - 1) / 2) / S < 8) ramp--;   // the shortest chunk keeps >= 8 steps
+  }
+  return ramp;
+}
+
 int gemm_tn_plan(const GemmTN& p, int* kind, int* tiles, int* splits, int* grid) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 0) return -1;
+  if (p.group_next) {                                               // a chain that runs as one launch: kind 3 with the group's tiles / chunks / grid
+    const TnGroupPlan gp = tn_group_plan(p);
+    if (gp.ok) { if (kind) *kind = 3; if (tiles) *tiles = gp.tiles; if (splits) *splits = gp.splits; if (grid) *grid = gp.grid; return 0; }
+  }
   const TnPlan pl = tn_plan(p);
   if (kind) *kind = pl.kind; if (tiles) *tiles = pl.tiles; if (splits) *splits = pl.splits; if (grid) *grid = pl.grid;
   return 0;
@@ -2443,6 +2513,24 @@ int gemm_tn_plan(const GemmTN& p, int* kind, int* tiles, int* splits, int* grid)
 int gemm_tn(const GemmTN& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.splits < 0) return -1;
   if ((p.lda | p.ldb | p.a_cols | p.b_cols) & 7) return -2;
+  if (p.group_next) {
+    const TnGroupPlan gp = tn_group_plan(p);
+    if (gp.ok) {
+      bool sum = false;
+      for (int i = 0; i < gp.count; i++) sum = sum || gp.g.p[i].colsum != nullptr;
+      const int ramp = tn_ramp(p.M, gp.tiles, gp.splits);
+      static uint32_t attr_g0 = 0, attr_g1 = 0;
+      if (sum) { ensure_smem_attr((const void*)gemm_tn_ow_group_kernel<true>, 131072, attr_g1); hipLaunchKernelGGL(gemm_tn_ow_group_kernel<true>, dim3(gp.grid), dim3(256), 131072, s, gp.g, ramp); }
+      else { ensure_smem_attr((const void*)gemm_tn_ow_group_kernel<false>, 131072, attr_g0); hipLaunchKernelGGL(gemm_tn_ow_group_kernel<false>, dim3(gp.grid), dim3(256), 131072, s, gp.g, ramp); }
+      return (int)hipGetLastError();
+    }
+    for (const GemmTN* q = &p; q; q = (const GemmTN*)q->group_next) {     // not groupable: the chain's products one by one
+      GemmTN one = *q; one.group_next = nullptr;
+      const int rc = gemm_tn(one, s);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   static uint32_t attr_set = 0;
   const int smem = 2 * 2 * TN_BMK * TN_LD * 2;
   ensure_smem_attr((const void*)gemm_tn_kernel, smem, attr_set);
@@ -2465,15 +2553,7 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
     // 1.25 TB/s), i.e. d = 0.2 us x tiles / (a step's 1.35 us) steps of 64 rows per chunk index.  TFX_TN_RAMP scales it (0 = equal chunks).  Measured
     // (gpurun_out/ow31.txt, steady state): -3.5 ... -7.8 % on the 11-20-chunk launches of config 2 at factor 1, worse at 0.5 / 1.5 / 2, nothing to +1 % on the
     // 2-5-chunk launches - so from 8 chunks on
-    static double ramp_f = -1;
-    if (ramp_f < 0) { const char* e = getenv("TFX_TN_RAMP"); ramp_f = e ? atof(e) : 1.0; }
-    int ramp = 0;
-    if (q.splits >= 8 && ramp_f > 0) {
-      const int S = q.splits, U = q.M / TN_BMK;
-      ramp = (int)(0.148 * pl.tiles * ramp_f + 0.5);
-      while (ramp > 0 && (U - ramp * S * (S - 1) / 2) / S < 8) ramp--;   // the shortest chunk keeps >= 8 steps
-      if (U * TN_BMK != q.M) ramp = 0;
-    }
+    const int ramp = tn_ramp(q.M, pl.tiles, q.splits);
     if (q.colsum) {
       static uint32_t attr_tnows = 0;
       ensure_smem_attr((const void*)gemm_tn_ow_kernel<true>, 131072, attr_tnows);

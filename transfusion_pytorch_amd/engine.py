@@ -330,6 +330,28 @@ class Plan:
         a._algo_flops = 2.0 * M * (algo_n or N) * kw['k_valid']
         lst.append(Side(('tfx_gemm_tn', a)) if side else ('tfx_gemm_tn', a))
 
+    def _tn_group(self, lst, M, problems, side=False):
+        """Weight-gradient products over the same M rows as ONE launch (tfx.h group_next): `problems` = [(N, K, kwargs of _tn), ...].  The library runs the chain
+        on one grid of its one-wave kernel - half the fp32 atomics of the split-M sums, 256 x 256 tiles for the 512 x 512 products - or, where a product does not
+        qualify, one by one.  TFX_TN_GROUP=0 keeps them separate launches (what the list held through round 5's first session)."""
+        if len(problems) < 2 or os.environ.get('TFX_TN_GROUP', '1') == '0':
+            for (N, K, kw) in problems:
+                self._tn(lst, M, N, K, side=side, **kw)
+            return
+        structs, flops = [], 0.0
+        for (N, K, kw) in problems:
+            kw = dict(kw); kw.setdefault('k_valid', K)
+            algo_n = kw.pop('algo_n', None)
+            a = capi.make_args('tfx_gemm_tn_args', M=M, N=N, K=K, splits=0, accumulate=1, alpha=1.0, **kw)
+            flops += 2.0 * M * (algo_n or N) * kw['k_valid']
+            structs.append(a)
+        for a, b in zip(structs, structs[1:]):
+            a.group_next = ctypes.addressof(b)
+        head = structs[0]
+        head._chain = structs[1:]                                # (keeps the chained structs alive with the list)
+        head._algo_flops = flops
+        lst.append(Side(('tfx_gemm_tn', head)) if side else ('tfx_gemm_tn', head))
+
     def _k(self, lst, fn, struct, **kw):
         lst.append((fn, capi.make_args(struct, **kw)))
 
@@ -784,9 +806,9 @@ class Plan:
             sync('tfx_fork', 2 * i)
             # (round 5 tried net.3's bias gradient as this GEMM's `colsum` to free 8 registers of the pull kernel: the SUM form of the GEMM is 13 us slower per
             # launch (158 vs 145 us, profiles/r05_shapes.txt) - and with its scale row in LDS the pull kernel no longer spills WITH the bias partials)
-            self._tn(L, T, d, di, side=side, A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)
-            self._tn(L, T, 2 * dip, d, side=side, algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
-                     C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias'))
+            self._tn_group(L, T, [(d, di, dict(A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)),
+                                  (2 * dip, d, dict(algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
+                                                    C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias')))], side=side)
             self._nt(L, algo_k=2 * di, A=dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             a_pref = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                                     gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
@@ -835,20 +857,20 @@ class Plan:
             self._seg_args.append(L[-1][1])
             # weight gradients of the attention wrapper (dy_a, d[q|k|v|gates] and G = dH[i+1] are final) on the side stream
             sync('tfx_fork', 2 * i + 1)
-            self._tn(L, T, d, hd, side=side, A=dy_a, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=md.hd,
-                     k_group=0 if md.dim_head == 64 else md.dim_head)
-            self._tn(L, T, md.nqk, d, side=side, algo_n=md.nq, A=dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d,
-                     rowmap=ps._maps['heads'] if md.dim_head != 64 else None)
+            grp = [(d, hd, dict(A=dy_a, lda=d, a_cols=d, B=self.og[i], ldb=hd, b_cols=hd, C=gp(f'{p}.1.fn.to_out.1.weight'), ldc=md.hd,
+                                k_group=0 if md.dim_head == 64 else md.dim_head)),
+                   (md.nqk, d, dict(algo_n=md.nq, A=dqkvg, lda=ldq, a_cols=ldq, B=self.ua[i], ldb=d, b_cols=d, C=gp(f'{p}.1.fn.to_qk.0.weight'), ldc=d,
+                                    rowmap=ps._maps['heads'] if md.dim_head != 64 else None))]
             if md.has_skip(i):
                 sk = self.xres[src[i]]
-                # d W_skip [d, 2 d] = G^T [x | skip].  TFX_SKIP_TN_SPLIT=1: ONE product with a split B (tfx.h B2 / K1; 8 tiles of 256 x 256 on the one-wave kernel).
-                # Built, tested - and measured neutral on the GPU (117.6 us against 2 x 64 us: at 29 row chunks the 256 x 256 tiles push 58 MiB through the fp32
-                # atomics where the 128 x 128 blocks push 32) and +0.1 ms per step in two same-box rounds (gpurun_out/ow26_step.txt, ow27_*): off
+                # d W_skip [d, 2 d] = G^T [x | skip].  TFX_SKIP_TN_SPLIT=1: ONE product with a split B (tfx.h B2 / K1).  Built, tested - and measured neutral as
+                # its own launch (117.6 us against 2 x 64 us; gpurun_out/ow26_step.txt, ow27_*): off; inside the layer's group the two products are two members
                 if os.environ.get('TFX_SKIP_TN_SPLIT', '0') == '1':
-                    self._tn(L, T, d, 2 * d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, B2=sk, ldb2=d, K1=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
+                    grp.append((d, 2 * d, dict(A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, B2=sk, ldb2=d, K1=d, C=gp(f'{p}.0.weight'), ldc=2 * d)))
                 else:
-                    self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)
-                    self._tn(L, T, d, d, side=side, A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)
+                    grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)))
+                    grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)))
+            self._tn_group(L, T, grp, side=side)
             per = -(-D // self.dp_groups) if self.dp_groups > 0 else D
             if I > 0 and i % per == 0:
                 # AdaLN conditioning weights (6d table columns per layer, 63 % of all parameters) of the layer GROUP that ends here: their table
