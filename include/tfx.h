@@ -106,8 +106,8 @@ typedef struct {
    * (ldb2 >= K - K1, % 8 == 0); K1 % 256 == 0, k_group == 0.  B2 == NULL: off. */
   const tfx_bf16* B2; int32_t ldb2; int32_t K1;
   /* grouped launch (round 5): HOST pointer to the tfx_gemm_tn_args of another product over the same M rows (its own group_next continues the chain; at most 4
-   * products; `splits` of the chain's head applies).  The products of a transformer layer that are ready together - the FeedForward pair, to_out + to_qk/v/gates
-   * (+ the skip projection) - then run as ONE launch whose output tiles fill the chip at 7-13 row chunks instead of 11-20 per product: half the fp32 atomics of the
+   * products; `splits` of the chain's head applies).  The weight-gradient products of a transformer layer - the FeedForward pair, to_out, to_qk/v/gates, the skip
+   * projection's halves - then run as ONE launch whose output tiles fill the chip at 4 row chunks instead of 11-20 per product: half the fp32 atomics of the
    * split-M sums (which the chip retires at ~1.25 TB/s: 27-42 % of the ungrouped kernels) and 256 x 256 tiles for the 512 x 512 products.  Products the one-wave
    * kernel does not take (row-gathered operands, M % 64 != 0, chunks under 192 rows) make the library run the chain one by one - same results.  NULL = single. */
   const void* group_next;

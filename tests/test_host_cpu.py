@@ -453,4 +453,4 @@ def test_tn_grouped_launch_plan():
     assert plan([args(T, 512, 512), args(T, 1544, 512), args(T, 512, 512), args(T, 512, 512)]) == (3, 26, 9, 240)      # + the skip projection's two halves
     assert plan([args(T, 512, 512), args(T, 1544, 512, a_rowmap=64)]) == (0, 16, 16, 256)          # a gathered member: the head's own plan
     assert plan([args(T, 512, 512), args(T // 2, 1544, 512)])[0] == 0                              # different row counts
-    assert plan([args(T, 512, 512) for _ in range(5)])[0] == 0                                     # more than four members
+    assert plan([args(T, 512, 512) for _ in range(7)])[0] == 0                                     # more than six members

@@ -2158,15 +2158,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_ow_kernel(GemmTN p, int ramp) 
   const int ntn = (p.N + 255) / 256, ntk = (p.K + 255) / 256;
   tn_ow_body<SUM>(p, tn_block_ramp(p, ntn * ntk, ramp));
 }
-// grouped launch (tfx.h group_next): up to four products over the same M rows share one grid; the (row chunk, tile) pairs are numbered over the CONCATENATED tile
+// grouped launch (tfx.h group_next): up to TN_GROUP_MAX products over the same M rows share one grid; the (row chunk, tile) pairs are numbered over the CONCATENATED tile
 // lists, so an XCD still walks all tiles of a chunk side by side; a block finds its product by its tile number (block-uniform) and runs the body on it
-struct TnGroup { int count; int tile_end[4]; GemmTN p[4]; };
+constexpr int TN_GROUP_MAX = 6;
+struct TnGroup { int count; int tile_end[TN_GROUP_MAX]; GemmTN p[TN_GROUP_MAX]; };
 template <bool SUM>
 __global__ __launch_bounds__(256, 1) void gemm_tn_ow_group_kernel(TnGroup g, int ramp) {
   TnBlock blk = tn_block_ramp(g.p[0], g.tile_end[g.count - 1], ramp);    // (M and splits of the head)
   int pid = 0, first = 0;
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < TN_GROUP_MAX - 1; i++)
     if (i + 1 < g.count && blk.tile >= g.tile_end[i]) { pid = i + 1; first = g.tile_end[i]; }
   blk.tile -= first;
   tn_ow_body<SUM>(g.p[__builtin_amdgcn_readfirstlane(pid)], blk);        // (uniform index into the kernel-argument segment: scalar loads)
@@ -2468,7 +2469,7 @@ static TnGroupPlan tn_group_plan(const GemmTN& head) {
   const GemmTN* q = &head;
   int n = 0, tiles = 0;
   bool ok = grp != 0 && tn_ow_mode() != 0;
-  while (q && n < 4) {
+  while (q && n < TN_GROUP_MAX) {
     ok = ok && q->M == head.M && tn_ow_operands_ok(*q);
     tiles += ((q->N + 255) / 256) * ((q->K + 255) / 256);
     gp.g.p[n] = *q; gp.g.p[n].group_next = nullptr; gp.g.tile_end[n] = tiles;

@@ -806,9 +806,16 @@ class Plan:
             sync('tfx_fork', 2 * i)
             # (round 5 tried net.3's bias gradient as this GEMM's `colsum` to free 8 registers of the pull kernel: the SUM form of the GEMM is 13 us slower per
             # launch (158 vs 145 us, profiles/r05_shapes.txt) - and with its scale row in LDS the pull kernel no longer spills WITH the bias partials)
-            self._tn_group(L, T, [(d, di, dict(A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)),
-                                  (2 * dip, d, dict(algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
-                                                    C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias')))], side=side)
+            ff_grp = [(d, di, dict(A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)),
+                      (2 * dip, d, dict(algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
+                                        C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias')))]
+            # TFX_TN_LAYER_GROUP=1: these two wait for the attention wrapper's products and the whole layer goes out as ONE launch of up to 6 products (only with
+            # the side stream's separate dy_f / dy_a parity buffers: without it the attention backward overwrites dy_f first).  Measured: weight-gradient family
+            # 4.21 -> 3.97 ms bracketed, but the overlapped step 25.05 / 25.16 -> 25.32 / 25.09 ms (gpurun_out/ow38_step.txt): one big launch late in the layer
+            # overlaps less with the main stream than two - off
+            layer_group = side and os.environ.get('TFX_TN_LAYER_GROUP', '0') == '1' and os.environ.get('TFX_TN_GROUP', '1') != '0'
+            if not layer_group:
+                self._tn_group(L, T, ff_grp, side=side)
             self._nt(L, algo_k=2 * di, A=dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             a_pref = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                                     gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
@@ -870,6 +877,10 @@ class Plan:
                 else:
                     grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)))
                     grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)))
+            if layer_group and len(ff_grp) + len(grp) <= 6:
+                grp = ff_grp + grp
+            elif layer_group:
+                self._tn_group(L, T, ff_grp, side=side)
             self._tn_group(L, T, grp, side=side)
             per = -(-D // self.dp_groups) if self.dp_groups > 0 else D
             if I > 0 and i % per == 0:
