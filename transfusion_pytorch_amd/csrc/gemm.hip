@@ -2484,6 +2484,9 @@ static TnGroupPlan tn_group_plan(const GemmTN& head) {
   const int last = head.M % chunk == 0 ? chunk : head.M % chunk;
   if (chunk < 192 || last < 192) return gp;
   gp.grid = (tiles * gp.splits + 7) / 8 * 8;
+  // a group must still fill the chip: 132 tiles (dim 1024: 1024 x 2752 + 5504 x 1024) cannot be cut into two chunk rounds and would run on 132 of 256 CUs where
+  // the two products alone put 220 and 176 blocks out (config 3 measured 183.1 ms grouped against 179.4; gpurun_out/ow40.txt) - such chains run one by one
+  if (head.splits == 0 && tiles * gp.splits < 0.8 * 256) return gp;
   for (int i = 0; i < n; i++) gp.g.p[i].splits = gp.splits;
   gp.ok = true;
   return gp;

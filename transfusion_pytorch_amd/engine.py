@@ -299,11 +299,12 @@ class Plan:
             self.gx = {i: e(T, d) for i in range(D) if md.has_skip(i)}; self.du = e(T, d)
             # weight-gradient GEMMs run on a side stream one layer behind the data-gradient chain (TFX_SIDE_STREAM=0: one stream):
             # the buffers they read are kept per wrapper and double-buffered by layer parity
-            # measured (A/B on one box): dim 512 -2 % step time, dim 768 +2 %, dim 1024 +4 % - with wider models the GEMMs dominate and two
-            # GEMM kernels sharing the chip cost more than the token-wise overlap gains, so the side stream is used up to dim 512 only
+            # measured (A/B on one box): dim 512 -2 % step time; through round 5's first session dim 768 +2 % and dim 1024 +4 % (two 8-wave GEMM kernels sharing the
+            # chip cost more than the token-wise overlap gained), so the side stream stopped at dim 512.  With the one-wave weight-gradient kernels and their
+            # grouped launches it pays at every BASELINE width: dim 768 84.2 -> 83.0 ms, dim 1024 184.2 -> 181.8 ms per step (gpurun_out/ow41.txt, two rounds)
             # (TFX_SIDE_STREAM=1 forces it on, =0 off)
             env = os.environ.get('TFX_SIDE_STREAM')
-            self.side = D <= 30 and (env == '1' or (env is None and md.dim <= 512))
+            self.side = D <= 30 and (env == '1' or (env is None and md.dim <= 1024))
             nb = 2 if self.side else 1
             self.dy_f = [e(T, d) for _ in range(nb)]; self.dy_a = [e(T, d) for _ in range(nb)] if self.side else self.dy_f
             self.dskip = {j: e(T, d) for j in set(skip_sources(md).values())}
