@@ -9,8 +9,8 @@ mkdir -p $W/pkg/csrc $W/include          # the sources include "../../include/tf
 if [ "$REV" = WORK ]; then
   cp $R/transfusion_pytorch_amd/csrc/* $W/pkg/csrc/; cp $R/include/tfx.h $W/include/
 else
-  for f in gemm.hip attention.hip tokenwise.hip decode.hip collective.hip runner.hip tfx_common.h tfx_kernels.h; do git -C $R show $REV:transfusion_pytorch_amd/csrc/$f > $W/pkg/csrc/$f 2>/dev/null || rm -f $W/pkg/csrc/$f; done
-  git -C $R show $REV:include/tfx.h > $W/include/tfx.h
+  git -C $R archive $REV transfusion_pytorch_amd/csrc include/tfx.h | tar -x -C $W                     # the whole directory: the generated asm loops (*.inc) are sources too
+  cp $W/transfusion_pytorch_amd/csrc/* $W/pkg/csrc/
 fi
 OBJS=""
 for s in gemm attention tokenwise decode collective runner; do

@@ -12,8 +12,9 @@ Writes transfusion_pytorch_amd/csrc/gemm_tn_ow_loop.inc.  Operands (OW_TN_OPERAN
   %0-15 accumulators acc[i][j] (AGPR; i = block of 32 A columns = output rows, j = block of 32 B columns) | %16-19 / %20-23 fragment-read addresses of
   the A / B column blocks | %24 / %25 DMA lane offsets A / B | %26 LDS address of the wave's first A piece in the DMA target buffer | %27 steps left |
   %28 scratch SGPR | %29 +-64 KiB | %30 / %31 buffer resources | %32 / %33 bytes between two pieces (4 rows) | %34 / %35 bytes between two steps (64 rows)
-gemm_tn_ow_sum.inc (the waves that also form the bias gradient, A^T x ones: 16 more MFMAs per step) has four more outputs, the column-sum accumulators
-(VGPR) %30-33, which moves the inputs to %34-39, and one more input, the ones operand %40.
+gemm_tn_ow_sum01.inc / _sum23.inc (the waves of the first K columns also form the bias gradient, A^T x ones: the wk = 0 wave for its A blocks 0, 1, the wk = 1 wave -
+which holds the same A fragments - for blocks 2, 3: 8 more MFMAs per step each) have two more outputs, the column-sum accumulators (VGPR) %30-31, which moves the
+inputs to %32-37, and one more input, the ones operand %38.
 """
 import argparse
 import os
@@ -24,6 +25,7 @@ def RB(j): return 20 + j
 VOA, VOB, SM, CNT, SO, DELTA, RSA, RSB, STA, STB, KSA, KSB = 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35
 SUMS, ONES = 36, 40
 SUM = False
+SUM_BLOCKS = (0, 1, 2, 3)          # the A blocks whose column sums this loop form accumulates (gemm_tn_ow_sum01.inc: 0, 1 - the wk = 0 wave; sum23: 2, 3 - the wk = 1 wave)
 F0 = 64                                # first fragment register
 def FA(i, ks): return F0 + (ks >> 1) * 64 + (ks & 1) * 16 + i * 4          # v[FA : FA + 3]; halves of the step: ks 0,1 -> v64-127, ks 2,3 -> v128-191
 def FB(j, ks): return F0 + (ks >> 1) * 64 + 32 + (ks & 1) * 16 + j * 4
@@ -136,8 +138,10 @@ def body(kind, zero=False, loop=None):
         lines.append(mfma(m, zero))
         if SUM and m % 4 == 3:                                   # behind the four MFMAs of (k-step, A block i): the block's column sums (AHEAD of the gap's fillers: the last gap holds the loop branch)
             half, r = divmod(m, 32); ksl, r = divmod(r, 16); i = r // 4; ks = half * 2 + ksl
-            c = "0" if (zero and ks == 0) else f"%{SUMS + i}"
-            lines.append(f"v_mfma_f32_32x32x16_bf16 %{SUMS + i}, {vr(FA(i, ks), 4)}, %{ONES}, {c}")
+            if i in SUM_BLOCKS:
+                acc = SUMS + SUM_BLOCKS.index(i)
+                c = "0" if (zero and ks == 0) else f"%{acc}"
+                lines.append(f"v_mfma_f32_32x32x16_bf16 %{acc}, {vr(FA(i, ks), 4)}, %{ONES}, {c}")
         lines += fill[m]
     return lines
 
@@ -180,9 +184,11 @@ def main():
     for k in vars(OPT): setattr(OPT, k, getattr(a, k))
     here = os.path.dirname(os.path.abspath(__file__))
     out = a.out or os.path.join(here, "..", "transfusion_pytorch_amd", "csrc", "gemm_tn_ow_loop.inc")
-    global SUM, RSA, RSB, STA, STB, KSA, KSB, SUMS, ONES
-    for SUM, path in ((False, out), (True, out.replace("_loop.inc", "_sum.inc"))):
-        if SUM: SUMS, RSA, RSB, STA, STB, KSA, KSB, ONES = 30, 34, 35, 36, 37, 38, 39, 40
+    global SUM, RSA, RSB, STA, STB, KSA, KSB, SUMS, ONES, SUM_BLOCKS
+    # the bias gradient is shared by the two waves that hold the same A fragments (wk = 0 sums blocks 0, 1; wk = 1 blocks 2, 3): 8 more MFMAs per step on each
+    # instead of 16 on one of them (two column-sum accumulators %30, %31; inputs %32-37, ones %38)
+    for SUM, SUM_BLOCKS, path in ((False, (), out), (True, (0, 1), out.replace("_loop.inc", "_sum01.inc")), (True, (2, 3), out.replace("_loop.inc", "_sum23.inc"))):
+        if SUM: SUMS, RSA, RSB, STA, STB, KSA, KSB, ONES = 30, 32, 33, 34, 35, 36, 37, 38
         L = program()
         with open(path, "w") as f:
             f.write("// GENERATED by tools/gen_tn_ow_loop.py - do not edit; operands and schedule are documented there.  Fragments: fixed registers v[64:191].\n")

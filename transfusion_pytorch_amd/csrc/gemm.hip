@@ -2044,8 +2044,8 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void gemm_tn_wide_kernel(GemmTN p)
 // one MFMA operand), two 64 KiB LDS buffers fed by `buffer_load_dwordx4 ... lds` with two steps in flight, two barriers per step - in ONE generated
 // inline-asm block (gemm_tn_ow_loop.inc, tools/gen_tn_ow_loop.py).  Per MFMA it reads 0.5 KiB of fragments from LDS where the 8-wave kernel above reads
 // 0.75 KiB.  Same sub-slab layout, same accumulation order (rows in order, 16 per MFMA), same split-M atomics.  No dead-fragment skipping (ragged N / K
-// tiles compute on whatever the next rows hold and drop it at the store); the folded bias gradient is a second loop form (gemm_tn_ow_sum.inc) taken by
-// the waves of the first K columns.
+// tiles compute on whatever the next rows hold and drop it at the store); the folded bias gradient is a second pair of loop forms (gemm_tn_ow_sum01 / sum23.inc)
+// taken by the waves of the first K columns.
 // Needs chunks of >= 192 rows in multiples of 64.
 // ------------------------------------------------------------------------------------------------
 #define OWT_OUT                                                                                                                                     \
@@ -2109,15 +2109,25 @@ TFX_DEV void tn_ow_body(const GemmTN& p, const TnBlock& blk) {
     }
   }
   f32x16 acc[4][4];
-  f32x16 accs[SUM ? 4 : 1];                                              // bias gradient: A^T x ones, on the waves of the first K columns
-  const bool do_sum = SUM && p.colsum != nullptr && k0 == 0 && wk == 0;  // wave-uniform; both loop forms pass the same barriers
+  // bias gradient: A^T x ones in the blocks of the first K columns, shared by the two waves that hold the same A fragments - wk = 0 sums its A blocks 0, 1, wk = 1
+  // blocks 2, 3 (8 more MFMAs per step each instead of 16 on one wave: the block's pace is its slowest wave's).  Every loop form passes the same barriers.
+  f32x16 accs[2];
+  const bool do_sum = SUM && p.colsum != nullptr && k0 == 0;             // block-uniform; the wave's half by wk
   if (do_sum) {
     u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    asm volatile(
-#include "gemm_tn_ow_sum.inc"
-        : OWT_OUT, "=&v"(accs[0]), "=&v"(accs[SUM ? 1 : 0]), "=&v"(accs[SUM ? 2 : 0]), "=&v"(accs[SUM ? 3 : 0])
-        : OWT_IN, "v"(ones)
-        : OWT_CLOBBER);
+    if (wk == 0) {
+      asm volatile(
+#include "gemm_tn_ow_sum01.inc"
+          : OWT_OUT, "=&v"(accs[0]), "=&v"(accs[1])
+          : OWT_IN, "v"(ones)
+          : OWT_CLOBBER);
+    } else {
+      asm volatile(
+#include "gemm_tn_ow_sum23.inc"
+          : OWT_OUT, "=&v"(accs[0]), "=&v"(accs[1])
+          : OWT_IN, "v"(ones)
+          : OWT_CLOBBER);
+    }
   } else {
     asm volatile(
 #include "gemm_tn_ow_loop.inc"
@@ -2145,7 +2155,7 @@ TFX_DEV void tn_ow_body(const GemmTN& p, const TnBlock& blk) {
     for (int r = 0; r < 16; r++) {
       const int no = out_row[r];
       if (no < 0) continue;
-      if (SUM && do_sum && (l & 31) == 0) atomicAdd(p.colsum + no, accs[SUM ? i : 0][r]);
+      if (SUM && do_sum && (i >> 1) == wk && (l & 31) == 0) atomicAdd(p.colsum + no, accs[i & 1][r]);
       float* crow = p.C + (size_t)no * p.ldc;
 #pragma unroll
       for (int j = 0; j < 4; j++)
