@@ -2504,8 +2504,10 @@ static TnGroupPlan tn_group_plan(const GemmTN& head) {
 static int tn_ramp(int M, int tiles, int splits) {   // tn_block_ramp's d for a launch (see the kind-3 branch of gemm_tn)
   static double ramp_f = -1;
   if (ramp_f < 0) { const char* e = getenv("TFX_TN_RAMP"); ramp_f = e ? atof(e) : 1.0; }
+  static int ramp_min = -1;            // TFX_TN_RAMP_MIN: fewest row chunks that get a ramp (default 8: 2-5-chunk launches measured nothing to +1 %; 6 - the 7-chunk FeedForward group - 4.19 -> 4.17 ms, noise)
+  if (ramp_min < 0) { const char* e = getenv("TFX_TN_RAMP_MIN"); ramp_min = e ? atoi(e) : 8; }
   int ramp = 0;
-  if (splits >= 8 && ramp_f > 0 && M % TN_BMK == 0) {
+  if (splits >= ramp_min && ramp_f > 0 && M % TN_BMK == 0) {
     const int S = splits, U = M / TN_BMK;
     ramp = (int)(0.148 * tiles * ramp_f + 0.5);
     while (ramp > 0 && (U - ramp * S * (S - 1) / 2) / S < 8) ramp--;   // the shortest chunk keeps >= 8 steps
