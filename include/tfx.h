@@ -115,7 +115,8 @@ typedef struct {
 int tfx_gemm_tn(const tfx_gemm_tn_args* a, void* stream);
 /* what tfx_gemm_tn would launch for these arguments, without launching (host logic only, no device needed): kernel form (-1 register-staged
  * fallback, 0 = 128 x 128 tiles / 4 waves, 2 = 256 x 256 / 8 waves, 3 = 256 x 256 / 4 waves of 128 x 128 (one wave per SIMD, round 5)), output tiles,
- * row chunks (`splits`, chosen when a->splits == 0), grid. */
+ * row chunks (`splits`, chosen when a->splits == 0), grid.  For the head of a `group_next` chain that runs as one launch: kind 3 with the chain's summed tiles, its
+ * chunk count and grid; a chain that runs product by product reports the head's own plan. */
 int tfx_gemm_tn_plan(const tfx_gemm_tn_args* a, int32_t* kind, int32_t* tiles, int32_t* splits, int32_t* grid);
 
 /* ---- attention ------------------------------------------------------------------------------- */

@@ -2540,7 +2540,9 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
       else { ensure_smem_attr((const void*)gemm_tn_ow_group_kernel<false>, 131072, attr_g0); hipLaunchKernelGGL(gemm_tn_ow_group_kernel<false>, dim3(gp.grid), dim3(256), 131072, s, gp.g, ramp); }
       return (int)hipGetLastError();
     }
+    int guard = 0;
     for (const GemmTN* q = &p; q; q = (const GemmTN*)q->group_next) {     // not groupable: the chain's products one by one
+      if (++guard > 64) return -7;                                       // (a chain that loops back on itself)
       GemmTN one = *q; one.group_next = nullptr;
       const int rc = gemm_tn(one, s);
       if (rc) return rc;
