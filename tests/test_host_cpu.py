@@ -454,3 +454,52 @@ def test_tn_grouped_launch_plan():
     assert plan([args(T, 512, 512), args(T, 1544, 512, a_rowmap=64)]) == (0, 16, 16, 256)          # a gathered member: the head's own plan
     assert plan([args(T, 512, 512), args(T // 2, 1544, 512)])[0] == 0                              # different row counts
     assert plan([args(T, 512, 512) for _ in range(7)])[0] == 0                                     # more than six members
+
+
+def test_asm_loop_schedule_invariants():
+    """Static checks of the generated K-loop bodies (tools/gen_nt_ow_loop.py, tools/gen_tn_ow_loop.py) - what a GPU run would only show as a wrong number or a hang:
+    a steady K-tile issues exactly the 16 DMA pieces of the next-but-one K-tile and reads every fragment of a K-tile once; its counted `vmcnt` wait names exactly the
+    pieces issued ahead of it (so the PREVIOUS K-tile's sixteen are what it certifies); every wave passes the same number of barriers in every loop form of a kernel
+    (the bias-gradient forms share their blocks with the plain form); the scalar M0 / offset updates precede the DMA piece that uses them."""
+    import importlib.util, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, 'tools', name + '.py'))
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+        return m
+
+    def check_steady(lines, n_reads, n_mfma):
+        assert sum(ln.startswith('v_mfma') for ln in lines) == n_mfma
+        dma = [i for i, ln in enumerate(lines) if ln.startswith('buffer_load_dwordx4') and ln.endswith('lds')]
+        assert len(dma) == 16
+        assert sum(ln.startswith('ds_read') for ln in lines) == n_reads
+        waits = [(i, ln) for i, ln in enumerate(lines) if ln.startswith('s_waitcnt vmcnt')]
+        assert len(waits) == 1
+        i, ln = waits[0]
+        assert int(ln.split('(')[1].rstrip(')')) == sum(d < i for d in dma), ln
+        nxt_read = next(k for k in range(i, len(lines)) if lines[k].startswith('ds_read'))
+        assert 's_barrier' in lines[i:nxt_read]                                             # the wait is published by a barrier before anybody reads the K-tile it certifies
+        for d in dma:                                                                        # m0 is set / advanced between two consecutive pieces
+            prev = max([x for x in dma if x < d], default=-1)
+            assert any('m0' in lines[k] and lines[k].startswith('s_') for k in range(prev + 1, d)), lines[d]
+        return sum(ln == 's_barrier' for ln in lines)
+
+    nt = load('gen_nt_ow_loop')
+    bars = check_steady(nt.body('steady', loop=None), 32, 64)
+    assert bars == 3
+    assert check_steady(nt.body('steady', zero=True, loop=None), 32, 64) == 3
+    assert sum(ln.startswith('ds_read') for ln in nt.body('t2')) == 16 and sum(ln == 's_barrier' for ln in nt.body('t2')) == 0
+    tn = load('gen_tn_ow_loop')
+    tn.SUM = False
+    plain = check_steady(tn.body('steady'), 64, 64)
+    tn.SUM, tn.SUM_BLOCKS, tn.SUMS, tn.ONES = True, (0, 1), 30, 38
+    summed = check_steady(tn.body('steady'), 64, 72)
+    assert plain == summed == 3
+    for kind in ('t1', 't2'):
+        tn.SUM = False; a = sum(ln == 's_barrier' for ln in tn.body(kind))
+        tn.SUM = True; b = sum(ln == 's_barrier' for ln in tn.body(kind))
+        assert a == b
+    # a back branch is the LAST instruction of its body
+    body = tn.body('steady', loop='L_x')
+    assert body[-1] == 's_cbranch_scc1 L_x' and body[-2].startswith('s_cmp')
