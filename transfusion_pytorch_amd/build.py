@@ -14,8 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libtfx_hip.so')
 SOURCES = ['gemm.hip', 'attention.hip', 'tokenwise.hip', 'decode.hip', 'collective.hip', 'runner.hip']
-HEADERS = [os.path.join(CSRC, 'tfx_common.h'), os.path.join(CSRC, 'tfx_kernels.h'), os.path.join(CSRC, 'gemm_nt_ow_loop.inc'), os.path.join(CSRC, 'gemm_nt_owp_pro.inc'), os.path.join(CSRC, 'gemm_nt_owp_next.inc'), os.path.join(CSRC, 'gemm_nt_owp_last.inc'), os.path.join(CSRC, 'gemm_tn_ow_loop.inc'), os.path.join(CSRC, 'gemm_tn_ow_sum01.inc'), os.path.join(CSRC, 'gemm_tn_ow_sum23.inc'),
-           os.path.join(os.path.dirname(HERE), 'include', 'tfx.h')]
+HEADERS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.h', '.inc'))] + [os.path.join(os.path.dirname(HERE), 'include', 'tfx.h')]   # incl. the generated asm loops
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result'] + os.environ.get('TFX_HIPCC_EXTRA', '').split()   # e.g. -DTFX_PP_TIMING (tools/pp_timing.py)
 
 # per-file flags.  attention.hip: hipcc's SLP vectoriser packs adjacent fp32 adds / multiplies into v_pk_*_f32, which issue in 6.5 clocks per

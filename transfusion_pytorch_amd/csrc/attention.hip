@@ -556,6 +556,12 @@ TFX_DEV void fwd_drain(u32x4 (&p_prev)[2], f32x16 (&o)[2], const bf16* Vt_prev, 
   asm volatile("s_nop 7" : "+v"(vt[0]), "+v"(vt[1]), "+v"(vt[2]), "+v"(vt[3]), "+v"(p_prev[0]), "+v"(p_prev[1]));     // operands stay untouched while the last MFMA reads them
 }
 
+// ASM (round 6): the tiles every row of the block sees in full run in ONE generated asm statement (tools/gen_attn_loops.py: fixed registers, every LDS address a
+// lane register + an immediate, the vector stream at its 88-instruction floor per unit with the MFMAs and LDS reads placed inside it); the boundary tiles - the
+// last two of a causal block - stay on the C++ phases below.  The statement follows the C++ loop's tile protocol (wait + barrier at the top of a tile, then the
+// requests for K(j + 2) / V(j + 1)) and its arithmetic order: the hand-over is at a tile boundary and the outputs are bit-identical to the <false> form.
+// Training layouts only (no KV cache, no compacted rows: kv_end non-decreasing over a sample's rows), soft-cap plan modes 0 / 1.
+template <bool ASM>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(1024))) bf16 Ks[3][64 * 64];      // rings of LDS-DMA tiles (see swz_f): K(j), K(j+1), K(j+2) / V(j-1), V(j), V(j+1)
   __shared__ __attribute__((aligned(1024))) bf16 Vs[3][64 * 64];
@@ -606,7 +612,73 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(tfx_attn_args p) 
 #define AT_MARK(i)
 #define TS_ARG
 #endif
-  for (int j = 0; j < nt; j++) {
+  int j0 = 0;
+  if constexpr (ASM) {
+    // tiles 0 .. nfull - 1: every key visible to every row of the block (kv_end is non-decreasing: the block's first row sees the fewest), and the
+    // statement's unconditional requests for K(j + 2) / V(j + 1) stay inside the sample
+    const int kve_blk = __builtin_amdgcn_readfirstlane(p.kv_end[tok0 + q0]);
+    const int nfull = __builtin_amdgcn_readfirstlane(min(kve_blk >> 6, (nkv - 128) >> 6));
+    if (nfull > 0 && sc_.mode <= 1) {                              // (block-uniform)
+      const int wu = __builtin_amdgcn_readfirstlane(w);
+      const uint32_t ldsK = (uint32_t)(size_t)(lds_void_t*)&Ks[0][0], ldsV = (uint32_t)(size_t)(lds_void_t*)&Vs[0][0];
+      uint32_t ka[4], vaA[2], vaB[2], dk[2], dv[2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) ka[ks] = ldsK + 2u * (uint32_t)((l & 31) * 64 + (((2 * ks + hi) ^ swz_f(l & 31)) << 3));      // dma_rowfrag, slot 0, key block 0
+      {
+        const int q = l & 15, ra = 4 * hi + (q >> 2), rb = ra + 8;                                                               // dma_tr8, slot 0, rowA = 4 hi
+#pragma unroll
+        for (int db = 0; db < 2; db++) {
+          const int col = db * 32 + 16 * ((l >> 4) & 1) + 4 * (q & 3);
+          vaA[db] = ldsV + 2u * (uint32_t)(ra * 64 + (((col >> 3) ^ swz_f(ra)) << 3) + (col & 7));
+          vaB[db] = ldsV + 2u * (uint32_t)(rb * 64 + (((col >> 3) ^ swz_f(rb)) << 3) + (col & 7));
+        }
+      }
+#pragma unroll
+      for (int jp = 0; jp < 2; jp++) {                                                                                           // tile_dma's pieces as buffer offsets
+        const int r = w * 16 + jp * 8 + (l >> 3), c = (l & 7) ^ swz_f(r);
+        dk[jp] = 2u * (uint32_t)(r * p.ld_k + c * 8);
+        dv[jp] = 2u * (uint32_t)(r * p.ld_v + c * 8);
+      }
+      const uint64_t baseK = (uint64_t)(uintptr_t)kb_, baseV = (uint64_t)(uintptr_t)vb;
+      u32x4 rsK, rsV;
+      rsK[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseK); rsK[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseK >> 32) & 0xffffu); rsK[2] = 0xffffff00u; rsK[3] = 0x00020000u;
+      rsV[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseV); rsV[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseV >> 32) & 0xffffu); rsV[2] = 0xffffff00u; rsV[3] = 0x00020000u;
+      const uint32_t stk = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ld_k), stv = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ld_v);
+      uint32_t sko = 2u * stk, svo = stv, cnt = (uint32_t)nfull;
+      const uint32_t mk = __builtin_amdgcn_readfirstlane(ldsK + (uint32_t)wu * 2048u), mv = __builtin_amdgcn_readfirstlane(ldsV + (uint32_t)wu * 2048u);
+      const float p1 = sc_.p1, p3 = sc_.p3, p5 = sc_.p5;
+      u32x4 q0f = __builtin_bit_cast(u32x4, qf[0]), q1f = __builtin_bit_cast(u32x4, qf[1]), q2f = __builtin_bit_cast(u32x4, qf[2]), q3f = __builtin_bit_cast(u32x4, qf[3]);
+      // EARLY-CLOBBER in-outs ("+&"): `svo` starts out equal to the input `stv`; without the & hipcc gave both ONE register (it assumes a statement reads its inputs
+      // before it writes its outputs) and the V tile offset doubled per tile instead of advancing (first GPU trips: V(4) in V(3)'s slot - and only in the -fPIC build)
+#define AF_OPERANDS                                                                                                                                  \
+          : [o0] "+&v"(o[0]), [o1] "+&v"(o[1]), "+{v[64:79]}"(sA), "+{v[104:107]}"(pB[0]), "+{v[108:111]}"(pB[1]), "+{v112}"(lsum[0]), "+{v113}"(lsum[1]),    \
+            [sko] "+&s"(sko), [svo] "+&s"(svo), [cnt] "+&s"(cnt)                                                                                     \
+          : [qf0] "v"(q0f), [qf1] "v"(q1f), [qf2] "v"(q2f), [qf3] "v"(q3f), [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]),  \
+            [va0] "v"(vaA[0]), [va1] "v"(vaA[1]), [vb0] "v"(vaB[0]), [vb1] "v"(vaB[1]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]), \
+            [rsk] "s"(rsK), [rsv] "s"(rsV), [stk] "s"(stk), [stv] "s"(stv), [mk] "s"(mk), [mv] "s"(mv), [p1] "v"(p1), [p3] AF_P3(p3), [p5] "s"(p5)   \
+          : "memory", "scc", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",         \
+            "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124",      \
+            "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141",  \
+            "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151"
+      if (sc_.mode == 0) {
+#define AF_P3 "s"
+        asm volatile(
+#include "attn_fwd_loop_m0.inc"
+            AF_OPERANDS);
+#undef AF_P3
+      } else {
+#define AF_P3 "v"
+        asm volatile(
+#include "attn_fwd_loop_m1.inc"
+            AF_OPERANDS);
+#undef AF_P3
+      }
+#undef AF_OPERANDS
+      j0 = nfull;
+      kslot = vslot = nfull % 3;
+    }
+  }
+  for (int j = j0; j < nt; j++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of K(j + 1), V(j) have landed
     __builtin_amdgcn_s_barrier();                                 // ... everyone's have, and everyone is done with K(j - 1), V(j - 2)
     AT_MARK(0)
@@ -1009,7 +1081,13 @@ int attn_fwd(const tfx_attn_args& p, hipStream_t s) {
   if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out) & 7) return -2;
   if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;     // fixed-reference softmax needs exp2(cap*log2e) finite in fp32 sums
   tfx_attn_args q = p; q.order = attn_order();
-  if (attn_pipe()) hipLaunchKernelGGL(attn_fwd_pipe_kernel, attn_grid(q), dim3(256), 0, s, q);
+  // TFX_ATTN_ASM=1: the generated main loop for the unmasked tiles (bit-identical; OFF - measured round 6, profiles/r06_attn_fwd_asm_*: the loop's 88-instruction
+  // vector stream is 27 us of the launch, but 76 us of the 134 are prologue, boundary tiles and epilogue, and at 179 registers two blocks share a CU where the
+  // hipcc form (165) fits three: 145 against 134 us per launch in the step)
+  static int use_asm = -1;
+  if (use_asm < 0) { const char* e = getenv("TFX_ATTN_ASM"); use_asm = (e && e[0] == '1') ? 1 : 0; }
+  if (attn_pipe() && use_asm && p.n_kv == 0 && !p.q_cnt && !p.q_row0 && p.sc_plan) hipLaunchKernelGGL(attn_fwd_pipe_kernel<true>, attn_grid(q), dim3(256), 0, s, q);
+  else if (attn_pipe()) hipLaunchKernelGGL(attn_fwd_pipe_kernel<false>, attn_grid(q), dim3(256), 0, s, q);
   else hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(q), dim3(256), 0, s, q);
   return (int)hipGetLastError();
 }

@@ -257,8 +257,8 @@ class FusedAdam:
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, max_norm=max_norm,
                            grad_scale=gscale, step=self.step_count, sumsq=self.sumsq)
         capi.call('tfx_adam_step', a, stream)
-        # the master changed behind autograd's back: bump the version counters so the bf16 shadows are rebuilt
-        ps._shadow_version = None
+        # the master changed behind autograd's back: new weights epoch (shadows rebuilt, kept decode plans dropped)
+        ps.mark_dirty()
 
     def zero_grad(self, set_to_none: bool = True):
         ps = self.model.store

@@ -230,6 +230,7 @@ class ParamStore:
         _attach(root, 'rotary_emb.freqs', self.rot_param)
         self.shadows = {}
         self._shadow_version = None
+        self._epoch = 0                      # bumped by every write autograd cannot see (fused Adam, EMA kernel, mark_weights_changed): part of params_version()
         self._maps = {}
         self._jobs, self._job_table = [], None
         self._exp_ptrs = None
@@ -269,15 +270,17 @@ class ParamStore:
         self._maps = {}
 
     def mark_dirty(self):
-        """the master buffer changed behind autograd's back (fused optimizer / EMA kernels): rebuild the bf16 shadows on next use"""
+        """the master buffer changed behind autograd's back (fused optimizer / EMA kernels): rebuild the bf16 shadows on next use, and move
+        `params_version()` - everything keyed on it (the decode plans `sample_many` keeps, with their weight-derived AdaLN tables) is stale"""
         self._shadow_version = None
+        self._epoch += 1
 
     def params_version(self):
         """changes autograd can see: the version counters (optimizers, `load_state_dict`, `p.copy_` ...).  A parameter whose `.data` was RE-ASSIGNED
         (`p.data = w`) no longer points into the flat master buffer the kernels and the fused optimizer read: it is copied back into its slice and
         re-pointed here.  In-place writes THROUGH `.data` (`p.data.mul_(0.5)`) bump no counter and move no pointer - nothing can see them; callers
         that edit weights that way call `Transfusion.mark_weights_changed()`."""
-        ver = self.fourier_w._version
+        ver = self.fourier_w._version + (self._epoch << 32)         # raw-kernel writes (mark_dirty) are versions too (ADVICE r5)
         # (this runs on every forward: one data_ptr() and one version read per parameter against a cached list of expected addresses - the
         #  list is rebuilt when the flat buffer moves - instead of a name lookup + offset arithmetic per parameter)
         base = self.flat.data_ptr()
