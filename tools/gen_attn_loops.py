@@ -42,24 +42,24 @@ class Emit:
         self.lines = []
         self.lds_q = []           # outstanding LDS reads, oldest first (names)
     def op(self, s):
-        if os.environ.get("GEN_EMPTY") and not s.startswith(("s_sub_u32 %[cnt]", "s_cmp", "s_cbranch", "L_af")): return       # (timing build: the loop's control flow only)
-        if os.environ.get("GEN_NOVALU") and s.startswith(("v_mul", "v_fma", "v_exp", "v_add", "v_cvt")): return      # (timing build)
+        if os.environ.get("GEN_EMPTY") and not s.startswith(("s_sub_u32 %[cnt]", "s_cmp_eq_u32 %[cnt]", "s_cbranch_scc1 L_af_exit", "s_cbranch_scc0 L_af_loop", "s_cbranch_scc1 L_dq_exit", "s_cbranch_scc0 L_dq_loop", "L_af_loop", "L_af_exit", "L_dq_loop", "L_dq_exit")): return       # (timing build: the loop's control flow only)
+        if os.environ.get("GEN_NOVALU") and s.startswith(("v_mul", "v_fma", "v_exp", "v_add", "v_cvt", "v_sub", "v_cmp", "v_cndmask")): return      # (timing build)
+        if os.environ.get("GEN_NOEXP") and s.startswith("v_exp"): return
         if os.environ.get("GEN_NOMFMA") and s.startswith("v_mfma"): return
         self.lines.append(s)
     def lds_read(self, name, text):
         if os.environ.get("GEN_NOLDS") or os.environ.get("GEN_EMPTY"): return                    # (timing build)
         self.lines.append(text)
         self.lds_q.append(name)
-        assert len(self.lds_q) <= 15, "lgkmcnt is a 4-bit counter"
     def need(self, names):
         """wait until the LDS reads `names` have landed (in-order return): allow everything issued after the youngest of them."""
         idx = [i for i, n in enumerate(self.lds_q) if n in names]
         if not idx:
             return
         last = max(idx)
-        allow = len(self.lds_q) - 1 - last
+        allow = min(len(self.lds_q) - 1 - last, 15)               # (a 4-bit counter: more than 15 younger reads in flight = wait until 15 are left)
         self.lines.append(f"s_waitcnt lgkmcnt({allow})")
-        self.lds_q = self.lds_q[last + 1:]
+        self.lds_q = self.lds_q[len(self.lds_q) - allow:] if allow else []
     def drain(self):
         if self.lds_q:
             self.lines.append("s_waitcnt lgkmcnt(0)")
@@ -207,10 +207,211 @@ def program_fwd(mode):
     return e.lines
 
 
-def write_inc(out, L, what):
+# =====================================================================================================================
+# backward dQ (attn_bwd_dq_asm_kernel): the WHOLE tile loop - fill, every unit incl. the masked boundary units, drain
+# =====================================================================================================================
+# Measured (profiles/r06_attn_bwd_what_bounds_it.txt): the hipcc kernels issue ~470 instructions per 32-key unit and wave where the arithmetic needs ~175
+# (136 vector, 12 MFMA, 16 LDS reads, waits) - fragment-address arithmetic, register copies, s_nop padding - and run at one instruction per ~2.9 clocks and
+# SIMD whatever the mix: the kernels are ISSUE-bound, a software pipeline at the C++ level (attn_bwd_dq_pipe_kernel) changed nothing (226 vs 227 us).
+# Unit u = one phase of 8 chunks; chunk c = its MFMAs + the vector work of scores 2c, 2c + 1:
+#     MFMAs   S0 dP0 | S1 | dP1 S2 | dP2 | S3 dP3 | dQ0 | dQ1 dQ2 | dQ3      S / dP of unit u + 1 (operands read one phase earlier), dQ += dS K of unit u - 1
+#     vector  u = s^2, tanh' = d1 + d3 u, s2 = s (p1 + p3 u) - lse2, P = exp2, dS = P ((dP - delta) tanh') -> bf16 pairs                  17 (21) per chunk
+#     LDS     every operand fragment has its own registers and is re-read for the NEXT phase right behind the MFMA that consumed it
+# K and V tiles in rings of four (one LDS array: V slot s at +32 KiB), requested two tiles ahead, ONE barrier per tile; the rings are unrolled (tiles j % 4).
+DQ0 = 64
+D_SA, D_DPA, D_SB, D_DPB = DQ0, DQ0 + 16, DQ0 + 32, DQ0 + 48
+D_DSA, D_DSB = DQ0 + 64, DQ0 + 72
+D_KF, D_VF, D_TF = DQ0 + 80, DQ0 + 96, DQ0 + 112
+D_TMP = DQ0 + 128              # 12 temporaries
+D_MT = DQ0 + 140               # mask scratch
+D_TOP = DQ0 + 141
+
+
+def dq_reads(e, kind, idx, slot, kb):
+    """(re)read one operand fragment of the NEXT phase: kind K / V = row fragment k-step idx of (slot, kb) ; T = K^T fragment (tt, db) = idx of (slot, kb)."""
+    if kind == "K":
+        e.lds_read(f"K{idx}", f"ds_read_b128 {vr(D_KF + 4 * idx, 4)}, %[ka{idx}] offset:{slot * 8192 + kb * 4096}")
+    elif kind == "V":
+        e.lds_read(f"V{idx}", f"ds_read_b128 {vr(D_VF + 4 * idx, 4)}, %[ka{idx}] offset:{32768 + slot * 8192 + kb * 4096}")
+    else:
+        tt, db = idx >> 1, idx & 1
+        off = slot * 8192 + kb * 4096 + tt * 2048
+        e.lds_read(f"T{idx}a", f"ds_read_b64_tr_b16 {vr(D_TF + 4 * idx, 2)}, %[ta{db}] offset:{off}")
+        e.lds_read(f"T{idx}", f"ds_read_b64_tr_b16 {vr(D_TF + 4 * idx + 2, 2)}, %[tb{db}] offset:{off}")
+
+
+def dq_mask(e, s_dp):
+    """boundary unit: a masked score gets dP = delta (dS = 0).  element r of this lane is key u * 32 + 4 hi + (r & 3) + 8 (r >> 2); visible iff that < kv_end."""
+    e.op(f"v_subrev_u32 {vr(D_MT)}, %[su1], %[kmaskp]")           # kv_end - 4 hi + 32 - (u + 1) * 32 = keys of this unit the lane-half sees, counted from its first
+    for r in range(16):
+        cr = (r & 3) + 8 * (r >> 2)
+        e.op(f"v_cmp_lt_i32 vcc, {cr}, {vr(D_MT)}")
+        e.op("s_nop 1")
+        e.op(f"v_cndmask_b32 {vr(s_dp + r)}, %[dlt], {vr(s_dp + r)}, vcc")
+
+
+def dq_phase(e, mode, h, nxt, prv, tag, first=False):
+    """h: 0 = vector work on (SA, DPA) -> DSA, S / dP of the next unit -> (SB, DPB), dQ with DSB ; 1 = the other way round.
+    nxt = (kslot, vslot, kb) of the unit whose S / dP fragments are read here for the next phase ; prv = (kslot, kb) of the unit whose K^T fragments are read here."""
+    s_cur, dp_cur, s_nxt, dp_nxt = (D_SA, D_DPA, D_SB, D_DPB) if h == 0 else (D_SB, D_DPB, D_SA, D_DPA)
+    ds_cur, ds_prev = (D_DSA, D_DSB) if h == 0 else (D_DSB, D_DSA)
+    # ---- boundary units: wave-uniform test (u + 1) * 32 > min kv_end of the wave
+    e.op("s_cmp_gt_i32 %[su1], %[kvemin]")
+    e.op(f"s_cbranch_scc0 L_dq_nomask_{tag}_%=")
+    dq_mask(e, dp_cur)
+    e.op(f"L_dq_nomask_{tag}_%=:")
+    e.op("s_add_u32 %[su1], %[su1], 32")
+    sched = [["S0", "P0"], ["S1"], ["P1", "S2"], ["P2"], ["S3", "P3"], ["Q0"], ["Q1", "Q2"], ["Q3"]]
+    valu = dq_valu(mode, s_cur, dp_cur, ds_cur)
+    for c in range(8):
+        pending = []
+        for m in sched[c]:
+            k, i = m[0], int(m[1])
+            if k == "S":
+                e.need([f"K{i}"])
+                cc = "0" if i == 0 else vr(s_nxt, 16)
+                e.op(f"v_mfma_f32_32x32x16_bf16 {vr(s_nxt, 16)}, {vr(D_KF + 4 * i, 4)}, %[qf{i}], {cc}")
+                pending.append(("K", i))
+            elif k == "P":
+                e.need([f"V{i}"])
+                cc = "0" if i == 0 else vr(dp_nxt, 16)
+                e.op(f"v_mfma_f32_32x32x16_bf16 {vr(dp_nxt, 16)}, {vr(D_VF + 4 * i, 4)}, %[df{i}], {cc}")
+                pending.append(("V", i))
+            elif not first:
+                tt, db = i >> 1, i & 1
+                e.need([f"T{i}"])
+                e.op(f"v_mfma_f32_32x32x16_bf16 %[dq{db}], {vr(D_TF + 4 * i, 4)}, {vr(ds_prev + 4 * tt, 4)}, %[dq{db}]")
+                pending.append(("T", i))
+            else:
+                pending.append(("T", i))
+        def put():
+            if pending:
+                k, i = pending.pop(0)
+                if k == "K": dq_reads(e, "K", i, nxt[0], nxt[2])
+                elif k == "V": dq_reads(e, "V", i, nxt[1], nxt[2])
+                else: dq_reads(e, "T", i, prv[0], prv[1])
+        # vector work of this chunk: its share of the phase's latency-ordered stream (dq_valu), LDS re-reads spread through it
+        ops = valu[c]
+        k = max(1, len(ops) // (len(pending) + 1)) if pending else len(ops) + 1
+        for n, o in enumerate(ops):
+            e.op(o)
+            if pending and (n + 1) % k == 0: put()
+        while pending: put()
+
+
+def dq_valu(mode, s_cur, dp_cur, ds_cur):
+    """the 136 (168) vector instructions of a unit, ordered for LATENCY: four scores at a time, stage by stage - a result is read four instructions after it was
+    issued, not two - and the products / packing of a group of four ride inside the NEXT group (exp2 results are consumed ~14 instructions later).
+    (First GPU trip of the asm kernel: with two scores per chunk in dependency order the VECTOR-ONLY build of the loop ran at 5.4 clocks per instruction and SIMD,
+    twice the forward's rate - two waves per SIMD do not cover back-to-back dependent instructions.)  Returns the stream cut into 8 chunks."""
+    out = []
+    u = [D_TMP + k for k in range(4)]
+    th = [D_TMP + 4 + k for k in range(4)]
+    x = [D_TMP + 8 + k for k in range(4)]                           # (mode 1 only)
+    def tail(g):
+        r = [4 * g + k for k in range(4)]
+        L = [f"v_mul_f32 {vr(s_cur + q)}, {vr(s_cur + q)}, {vr(dp_cur + q)}" for q in r]
+        L += [f"v_cvt_pk_bf16_f32 {vr(ds_cur + 2 * g + h)}, {vr(s_cur + 4 * g + 2 * h)}, {vr(s_cur + 4 * g + 2 * h + 1)}" for h in range(2)]
+        return L
+    for g in range(4):
+        r = [4 * g + k for k in range(4)]
+        L = [f"v_mul_f32 {vr(u[k])}, {vr(s_cur + r[k])}, {vr(s_cur + r[k])}" for k in range(4)]
+        if mode == 0:
+            L += [f"v_fma_f32 {vr(th[k])}, {vr(u[k])}, %[d3], %[d1]" for k in range(4)]
+        else:
+            L += [f"v_fma_f32 {vr(th[k])}, {vr(u[k])}, %[d5], %[d3]" for k in range(4)]
+            L += [f"v_fma_f32 {vr(x[k])}, {vr(u[k])}, %[p5], %[p3]" for k in range(4)]
+            L += [f"v_fma_f32 {vr(th[k])}, {vr(u[k])}, {vr(th[k])}, %[d1]" for k in range(4)]
+        L += [f"v_sub_f32 {vr(dp_cur + r[k])}, {vr(dp_cur + r[k])}, %[dlt]" for k in range(4)]
+        if g > 0: L += tail(g - 1)
+        if mode == 0:
+            L += [f"v_fma_f32 {vr(u[k])}, {vr(u[k])}, %[p3], %[p1]" for k in range(4)]
+        else:
+            L += [f"v_fma_f32 {vr(u[k])}, {vr(u[k])}, {vr(x[k])}, %[p1]" for k in range(4)]
+        L += [f"v_mul_f32 {vr(dp_cur + r[k])}, {vr(dp_cur + r[k])}, {vr(th[k])}" for k in range(4)]
+        L += [f"v_fma_f32 {vr(s_cur + r[k])}, {vr(s_cur + r[k])}, {vr(u[k])}, -%[lse2]" for k in range(4)]
+        L += [f"v_exp_f32 {vr(s_cur + r[k])}, {vr(s_cur + r[k])}" for k in range(4)]
+        if g == 3: L += tail(3)
+        out += L
+    n = len(out)
+    cuts = [round(n * c / 8) for c in range(9)]
+    return [out[cuts[c]:cuts[c + 1]] for c in range(8)]
+
+
+def dq_tile_top(e, i, tag):
+    """top of tile j (j % 4 = i): K(j + 1) / V(j + 1) have landed for every wave; K(j + 2), V(j + 2) -> slot (i + 2) % 4 while rem2 = nt - 2 - j > 0."""
+    e.op("s_waitcnt vmcnt(0)")
+    e.op("s_barrier")
+    e.op("s_cmp_gt_i32 %[rem2], 0")
+    e.op(f"s_cbranch_scc0 L_dq_nodma_{tag}_%=")
+    slot = (i + 2) % 4
+    for base, dv, rs, so in ((slot * 8192, "dk", "%[rsk]", "%[sko]"), (32768 + slot * 8192, "dv", "%[rsv]", "%[svo]")):
+        for jp in range(2):
+            e.op(f"s_add_u32 m0, %[mk], {base + jp * 1024}")
+            e.op("s_nop 0")
+            e.op(f"buffer_load_dwordx4 %[{dv}{jp}], {rs}, {so} offen lds")
+    e.op(f"L_dq_nodma_{tag}_%=:")
+    e.op("s_sub_u32 %[rem2], %[rem2], 1")
+
+
+def dq_tile(e, mode, i, tag, first=False):
+    dq_tile_top(e, i, tag)
+    if first:
+        for ks in range(4): dq_reads(e, "K", ks, 0, 0); dq_reads(e, "V", ks, 0, 0)
+        for ks in range(4):
+            e.need([f"K{ks}"])
+            e.op(f"v_mfma_f32_32x32x16_bf16 {vr(D_SA, 16)}, {vr(D_KF + 4 * ks, 4)}, %[qf{ks}], " + ("0" if ks == 0 else vr(D_SA, 16)))
+            e.need([f"V{ks}"])
+            e.op(f"v_mfma_f32_32x32x16_bf16 {vr(D_DPA, 16)}, {vr(D_VF + 4 * ks, 4)}, %[df{ks}], " + ("0" if ks == 0 else vr(D_DPA, 16)))
+        for ks in range(4): dq_reads(e, "K", ks, 0, 1); dq_reads(e, "V", ks, 0, 1)      # S / dP of unit 1
+        e.op("s_nop 15")
+    n1 = (i + 1) % 4
+    # even unit 2j: reads here = S / dP fragments of unit 2j + 2 (first halves of K(j + 1), V(j + 1)) and K^T of unit 2j (first half of K(j))
+    dq_phase(e, mode, 0, (n1, n1, 0), (i, 0), tag + "a", first=first)
+    # the tile offsets of the next requests move a phase away from the buffer instructions (a VMEM instruction reads its scalar operands after it issues)
+    e.op("s_add_u32 %[sko], %[sko], %[stk]")
+    e.op("s_add_u32 %[svo], %[svo], %[stv]")
+    # odd unit 2j + 1: reads = S / dP of unit 2j + 3 (second halves of K(j + 1), V(j + 1)) and K^T of unit 2j + 1 (second half of K(j))
+    dq_phase(e, mode, 1, (n1, n1, 1), (i, 1), tag + "b")
+
+
+def program_dq(mode):
+    e = Emit()
+    e.op("s_nop 4")
+    def tail_check(last):
+        e.op("s_sub_u32 %[cnt], %[cnt], 1")
+        e.op("s_cmp_eq_u32 %[cnt], 0")
+        if last: e.op("s_cbranch_scc0 L_dq_loop_%=")
+        else: e.op("s_cbranch_scc1 L_dq_exit_%=")
+    dq_tile(e, mode, 0, "p0", first=True)
+    tail_check(False)
+    for i in (1, 2, 3):
+        dq_tile(e, mode, i, f"p{i}")
+        tail_check(False)
+    q_entry = list(e.lds_q)
+    e.op("L_dq_loop_%=:")
+    for i in (0, 1, 2, 3):
+        dq_tile(e, mode, i, f"l{i}")
+        tail_check(i == 3)
+    assert e.lds_q == q_entry, (e.lds_q, q_entry)
+    e.op("L_dq_exit_%=:")
+    e.lds_q = list(q_entry)
+    # drain: dQ of the very last unit (DSB; its K^T fragments were read by the last phase)
+    for f in range(4):
+        tt, db = f >> 1, f & 1
+        e.need([f"T{f}"])
+        e.op(f"v_mfma_f32_32x32x16_bf16 %[dq{db}], {vr(D_TF + 4 * f, 4)}, {vr(D_DSB + 4 * tt, 4)}, %[dq{db}]")
+    e.drain()
+    e.op("s_nop 15")
+    e.op("s_nop 15")
+    return e.lines
+
+
+def write_inc(out, L, what, top=None):
     with open(out, "w") as f:
         f.write(f"// GENERATED by tools/gen_attn_loops.py ({what}) - do not edit; the schedule is documented there.\n")
-        f.write(f"// Fixed registers v{B0}-v{TOP - 1}: scores v{SA}-v{SB + 15}, P^T v{PA}-v{PB + 7}, row sums v{L0}/v{L1}, V^T fragments v{VF}-v{VF + 15}, K fragments v{KF}-v{KF + 15}, temporaries v{TMP}-v{TMP + 3}\n")
+        if top is None: f.write(f"// Fixed registers v{B0}-v{TOP - 1}: scores v{SA}-v{SB + 15}, P^T v{PA}-v{PB + 7}, row sums v{L0}/v{L1}, V^T fragments v{VF}-v{VF + 15}, K fragments v{KF}-v{KF + 15}, temporaries v{TMP}-v{TMP + 3}\n")
+        else: f.write(f"// Fixed registers v{DQ0}-v{top - 1} (see the register map in the generator)\n")
         for ln in L:
             f.write('"' + ln + '\\n\\t"\n')
     n_mfma = sum(1 for ln in L if ln.startswith("v_mfma"))
@@ -225,6 +426,10 @@ def main():
     outdir = a.outdir or os.path.join(here, "..", "transfusion_pytorch_amd", "csrc")
     for mode in (0, 1):
         write_inc(os.path.join(outdir, f"attn_fwd_loop_m{mode}.inc"), program_fwd(mode), f"forward, unmasked tiles, soft-cap plan mode {mode}")
+        write_inc(os.path.join(outdir, f"attn_dq_loop_m{mode}.inc"), program_dq(mode), f"backward dQ, whole tile loop, soft-cap plan mode {mode}", D_TOP)
+    with open(os.path.join(outdir, "attn_asm_clobbers.inc"), "w") as f:
+        f.write("// GENERATED by tools/gen_attn_loops.py - the fixed registers of the generated attention loops, as clobber lists\n")
+        f.write("#define TFX_DQ_CLOBBERS " + ", ".join(f'"v{r}"' for r in range(DQ0, D_TOP)) + "\n")
 
 
 if __name__ == "__main__":

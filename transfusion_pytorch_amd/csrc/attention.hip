@@ -10,6 +10,7 @@
 // MFMA contraction "slots" e=0..7 of lane-half hi map to rows 16*tt + 8*(e>>2) + 4*hi + (e&3) of a
 // 32-row block: both operands use the same map, so the sum is unchanged.
 #include "tfx_kernels.h"
+#include "attn_asm_clobbers.inc"
 
 namespace tfx {
 
@@ -39,8 +40,10 @@ TFX_DEV bf16x8 lds_rowfrag(const bf16* lds, int r0, int ks) {
   return *(const bf16x8*)(lds + (r0 + (l & 31)) * LDT + 16 * ks + 8 * (l >> 5));
 }
 // same fragment straight from global memory (row clamped)
-TFX_DEV bf16x8 g_rowfrag(const bf16* base, int ld, int row, int nrows, int ks) {
-  const int l = threadIdx.x & 63;
+// (lane: callers inside a per-block TILE LOOP hand in an opaque copy of the thread index, so that hipcc does not hoist the lane-derived addresses out of that loop -
+//  where they are spilled next to an asm statement's fixed registers; -1 = threadIdx.x.  The same parameter on tile_dma, dma_rowfrag, dma_tr8, the block stores.)
+TFX_DEV bf16x8 g_rowfrag(const bf16* base, int ld, int row, int nrows, int ks, int lane = -1) {
+  const int l = (lane >= 0 ? lane : (int)threadIdx.x) & 63;
   row = min(row, nrows - 1);
   return *(const bf16x8*)(base + (size_t)row * ld + 16 * ks + 8 * (l >> 5));
 }
@@ -50,8 +53,8 @@ TFX_DEV bf16x8 g_rowfrag(const bf16* base, int ld, int row, int nrows, int ks) {
 // ds_read_b64_tr_b16 group do too (rows r, r+2 share a half but differ in chunk bit 2).  The DMA writes lane-linear
 // 1 KiB pieces (8 rows), so the same XOR is applied to the SOURCE chunk each lane fetches.
 TFX_DEV int swz_f(int row) { const int v = (row >> 1) & 7; return ((v & 1) << 2) | (v >> 1); }
-TFX_DEV void tile_dma(const bf16* base, int ld, int row0, int nrows, bf16* lds_tile) {   // 256 threads: wave w brings rows [16w, 16w+16)
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+TFX_DEV void tile_dma(const bf16* base, int ld, int row0, int nrows, bf16* lds_tile, int t = -1) {   // 256 threads: wave w brings rows [16w, 16w+16)
+  const int tx = t >= 0 ? t : (int)threadIdx.x, l = tx & 63, w = tx >> 6;
 #pragma unroll
   for (int j = 0; j < 2; j++) {
     const int r = w * 16 + j * 8 + (l >> 3);
@@ -59,12 +62,12 @@ TFX_DEV void tile_dma(const bf16* base, int ld, int row0, int nrows, bf16* lds_t
     glds16_asm(base + (size_t)min(row0 + r, nrows - 1) * ld + c * 8, lds_tile + (w * 16 + j * 8) * 64);
   }
 }
-TFX_DEV bf16x8 dma_rowfrag(const bf16* lds, int r0, int ks) {
-  const int l = threadIdx.x & 63, r = r0 + (l & 31);
+TFX_DEV bf16x8 dma_rowfrag(const bf16* lds, int r0, int ks, int lane = -1) {
+  const int l = (lane >= 0 ? lane : (int)threadIdx.x) & 63, r = r0 + (l & 31);
   return *(const bf16x8*)(lds + r * 64 + (((2 * ks + (l >> 5)) ^ swz_f(r)) << 3));
 }
-TFX_DEV bf16x8 dma_tr8(const bf16* tile, int rowA, int rowB, int c0) {
-  const int l = threadIdx.x & 63, q = l & 15;
+TFX_DEV bf16x8 dma_tr8(const bf16* tile, int rowA, int rowB, int c0, int lane = -1) {
+  const int l = (lane >= 0 ? lane : (int)threadIdx.x) & 63, q = l & 15;
   const int col = c0 + 16 * ((l >> 4) & 1) + 4 * (q & 3);
   const int ra = rowA + (q >> 2), rb = rowB + (q >> 2);
   s16x4 lo = lds_tr4(tile + ra * 64 + (((col >> 3) ^ swz_f(ra)) << 3) + (col & 7));
@@ -192,8 +195,8 @@ TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
 // 32 rows behind every store instruction and visits each line 8 times (the address coalescer walks the lines one by one: the same effect that
 // cost the NT epilogues 7 k clocks per tile, gemm.hip staged_epilogue_bf16).  `st` must be free: the callers pass a tile buffer behind a barrier.
 // Falls back to the direct stores when a row is not 16-byte aligned.
-TFX_DEV void wave_block_store(bf16* st, const bf16x4 (&v)[2][4], bf16* g0, int ld, int rows_valid) {
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+TFX_DEV void wave_block_store(bf16* st, const bf16x4 (&v)[2][4], bf16* g0, int ld, int rows_valid, int lane = -1) {
+  const int l = (lane >= 0 ? lane : (int)threadIdx.x) & 63, hi = l >> 5, r = l & 31, ch = l & 7;
   if (((ld & 7) | (int)(((uintptr_t)g0 >> 1) & 7)) != 0) {                      // wave-uniform
     if (r < rows_valid) {
 #pragma unroll
@@ -229,8 +232,8 @@ TFX_DEV void wave_block_store(bf16* st, const bf16x4 (&v)[2][4], bf16* g0, int l
 // in the raw / output matrices (WHICH = 1: the k half).  Rows past the end are computed on the last valid row and not stored (the cross-lane sums need
 // every lane).  pg: this lane's gain-gradient partials of columns (l & 7) * 8 .. + 7.
 template <int WHICH>
-TFX_DEV void wave_block_store_nr(bf16* st, const bf16x4 (&v)[2][4], const tfx_attn_args& p, size_t tok, int colq, int rows_valid, float (&pg)[8]) {
-  const int l = threadIdx.x & 63, hi = l >> 5, r = l & 31, ch = l & 7;
+TFX_DEV void wave_block_store_nr(bf16* st, const bf16x4 (&v)[2][4], const tfx_attn_args& p, size_t tok, int colq, int rows_valid, float (&pg)[8], int lane = -1) {
+  const int l = (lane >= 0 ? lane : (int)threadIdx.x) & 63, hi = l >> 5, r = l & 31, ch = l & 7;
   if (rows_valid <= 0) return;                                    // (wave-uniform) the whole block lies past the sample's end: nothing to read or write
 #pragma unroll
   for (int db = 0; db < 2; db++)
@@ -293,22 +296,23 @@ TFX_DEV void wave_block_store_nr(bf16* st, const bf16x4 (&v)[2][4], const tfx_at
   }
 }
 // gain gradients of a block: the 8 lanes of a wave that own the same 8 columns are summed by three exchanges, the four waves through LDS, 64 atomics
-TFX_DEV void nr_flush_dgamma(float (&pg)[8], float* sg /* [4][64] */, float* dgamma, float* scratch_row /* this block's [64] row of tfx_attn_args.nr_scratch, or null */) {
+TFX_DEV void nr_flush_dgamma(float (&pg)[8], float* sg /* [4][64] */, float* dgamma, float* scratch_row /* this block's [64] row of tfx_attn_args.nr_scratch, or null */, int t = -1) {
+  const int tx = t >= 0 ? t : (int)threadIdx.x;
 #pragma unroll
   for (int e = 0; e < 8; e++) {
 #pragma unroll
     for (int m = 8; m < 64; m <<= 1) pg[e] += __shfl_xor(pg[e], m, 64);
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = tx & 63, wv = tx >> 6;
   if (lane < 8) {
 #pragma unroll
     for (int e = 0; e < 8; e++) sg[wv * 64 + lane * 8 + e] = pg[e];
   }
   __syncthreads();
-  if (threadIdx.x < 64) {
-    const float s4 = sg[threadIdx.x] + sg[64 + threadIdx.x] + sg[128 + threadIdx.x] + sg[192 + threadIdx.x];
-    if (scratch_row) scratch_row[threadIdx.x] = s4;                 // one 256-byte row per block; summed by attn_nr_reduce_kernel
-    else if (s4 != 0.f) atomicAdd(dgamma + threadIdx.x, s4);
+  if (tx < 64) {
+    const float s4 = sg[tx] + sg[64 + tx] + sg[128 + tx] + sg[192 + tx];
+    if (scratch_row) scratch_row[tx] = s4;                 // one 256-byte row per block; summed by attn_nr_reduce_kernel
+    else if (s4 != 0.f) atomicAdd(dgamma + tx, s4);
   }
 }
 TFX_DEV size_t linear_block() { return blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z); }
@@ -761,11 +765,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(tfx_attn_args p) {
 
 // ------------------------------------------------------------------------------------------------
 // backward dQ: block = 128 query rows, loop over 64-key tiles (forward structure + one more MFMA)
-// PREP (round 5): the block also does attn_bwd_prep_kernel's work for its own 128 rows x 1 head - every (row, head) belongs to exactly one dQ block - from
-// the row fragments it loads anyway: delta = sum_d dout og (own 32 columns + one exchange with lane ^ 32), do_eff = dout sigmoid(gate) (used from registers AND
-// written for the dK/dV kernel, which therefore runs BEHIND this one), dgate.  One launch, one read of do_eff and one of delta less per layer.
+// (the plain loop: kept as the A/B reference of the pipelined kernel below, TFX_ATTN_BWD_PIPE=0)
 // ------------------------------------------------------------------------------------------------
-template <bool PREP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
   __shared__ __attribute__((aligned(16))) bf16 Ks[64 * LDT];
   __shared__ __attribute__((aligned(16))) bf16 Vs[64 * LDT];
@@ -788,31 +789,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
   const int kve_min = wave_min_i(kve);
 
   bf16x8 qf[4], dof[4];
-  if constexpr (PREP) {
-    const float gsig = sigmoidf_(bf2f(p.gate[(tok0 + qc) * p.ld_gate + h]));
-    const bf16* dyb = p.dout + tok0 * p.ld_dout + h * DH;
-    const bf16* ogb = p.out + tok0 * p.ld_out + h * DH;
-    bf16x8 d8[4], o8[4];
+  dlt = p.delta[((size_t)b * p.h + h) * n + qc];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) { qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks); d8[ks] = g_rowfrag(dyb, p.ld_dout, qrow, n, ks); o8[ks] = g_rowfrag(ogb, p.ld_out, qrow, n, ks); }
-    float dl = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-      for (int e = 0; e < 8; e++) { const float d = bf2f(d8[ks][e]); dl += d * bf2f(o8[ks][e]); dof[ks][e] = f2bf(d * gsig); }
-      if (qrow < n) *(bf16x8*)(p.do_eff + (tok0 + qrow) * p.ld_do + h * DH + 16 * ks + 8 * hi) = dof[ks];
-    }
-    dl += __shfl_xor(dl, 32, 64);                                  // the row's other 32 columns live in lane ^ 32
-    dlt = dl;
-    if (hi == 0 && qrow < n) {
-      p.delta[((size_t)b * p.h + h) * n + qrow] = dl;
-      p.dgate[(tok0 + qrow) * p.ld_dgate + h] = f2bf(dl * (1.f - gsig));
-    }
-  } else {
-    dlt = p.delta[((size_t)b * p.h + h) * n + qc];
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) { qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks); dof[ks] = g_rowfrag(dob, p.ld_do, qrow, n, ks); }
-  }
+  for (int ks = 0; ks < 4; ks++) { qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks); dof[ks] = g_rowfrag(dob, p.ld_do, qrow, n, ks); }
   f32x16 dq[2];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -899,6 +878,260 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
       nr_flush_dgamma(pg, sg, p.nr_dgamma_q, p.nr_scratch ? p.nr_scratch + linear_block() * 64 : nullptr);
     } else
     wave_block_store((w < 2 ? Ks : Vs) + (w & 1) * 2048, ov, p.dq + (tok0 + q0 + w * 32) * p.ld_dq + h * DH, p.ld_dq, n - (q0 + w * 32));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dQ, software-pipelined form (round 6; the product kernel for soft-cap plan modes 0 / 1)
+// ------------------------------------------------------------------------------------------------
+// What bounded the plain loop above (profiles/r06_attn_fwd_asm_ablation.txt, item 5): per launch its vector work is ~100 us, its MFMAs 55 us, its LDS traffic
+// 55-65 us - and the kernel took their SUM (225 us).  S / dP -> soft-max arithmetic -> dQ is one dependency chain per 32-key block, the two waves of a SIMD
+// drift into the same part of it, and K / V tiles went global -> registers -> LDS behind two block barriers per tile.  Here, as in the forward's pipe kernel,
+// the chain is cut in 32-key UNITS and phase u runs three independent streams:
+//       vector: u^2, soft-cap derivative, exp2, dS = P (dP - delta) tanh', bf16 packing of unit u         (16 scores per lane, 8 chunks of 2)
+//       matrix: S and dP of unit u + 1 (8 MFMAs, two per chunk 0..3)  and  dQ += dS K of unit u - 1 (4 MFMAs, chunks 4..7)
+// K tiles live in a ring of four (a tile is read from the S of its first unit to the dQ of its last one, two phases later), V tiles in a ring of three, both by
+// LDS-DMA two tiles ahead, ONE barrier per tile.  Same arithmetic per element, same accumulation order per accumulator: bit-identical to the plain kernel.
+template <int MODE>
+TFX_DEV void dq_phase(const f32x16& s_cur, const f32x16& dp_cur, f32x16& s_nxt, f32x16& dp_nxt, u32x4 (&ds_prev)[2], u32x4 (&ds_cur)[2], f32x16 (&dq)[2],
+                      const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], const bf16* Kt_nxt, const bf16* Vt_nxt, int kb_nxt, const bf16* Kt_prev, int kb_prev,
+                      float lse2, float dlt, const SoftCap& c, int lane) {
+  const int hi = (lane >> 5) & 1;
+  // operand of MFMA m: 0..7 = row fragments of unit u + 1 (k-step m >> 1; even: K for S, odd: V for dP), 8..11 = K^T fragments of unit u - 1 (tt = (m - 8) >> 1, db = m & 1)
+  auto fetch = [&](int m) -> bf16x8 {
+    if (m < 8) return dma_rowfrag((m & 1) ? Vt_nxt : Kt_nxt, kb_nxt * 32, m >> 1, lane);
+    const int ra = kb_prev * 32 + 16 * ((m - 8) >> 1) + 4 * hi;
+    return dma_tr8(Kt_prev, ra, ra + 8, (m & 1) * 32, lane);
+  };
+  // MFMA order over the 8 chunks: 2, 1, 2, 1, 2, 1, 2, 1 (S0 dP0 | S1 | dP1 S2 | dP2 | S3 dP3 | dQ0 | dQ1 dQ2 | dQ3) - never more than three operand fragments alive
+  // (this chunk's and the next one's): MFMA m takes frag[m % 3], the next chunk's are requested before this chunk's vector work
+  constexpr int first[9] = {0, 2, 3, 5, 6, 8, 9, 11, 12};          // first MFMA of chunk ch
+  // MFMA index -> operand: 0 S0, 1 dP0, 2 S1, 3 dP1, 4 S2, 5 dP2, 6 S3, 7 dP3 (fetch(m): k-step m >> 1, odd = V), 8..11 dQ
+  bf16x8 frag[3];
+  frag[0] = fetch(0); frag[1] = fetch(1);
+#pragma unroll
+  for (int ch = 0; ch < 8; ch++) {
+    if (ch < 7) {
+#pragma unroll
+      for (int m = first[ch + 1]; m < first[ch + 2 > 8 ? 8 : ch + 2]; m++) frag[m % 3] = fetch(m);
+    }
+    float d0, d1;
+    {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int r = 2 * ch + e;
+        const float a = s_cur[r], u = a * a;
+        float dth, arg;
+        if constexpr (MODE == 0) { dth = fmaf(u, c.d3, c.d1); arg = fmaf(a, fmaf(u, c.p3, c.p1), -lse2); }
+        else if constexpr (MODE == 1) { dth = fmaf(u, fmaf(u, c.d5, c.d3), c.d1); arg = fmaf(a, fmaf(u, fmaf(u, c.p5, c.p3), c.p1), -lse2); }
+        else { dth = fmaf(u, -c.g2, 1.f); arg = a - lse2; }          // s_cur was soft-capped by the caller (softcap16): 1 - tanh^2 from the capped score
+        const float dpv = (dp_cur[r] - dlt) * dth;
+        const float pv = __builtin_amdgcn_exp2f(arg);
+        (e == 0 ? d0 : d1) = pv * dpv;                              // dS_raw^T
+      }
+    }
+    // the chunk's results are operands of the MFMA statements: computed BEFORE them, packed after (see fwd_phase)
+#pragma unroll
+    for (int m = first[ch]; m < first[ch + 1]; m++) {
+      if (m == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, 0" : "=&v"(s_nxt), "+v"(d0), "+v"(d1), "+v"(frag[m % 3]) : "v"(qf[0]));
+      else if (m == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, 0" : "=&v"(dp_nxt), "+v"(d0), "+v"(d1), "+v"(frag[m % 3]) : "v"(dof[0]));
+      else if (m < 8 && !(m & 1)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0" : "+v"(s_nxt), "+v"(d0), "+v"(d1), "+v"(frag[m % 3]) : "v"(qf[m >> 1]));
+      else if (m < 8) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0" : "+v"(dp_nxt), "+v"(d0), "+v"(d1), "+v"(frag[m % 3]) : "v"(dof[m >> 1]));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %3, %4, %0" : "+v"(dq[m & 1]), "+v"(d0), "+v"(d1), "+v"(frag[m % 3]), "+v"(ds_prev[(m - 8) >> 1]));
+    }
+    bf16x2 pk2; pk2[0] = f2bf(d0); pk2[1] = f2bf(d1);
+    uint32_t pk = __builtin_bit_cast(uint32_t, pk2);
+    asm volatile("" : "+v"(pk));
+    ds_cur[ch >> 2][ch & 3] = pk;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int MODE>
+TFX_DEV void dq_phase_any(f32x16& s_cur, f32x16& dp_cur, f32x16& s_nxt, f32x16& dp_nxt, u32x4 (&ds_prev)[2], u32x4 (&ds_cur)[2], f32x16 (&dq)[2],
+                          const bf16x8 (&qf)[4], const bf16x8 (&dof)[4], const bf16* Kt_nxt, const bf16* Vt_nxt, int kb_nxt, const bf16* Kt_prev, int kb_prev,
+                          float lse2, float dlt, const SoftCap& c, int key0, int kve, bool mask, int lane) {
+  if constexpr (MODE == 2) softcap16(s_cur, c);                     // no plan: the degree follows the wave's scores (not overlapped with the matrix work)
+  // boundary units (one or two per wave): a masked score gets dP = delta, i.e. dS = P (delta - delta) tanh' = 0 - the plain kernel's P = 0 up to the sign of the
+  // zero; ONE straight-line phase (a second, masked instantiation of it pushed the kernel from 230 registers to 256 + 131 spilled)
+  if (mask) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) dp_cur[r] = key0 + (r & 3) + 8 * (r >> 2) < kve ? dp_cur[r] : dlt;
+  }
+  dq_phase<MODE>(s_cur, dp_cur, s_nxt, dp_nxt, ds_prev, ds_cur, dq, qf, dof, Kt_nxt, Vt_nxt, kb_nxt, Kt_prev, kb_prev, lse2, dlt, c, lane);
+}
+
+template <int MODE>
+TFX_DEV void dq_pipe_loop(const tfx_attn_args& p, bf16 (&Ks)[4][64 * 64], bf16 (&Vs)[3][64 * 64], const bf16* kb_, const bf16* vb, int n, int nt, const bf16x8 (&qf)[4],
+                          const bf16x8 (&dof)[4], f32x16 (&dq)[2], float lse2_, float dlt_, const SoftCap& sc_, int kve, int kve_min, int tx) {
+  const int hi = (tx >> 5) & 1, lane = tx & 63;
+  f32x16 sA, sB, dpA, dpB;
+  u32x4 dsA[2], dsB[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) { dsA[i][e] = 0u; dsB[i][e] = 0u; }
+#pragma unroll
+  for (int r = 0; r < 16; r++) { sA[r] = 0.f; sB[r] = 0.f; dpA[r] = 0.f; dpB[r] = 0.f; }
+  int kslot = 0, vslot = 0;                                       // ring slots of K(j) / V(j)
+  for (int j = 0; j < nt; j++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of K(j + 1), V(j + 1) have landed
+    __builtin_amdgcn_s_barrier();                                 // ... everyone's have, and everyone is done with K(j - 2), V(j - 1)
+    const int kslot1 = (kslot + 1) & 3, kslot2 = (kslot + 2) & 3, kprev = (kslot + 3) & 3;
+    const int vslot1 = vslot == 2 ? 0 : vslot + 1, vslot2 = vslot1 == 2 ? 0 : vslot1 + 1;
+    if (j + 2 < nt) { tile_dma(kb_, p.ld_k, (j + 2) * 64, n, Ks[kslot2], tx); tile_dma(vb, p.ld_v, (j + 2) * 64, n, Vs[vslot2], tx); }
+    if (j == 0) {                                                 // pipeline fill: S and dP of unit 0
+      sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dma_rowfrag(Ks[0], 0, 0, lane), qf[0], f32x16{}, 0, 0, 0);
+      dpA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dma_rowfrag(Vs[0], 0, 0, lane), dof[0], f32x16{}, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ks++) { sA = MFMA(dma_rowfrag(Ks[0], 0, ks, lane), qf[ks], sA); dpA = MFMA(dma_rowfrag(Vs[0], 0, ks, lane), dof[ks], dpA); }
+    }
+    // even unit u = 2j: vector work on (sA, dpA) -> dsA ; S / dP of unit 2j + 1 -> (sB, dpB) (second halves of K(j), V(j)) ; dQ of unit 2j - 1 (dsB, second half of
+    // K(j - 1); dsB = 0 for j = 0, against K(0)'s own tile so that no uninitialised LDS meets the zero operand)
+    int u = 2 * j;
+    dq_phase_any<MODE>(sA, dpA, sB, dpB, dsB, dsA, dq, qf, dof, Ks[kslot], Vs[vslot], 1, j == 0 ? Ks[kslot] : Ks[kprev], 1, lse2_, dlt_, sc_, u * 32 + 4 * hi, kve, (u + 1) * 32 > kve_min, lane);
+    // odd unit u = 2j + 1: (sB, dpB) -> dsB ; S / dP of unit 2j + 2 -> (sA, dpA) (first halves of K(j + 1), V(j + 1); past the last tile: a stale tile, unused results) ; dQ of unit 2j
+    u = 2 * j + 1;
+    dq_phase_any<MODE>(sB, dpB, sA, dpA, dsA, dsB, dq, qf, dof, Ks[kslot1], Vs[vslot1], 0, Ks[kslot], 0, lse2_, dlt_, sc_, u * 32 + 4 * hi, kve, (u + 1) * 32 > kve_min, lane);
+    kslot = kslot1; vslot = vslot1;
+  }
+  {                                                               // drain: dQ of the very last unit (dsB, second half of K(nt - 1))
+    const bf16* Kt = Ks[(kslot + 3) & 3];
+    bf16x8 kt[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { const int ra = 32 + 16 * (m >> 1) + 4 * hi; kt[m] = dma_tr8(Kt, ra, ra + 8, (m & 1) * 32, lane); }
+#pragma unroll
+    for (int m = 0; m < 4; m++) MFMA_ACC(dq[m & 1], kt[m], dsB[m >> 1]);
+    asm volatile("s_nop 7" : "+v"(kt[0]), "+v"(kt[1]), "+v"(kt[2]), "+v"(kt[3]), "+v"(dsB[0]), "+v"(dsB[1]));
+  }
+}
+
+// The whole tile loop is ONE generated asm statement (tools/gen_attn_loops.py program_dq) for plan modes 0 / 1; mode 2 (no plan) takes the C++ pipeline above.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(tfx_attn_args p) {
+  __shared__ __attribute__((aligned(1024))) bf16 ring[8][64 * 64];    // rings of LDS-DMA tiles (see swz_f): K(j - 1) .. K(j + 2) in slots 0 .. 3, V in slots 4 .. 7
+  bf16 (&Ks)[4][64 * 64] = *reinterpret_cast<bf16 (*)[4][64 * 64]>(&ring[0][0]);
+  bf16 (&Vs)[3][64 * 64] = *reinterpret_cast<bf16 (*)[3][64 * 64]>(&ring[4][0]);
+  const int n = p.n, ntile = (n + 127) / 128;
+  // (A pair-persistent grid - one block per (head, sample) walking its 8 query tiles - measured no faster, 227 vs 221 us: two blocks per CU already hide one
+  //  block's start-up behind the other's loop.  profiles/r06_attn_bwd_what_bounds_it.txt)
+  const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
+  const int tx = threadIdx.x, l = tx & 63, w = tx >> 6, hi = l >> 5;
+  const int q0 = (ntile - 1 - z) * 128;
+  const size_t tok0 = (size_t)b * n;
+  const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
+  const bf16* kb_ = p.k + tok0 * p.ld_k + h * DH;
+  const bf16* vb = p.v + tok0 * p.ld_v + h * DH;
+  const bf16* dob = p.do_eff + tok0 * p.ld_do + h * DH;
+  // the first two K / V tiles are requested BEFORE anything is loaded: their addresses depend on the block index alone
+  tile_dma(kb_, p.ld_k, 0, n, Ks[0], tx);
+  tile_dma(vb, p.ld_v, 0, n, Vs[0], tx);
+  if (n > 64) { tile_dma(kb_, p.ld_k, 64, n, Ks[1], tx); tile_dma(vb, p.ld_v, 64, n, Vs[1], tx); }
+  const int qrow = q0 + w * 32 + (l & 31);
+  const int qc = min(qrow, n - 1);
+  const int kve = p.kv_end[tok0 + qc];
+  const int kv_limit = p.kv_end[tok0 + min(q0 + 127, n - 1)];
+  const int nt = (kv_limit + 63) / 64;
+  const float lse2 = p.lse[((size_t)b * p.h + h) * n + qc] * LOG2E;
+  const float dlt = p.delta[((size_t)b * p.h + h) * n + qc];
+  const int kve_min = wave_min_i(kve);
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) { qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks, l); dof[ks] = g_rowfrag(dob, p.ld_do, qrow, n, ks, l); }
+  const SoftCap sc_ = make_softcap(p.softcap, p.sc_plan);
+  // compiler-visible loads are consumed before the counted DMA waits (see attn_fwd_kernel)
+  float lse2_ = lse2, dlt_ = dlt;
+  asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(dof[0]), "+v"(dof[1]), "+v"(dof[2]), "+v"(dof[3]), "+v"(lse2_), "+v"(dlt_));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dq[i][r] = 0.f;
+  bool done = false;
+  {
+    if (sc_.mode <= 1) {                                           // (scalar branch: the layer's plan)
+      const int wu = __builtin_amdgcn_readfirstlane(w);
+      const uint32_t lds0 = (uint32_t)(size_t)(lds_void_t*)&ring[0][0];
+      uint32_t ka[4], ta[2], tb[2], dk[2], dv[2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) ka[ks] = lds0 + 2u * (uint32_t)((l & 31) * 64 + (((2 * ks + hi) ^ swz_f(l & 31)) << 3));      // dma_rowfrag, slot 0, key block 0
+      {
+        const int q = l & 15, ra = 4 * hi + (q >> 2), rb = ra + 8;                                                               // dma_tr8, slot 0, rowA = 4 hi
+#pragma unroll
+        for (int db = 0; db < 2; db++) {
+          const int col = db * 32 + 16 * ((l >> 4) & 1) + 4 * (q & 3);
+          ta[db] = lds0 + 2u * (uint32_t)(ra * 64 + (((col >> 3) ^ swz_f(ra)) << 3) + (col & 7));
+          tb[db] = lds0 + 2u * (uint32_t)(rb * 64 + (((col >> 3) ^ swz_f(rb)) << 3) + (col & 7));
+        }
+      }
+#pragma unroll
+      for (int jp = 0; jp < 2; jp++) {                                                                                           // tile_dma's pieces as buffer offsets
+        const int r = w * 16 + jp * 8 + (l >> 3), c = (l & 7) ^ swz_f(r);
+        dk[jp] = 2u * (uint32_t)(r * p.ld_k + c * 8);
+        dv[jp] = 2u * (uint32_t)(r * p.ld_v + c * 8);
+      }
+      // raw buffer resources over the sample's rows: a row past the end reads as zeros (its keys are masked)
+      const uint64_t baseK = (uint64_t)(uintptr_t)kb_, baseV = (uint64_t)(uintptr_t)vb;
+      u32x4 rsK, rsV;
+      rsK[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseK); rsK[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseK >> 32) & 0xffffu);
+      rsK[2] = __builtin_amdgcn_readfirstlane((uint32_t)(n - 1) * (uint32_t)p.ld_k * 2u + 128u); rsK[3] = 0x00020000u;
+      rsV[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseV); rsV[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseV >> 32) & 0xffffu);
+      rsV[2] = __builtin_amdgcn_readfirstlane((uint32_t)(n - 1) * (uint32_t)p.ld_v * 2u + 128u); rsV[3] = 0x00020000u;
+      const uint32_t stk = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ld_k), stv = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ld_v);
+      uint32_t sko = 2u * stk, svo = 2u * stv, cnt = (uint32_t)__builtin_amdgcn_readfirstlane(nt), su1 = 32u;
+      int rem2 = __builtin_amdgcn_readfirstlane(nt - 2);
+      const uint32_t mk = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wu * 2048u);
+      const int kmaskp = kve - 4 * hi + 32;
+      const float p1 = sc_.p1, p3 = sc_.p3, p5 = sc_.p5, d1 = sc_.d1, d3 = sc_.d3, d5 = sc_.d5;
+      u32x4 q0f = __builtin_bit_cast(u32x4, qf[0]), q1f = __builtin_bit_cast(u32x4, qf[1]), q2f = __builtin_bit_cast(u32x4, qf[2]), q3f = __builtin_bit_cast(u32x4, qf[3]);
+      u32x4 d0f = __builtin_bit_cast(u32x4, dof[0]), d1f = __builtin_bit_cast(u32x4, dof[1]), d2f = __builtin_bit_cast(u32x4, dof[2]), d3f = __builtin_bit_cast(u32x4, dof[3]);
+      // in-outs are EARLY-CLOBBER (see the forward's statement): sko / svo start out equal to multiples of the inputs stk / stv
+#define DQ_OPERANDS                                                                                                                                  \
+          : [dq0] "+&v"(dq[0]), [dq1] "+&v"(dq[1]), [sko] "+&s"(sko), [svo] "+&s"(svo), [cnt] "+&s"(cnt), [rem2] "+&s"(rem2), [su1] "+&s"(su1)            \
+          : [qf0] "v"(q0f), [qf1] "v"(q1f), [qf2] "v"(q2f), [qf3] "v"(q3f), [df0] "v"(d0f), [df1] "v"(d1f), [df2] "v"(d2f), [df3] "v"(d3f),          \
+            [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]), [ta0] "v"(ta[0]), [ta1] "v"(ta[1]), [tb0] "v"(tb[0]), [tb1] "v"(tb[1]), \
+            [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]), [rsk] "s"(rsK), [rsv] "s"(rsV), [stk] "s"(stk), [stv] "s"(stv),  \
+            [mk] "s"(mk), [kvemin] "s"(kve_min), [p1] "v"(p1), [d1] "v"(d1), [p3] DQ_C3(p3), [d3] DQ_C3(d3), [p5] "s"(p5), [d5] "s"(d5),            \
+            [lse2] "v"(lse2_), [dlt] "v"(dlt_), [kmaskp] "v"(kmaskp)                                                                                 \
+          : "memory", "scc", "vcc", TFX_DQ_CLOBBERS
+      if (sc_.mode == 0) {
+#define DQ_C3 "s"
+        asm volatile(
+#include "attn_dq_loop_m0.inc"
+            DQ_OPERANDS);
+#undef DQ_C3
+      } else {
+#define DQ_C3 "v"
+        asm volatile(
+#include "attn_dq_loop_m1.inc"
+            DQ_OPERANDS);
+#undef DQ_C3
+      }
+#undef DQ_OPERANDS
+      done = true;
+    }
+  }
+  if (!done) dq_pipe_loop<2>(p, Ks, Vs, kb_, vb, n, nt, qf, dof, dq, lse2_, dlt_, sc_, kve, kve_min, tx);
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(dq[0]), "+v"(dq[1]));                // the asm MFMAs' results are read by vector code from here on
+  {
+    bf16x4 ov[2][4];
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) ov[db][rg][e] = f2bf(dq[db][rg * 4 + e]);
+    __syncthreads();                                            // the K / V tiles are free: staging area of the coalesced stores
+    bf16* st = &ring[0][0] + w * 2048;
+    if (p.nr_qkv) {                                             // (kernel argument: block-uniform) QK-norm + RoPE backward on the way out
+      __shared__ float sg[4 * 64];
+      float pg[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) pg[e] = 0.f;
+      wave_block_store_nr<0>(st, ov, p, tok0 + q0 + w * 32, h * DH, n - (q0 + w * 32), pg, l);
+      nr_flush_dgamma(pg, sg, p.nr_dgamma_q, p.nr_scratch ? p.nr_scratch + ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * z)) * 64 : nullptr, tx);
+    } else
+    wave_block_store(st, ov, p.dq + (tok0 + q0 + w * 32) * p.ld_dq + h * DH, p.ld_dq, n - (q0 + w * 32), l);
   }
 }
 
@@ -1102,20 +1335,13 @@ int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
     if (((p.nr_ld_qkv | p.nr_ld_dqkv) & 7) || (((uintptr_t)p.nr_qkv | (uintptr_t)p.nr_dqkv) & 15)) return -5;
   }
   tfx_attn_args q = p; q.order = attn_order();
-  // TFX_ATTN_PREP=1: the dQ kernel prepares its own rows (one launch, one read of do_eff / delta less per layer).  Built and measured in round 5: NEUTRAL
-  // (27.18-27.28 against 27.18-27.32 ms per step over four same-box rounds, attention backward 4.13 vs 4.14 ms) - the 36 us launch it removes comes back as
-  // prologue latency of the dQ blocks.  Off by default: the separate launch is the form every round's tests have run on.
-  static int prep_fused = -1;
-  if (prep_fused < 0) { const char* e = getenv("TFX_ATTN_PREP"); prep_fused = (e && e[0] == '1') ? 1 : 0; }
-  if (prep_fused && (p.ld_do & 7) == 0 && (((uintptr_t)p.do_eff) & 15) == 0) {
-    // the dQ kernel prepares its own rows (delta, do_eff, dgate) and runs FIRST: the dK/dV kernel reads what it wrote
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, attn_grid(q), dim3(256), 0, s, q);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, attn_grid(q), dim3(256), 0, s, q);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, q);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, attn_grid(q), dim3(256), 0, s, q);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, attn_grid(q), dim3(256), 0, s, q);
-  }
+  // TFX_ATTN_BWD_PIPE=0: the plain-loop dQ kernel (A/B; bit-identical results)
+  static int pipe = -1;
+  if (pipe < 0) { const char* e = getenv("TFX_ATTN_BWD_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; }
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, q);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, attn_grid(q), dim3(256), 0, s, q);
+  if (pipe) hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel, attn_grid(q), dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel, attn_grid(q), dim3(256), 0, s, q);
   if (p.nr_qkv && p.nr_scratch) {
     const dim3 g = attn_grid(q);
     const int nblocks = (int)(g.x * g.y * g.z);
