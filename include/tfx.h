@@ -101,11 +101,7 @@ typedef struct {
                                  folded into the GEMM (one extra MFMA against a ones operand in the blocks of the first K tile) */
   int32_t k_group;            /* 0 = off; else the K columns come in groups of 64 of which the first k_group are written, compacted:
                                  C column = (k / 64) * k_group + k % 64  (per-head padded operand -> unpadded weight gradient) */
-  /* optional second B source for the product columns k >= K1 (round 5): C[N, K] = A^T [B | B2] - the weight gradient of the U-Net skip projection over
-   * cat(x, skip) (reference T:1214-1219) as ONE product with 8 tiles of 256 x 256 instead of two with 4 each.  B then holds K1 columns, B2 the other K - K1
-   * (ldb2 >= K - K1, % 8 == 0); K1 % 256 == 0, k_group == 0.  B2 == NULL: off. */
-  const tfx_bf16* B2; int32_t ldb2; int32_t K1;
-  /* grouped launch (round 5): HOST pointer to the tfx_gemm_tn_args of another product over the same M rows (its own group_next continues the chain; at most 4
+  /* grouped launch (round 5): HOST pointer to the tfx_gemm_tn_args of another product over the same M rows (its own group_next continues the chain; at most 6
    * products; `splits` of the chain's head applies).  The weight-gradient products of a transformer layer - the FeedForward pair, to_out, to_qk/v/gates, the skip
    * projection's halves - then run as ONE launch whose output tiles fill the chip at 4 row chunks instead of 11-20 per product: half the fp32 atomics of the
    * split-M sums (which the chip retires at ~1.25 TB/s: 27-42 % of the ungrouped kernels) and 256 x 256 tiles for the 512 x 512 products.  Products the one-wave
@@ -163,10 +159,6 @@ typedef struct {
   const int32_t* nr_rot_pos; const float* nr_cos; const float* nr_sin;
   float nr_q_scale, nr_norm_scale;
   float* nr_dgamma_q; float* nr_dgamma_k;
-  /* optional scratch, fp32 [2][h * b * ceil(n / 128)][64]: with it every block of the dQ / dK/dV kernel WRITES its gain-gradient partials to its own row and a
-   * small reduction launch behind the two kernels adds them into nr_dgamma_q / nr_dgamma_k - instead of 64 atomics per block onto the same 64 addresses
-   * (4096 blocks: ~60 us of serialised same-address atomics per kernel, measured as +26 us per kernel in the step).  NULL = the atomics. */
-  float* nr_scratch;
 } tfx_attn_args;
 int tfx_attn_fwd(const tfx_attn_args* a, void* stream);
 int tfx_attn_bwd(const tfx_attn_args* a, void* stream);   /* prep + dK/dV kernel + dQ kernel */

@@ -66,11 +66,11 @@ def test_gemm_nt_bf16_bias(M, N, K):
 def test_gemm_nt_one_wave_kernels_bit_identical_to_ping_pong():
     """round 5: the one-wave-per-SIMD NT kernels (gemm_nt_ow_kernel: one tile per block; gemm_nt_owp_kernel: persistent, K-tile stream across tile boundaries;
     hand-scheduled inline-asm K loops from tools/gen_nt_ow_loop.py) keep the ping-pong kernel's LDS layout, per-accumulator k order and epilogues: the same bits.
-    The library reads TFX_NT_OW once per process, so the cases run in two child processes (0 = ping-pong, 2 = every epilogue on the new kernels; TFX_NT_PP_MIN=1
-    sends the few-tile shapes to the 256 x 256 family) and the hashes of every output must agree."""
+    The library reads TFX_NT_OW once per process, so the cases run in two child processes (0 = ping-pong, 1 = the default: bf16 outputs and long-K fp32 outputs on
+    the new kernels; TFX_NT_PP_MIN=1 sends the few-tile shapes to the 256 x 256 family) and the hashes of every output must agree."""
     import subprocess, sys
     outs = []
-    for mode in ('0', '2'):
+    for mode in ('0', '1'):
         env = dict(os.environ, TFX_NT_OW=mode, TFX_NT_PP_MIN='1')
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), '_nt_hash_child.py')], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -332,43 +332,19 @@ def test_gemm_tn_folded_bias_gradient_and_head_compaction(M, N, K, splits, kg):
     check(f'gemm_tn colsum/k_group bias grad {M}x{N}x{K}', bias, bref, 5e-3)
 
 
-@pytest.mark.parametrize('M,N,K,K1,splits,want_kind', [(8192, 512, 1024, 512, 0, 3), (4096, 768, 1536, 768, 4, 3), (4096, 512, 1024, 512, 64, None),
-                                                        (1000, 200, 272, 136, 2, None), (2048, 384, 768, 384, 0, None)])
-def test_gemm_tn_split_b(M, N, K, K1, splits, want_kind):
-    """round 5: `B2` / `K1` - C[N, K] = A^T [B | B2], the weight gradient of the U-Net skip projection over cat(x, skip) (reference T:1214-1219) as ONE product.
-    K1 % 256 == 0 on the one-wave kernel (plan kind 3: a block picks its B source by its tile); every other case (chunks under 192 rows, K1 off the tile grid,
-    M % 64 != 0) runs as the two products inside the library - same result either way, against fp32 torch on the concatenated operand."""
-    torch.manual_seed(8)
-    A = rnd(M, N, scale=0.5); B = rnd(M, K1, scale=0.5); ld2 = K - K1 + 8; B2 = rnd(M, ld2, scale=0.5)
-    C = torch.zeros(N, K, device=DEV); bias = torch.zeros(N, device=DEV)
-    a = capi.make_args('tfx_gemm_tn_args', A=A, lda=N, a_cols=N, B=B, ldb=K1, b_cols=K1, B2=B2, ldb2=ld2, K1=K1, M=M, N=N, K=K, C=C, ldc=K, k_valid=K,
-                       splits=splits, accumulate=1, alpha=1.0, colsum=bias)
-    if want_kind is not None:
-        out = [ctypes.c_int32(-9) for _ in range(4)]
-        assert capi.lib().tfx_gemm_tn_plan(ctypes.byref(a), *[ctypes.byref(o) for o in out]) == 0 and out[0].value == want_kind, [o.value for o in out]
-    capi.call('tfx_gemm_tn', a, stream())
-    ref = A.float().T @ torch.cat([B, B2[:, :K - K1]], 1).float()
-    check(f'gemm_tn split-B {M}x{N}x{K} (K1 {K1})', C, ref, 5e-3)
-    check(f'gemm_tn split-B bias grad {M}x{N}x{K}', bias, A.float().sum(0), 5e-3)
-
-
 @pytest.mark.parametrize('M,shapes,groupable', [(8192, [(512, 1408), (2816, 512)], True), (4096, [(512, 512), (1544, 512), (512, 512), (512, 512)], True),
                                                  (1000, [(200, 136), (136, 200)], False), (16384, [(512, 512), (512, 1024)], True), (8192, [(512, 512), (512, 1024)], False)])
 def test_gemm_tn_grouped_launch(M, shapes, groupable):
     """round 5: `group_next` - weight-gradient products over the same M rows as ONE launch (a transformer layer's FeedForward pair; to_out + to_qk/v/gates + the skip
     projection).  The group's tiles share one grid of the one-wave kernel (plan kind 3, tiles = the sum); chains the kernel does not take run product by product inside
-    the library.  Each member against fp32 torch, with a row map + folded bias gradient on the second member and a split B on a member of the last case."""
+    the library.  Each member against fp32 torch, with a row map + folded bias gradient on the second member."""
     torch.manual_seed(9)
     structs, keep, refs = [], [], []
     for idx, (N, K) in enumerate(shapes):
         lda = (N + 7) // 8 * 8; ldb = (K + 7) // 8 * 8
         A = rnd(M, lda, scale=0.5); C = torch.zeros(N, K, device=DEV)
         kw = dict(A=A, lda=lda, a_cols=lda, M=M, N=N, K=K, C=C, ldc=K, k_valid=K, splits=0, accumulate=1, alpha=1.0)
-        if K == 1024 and idx == 1:                                   # split B: [B | B2]
-            B, B2 = rnd(M, 512, scale=0.5), rnd(M, 520, scale=0.5)
-            kw.update(B=B, ldb=512, b_cols=512, B2=B2, ldb2=520, K1=512); Bfull = torch.cat([B, B2[:, :512]], 1); keep += [B, B2]
-        else:
-            B = rnd(M, ldb, scale=0.5); kw.update(B=B, ldb=ldb, b_cols=ldb); Bfull = B[:, :K]; keep.append(B)
+        B = rnd(M, ldb, scale=0.5); kw.update(B=B, ldb=ldb, b_cols=ldb); Bfull = B[:, :K]; keep.append(B)
         prod = A[:, :N].float().T @ Bfull.float()
         if idx == 1:
             rowmap = torch.randperm(N, device=DEV).to(torch.int32); bias = torch.zeros(N, device=DEV)
@@ -497,7 +473,7 @@ def test_attention_bwd_with_fused_qk_norm_rope_bwd(b, h, n):
     out = torch.zeros(T, HD, device=DEV, dtype=BF); lse = torch.zeros(b, h, n, device=DEV)
     dout = rnd(T, HD)
     res = []
-    for fused in (False, True, 'scratch'):                        # 'scratch': per-block partial rows + the reduction launch instead of same-address atomics
+    for fused in (False, True):
         do_eff = torch.zeros(T, HD, device=DEV, dtype=BF); delta = torch.zeros(b, h, n, device=DEV)
         dqk = torch.full((T, 2 * HD), float('nan'), device=DEV, dtype=BF)
         dqkv = torch.full((T, ld), float('nan'), device=DEV, dtype=BF)
@@ -508,9 +484,6 @@ def test_attention_bwd_with_fused_qk_norm_rope_bwd(b, h, n):
         if fused:
             kw.update(nr_qkv=qkv, nr_ld_qkv=ld, nr_dqkv=dqkv, nr_ld_dqkv=ld, nr_gamma_q=gq, nr_gamma_k=gk, nr_rot_pos=pos, nr_cos=cos_t, nr_sin=sin_t,
                       nr_q_scale=0.125, nr_norm_scale=8.0, nr_dgamma_q=dgq, nr_dgamma_k=dgk)
-            if fused == 'scratch':
-                scratch = torch.full((2 * h * b * ((n + 127) // 128) * 64,), float('nan'), device=DEV)      # every row must be written before it is summed
-                kw.update(nr_scratch=scratch)
         a = capi.make_args('tfx_attn_args', **kw)
         if not fused:
             capi.call('tfx_attn_fwd', a, stream())
@@ -524,25 +497,32 @@ def test_attention_bwd_with_fused_qk_norm_rope_bwd(b, h, n):
         torch.cuda.synchronize()
         res.append((dqkv.clone(), dgq.clone(), dgk.clone()))
     (d0, gq0, gk0) = res[0]
-    for tag, (d1, gq1, gk1) in zip(('atomics', 'scratch rows'), res[1:]):
+    for tag, (d1, gq1, gk1) in zip(('atomics',), res[1:]):
         assert torch.isfinite(d1[:, :3 * HD + h].float()).all(), 'every d q | d k | d v | d gate element must have been written'
         check(f'fused ({tag}): d q (raw)', d1[:, :HD], d0[:, :HD].float(), 2e-4)               # measured 0 ... 1e-5: a handful of one-ulp bf16 flips
         check(f'fused ({tag}): d k (raw)', d1[:, HD:2 * HD], d0[:, HD:2 * HD].float(), 2e-4)       # measured 0 ... 2.4e-5
         assert torch.equal(d1[:, 2 * HD:3 * HD + h], d0[:, 2 * HD:3 * HD + h]), 'd v / d gate must not change'
         check(f'fused ({tag}): d gamma_q', gq1, gq0, 2e-5)                                       # measured 1e-7 ... 3e-7 (summation order)
         check(f'fused ({tag}): d gamma_k', gk1, gk0, 2e-5)
-    assert torch.equal(res[1][0][:, :3 * HD + h], res[2][0][:, :3 * HD + h])        # (columns past the gates stay poisoned in every run)
-
-
-def test_attention_bwd_with_the_preparation_fused_into_the_dq_kernel():
-    """round 5, TFX_ATTN_PREP=1 (off by default: measured neutral): delta, do_eff and dgate computed by the dQ kernel for its own rows, dK/dV behind it.  The
-    library reads the switch once per process, so the attention backward tests run again in a child process with it set."""
-    import subprocess, sys
-    env = dict(os.environ, TFX_ATTN_PREP='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
-                        'test_attention_fwd_bwd or test_attention_bwd_with_fused_qk_norm_rope_bwd'], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-1500:]
+    # ---- and DIRECTLY against fp32 torch autograd through norm -> RoPE -> attention (the fused outputs had only been compared with the unfused HIP form)
+    x = qkv[:, :2 * HD].float().reshape(T, 2, h, 64).requires_grad_(True)
+    gqr, gkr = gq.clone().requires_grad_(True), gk.clone().requires_grad_(True)
+    y = F.normalize(x, dim=-1) * 8 * (torch.stack([gqr, gkr])[None, :, None, :] + 1)
+    angp = ang[pos.long()].repeat_interleave(2, dim=-1)[:, None, None, :]
+    y2 = y.reshape(T, 2, h, 32, 2)
+    rot = torch.stack((-y2[..., 1], y2[..., 0]), -1).reshape(T, 2, h, 64)
+    qkr = (y * angp.cos() + rot * angp.sin()) * torch.tensor([0.125, 1.0], device=DEV)[None, :, None, None]
+    hd4 = lambda t: t.reshape(b, n, h, 64).transpose(1, 2)
+    vr = qkv[:, 2 * HD:3 * HD].float().requires_grad_(True)
+    gr = qkv[:, 3 * HD:3 * HD + h].float().requires_grad_(True)
+    ref = attn_ref(hd4(qkr[:, 0]), hd4(qkr[:, 1]), hd4(vr.reshape(T, h, 64)), gr.reshape(b, n, h).transpose(1, 2), kv_end.long(), 50.0)
+    ref.backward(hd4(dout.float().reshape(T, h, 64)))
+    d1, gq1, gk1 = res[1]
+    check('fused vs fp32 autograd: d q (raw)', d1[:, :HD].reshape(T, h, 64), x.grad[:, 0], 2.5e-2)
+    check('fused vs fp32 autograd: d k (raw)', d1[:, HD:2 * HD].reshape(T, h, 64), x.grad[:, 1], 2.5e-2)
+    check('fused vs fp32 autograd: d v', d1[:, 2 * HD:3 * HD], vr.grad, 2e-2)
+    check('fused vs fp32 autograd: d gamma_q', gq1, gqr.grad, 2e-2)
+    check('fused vs fp32 autograd: d gamma_k', gk1, gkr.grad, 2e-2)
 
 
 @pytest.mark.parametrize('gscale,want_mode', [(0.04, 0), (0.22, 1), (1.0, 2)])
@@ -805,7 +785,7 @@ def test_gemm_nt_fused_qk_norm_rope_epilogue_is_bit_identical(T, H):
     assert torch.equal(qk1, qk0), f'q~ | k~ differ in {(qk1 != qk0).sum().item()} elements'
     assert torch.equal(plan1, plan0)
     kind, grid = ctypes.c_int32(-1), ctypes.c_int32(-1)
-    pa = capi.make_args('tfx_gemm_nt_args', A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_BF16'], C=C0, ldc=ldq)
+    pa = capi.make_args('tfx_gemm_nt_args', A=u, lda=d, B=W, ldb=d, M=T, N=N, K=d, epi=capi.ENUMS['TFX_EPI_QKV_NORM_ROPE'], C=C0, ldc=ldq)
     capi.lib().tfx_gemm_nt_plan(ctypes.byref(pa), ctypes.byref(kind), ctypes.byref(grid))
     assert (kind.value == 3) == (T > 60000)                        # the large shapes really took the ping-pong kernel (fused), the small one the two launches
 

@@ -240,14 +240,16 @@ def dq_reads(e, kind, idx, slot, kb):
         e.lds_read(f"T{idx}", f"ds_read_b64_tr_b16 {vr(D_TF + 4 * idx + 2, 2)}, %[tb{db}] offset:{off}")
 
 
-def dq_mask(e, s_dp):
-    """boundary unit: a masked score gets dP = delta (dS = 0).  element r of this lane is key u * 32 + 4 hi + (r & 3) + 8 (r >> 2); visible iff that < kv_end."""
+def dq_mask(e, s_s, s_dp):
+    """boundary unit: a masked score gets dP = delta (dS = P x 0 = 0) and the score 0 (P = exp2(-lse2): finite - a large masked score against a small lse would give
+    inf x 0).  element r of this lane is key u * 32 + 4 hi + (r & 3) + 8 (r >> 2); visible iff that < kv_end."""
     e.op(f"v_subrev_u32 {vr(D_MT)}, %[su1], %[kmaskp]")           # kv_end - 4 hi + 32 - (u + 1) * 32 = keys of this unit the lane-half sees, counted from its first
     for r in range(16):
         cr = (r & 3) + 8 * (r >> 2)
         e.op(f"v_cmp_lt_i32 vcc, {cr}, {vr(D_MT)}")
         e.op("s_nop 1")
         e.op(f"v_cndmask_b32 {vr(s_dp + r)}, %[dlt], {vr(s_dp + r)}, vcc")
+        e.op(f"v_cndmask_b32 {vr(s_s + r)}, 0, {vr(s_s + r)}, vcc")
 
 
 def dq_phase(e, mode, h, nxt, prv, tag, first=False):
@@ -258,7 +260,7 @@ def dq_phase(e, mode, h, nxt, prv, tag, first=False):
     # ---- boundary units: wave-uniform test (u + 1) * 32 > min kv_end of the wave
     e.op("s_cmp_gt_i32 %[su1], %[kvemin]")
     e.op(f"s_cbranch_scc0 L_dq_nomask_{tag}_%=")
-    dq_mask(e, dp_cur)
+    dq_mask(e, s_cur, dp_cur)
     e.op(f"L_dq_nomask_{tag}_%=:")
     e.op("s_add_u32 %[su1], %[su1], 32")
     sched = [["S0", "P0"], ["S1"], ["P1", "S2"], ["P2"], ["S3", "P3"], ["Q0"], ["Q1", "Q2"], ["Q3"]]

@@ -188,8 +188,9 @@ TFX_DEV bf16x8 pack8(const f32x16& v, int tt) {
 // queries q_start .. n), 1 : 8 across a 1024-token sample.  The grid is (heads, samples, tiles) with the tile rank in the SLOWEST
 // dimension, decoded heaviest-first: the long blocks start first and the kernel ends on the short ones (no tail of lone 8-unit
 // blocks), and since workgroups go to the XCDs round-robin in linear order, every tile of one (head, sample) lands on the SAME XCD
-// whenever heads * samples is a multiple of 8 (its K / V stay in that XCD's L2).  `order` == 0 is the tile-fastest grid
-// (tiles, heads, samples) of the first version (env TFX_ATTN_ORDER=0, A/B).
+// whenever heads * samples is a multiple of 8.  (Measured round 6, profiles/r06_attn_pmc_l2_by_block_order.txt: the L2 hit rate of this order is 5 % - 512 other
+// pairs run between two tiles of a pair; an XCD-local order reaches 68 % and is SLOWER in the step: the operands come from the Infinity Cache either way and the
+// heaviest-first balance matters more.  The tile-fastest grid of round 1 was removed.)
 // A wave's 32 x 64 bf16 output block (this lane: row l & 31, columns db * 32 + 8 rg + 4 hi .. + 3) leaves through a wave-private 4 KiB LDS image:
 // 16-byte stores, 8 lanes per 128-byte row = 8 cache lines per instruction.  The direct form - 8 bytes per lane in accumulator shape - puts
 // 32 rows behind every store instruction and visits each line 8 times (the address coalescer walks the lines one by one: the same effect that
@@ -296,7 +297,7 @@ TFX_DEV void wave_block_store_nr(bf16* st, const bf16x4 (&v)[2][4], const tfx_at
   }
 }
 // gain gradients of a block: the 8 lanes of a wave that own the same 8 columns are summed by three exchanges, the four waves through LDS, 64 atomics
-TFX_DEV void nr_flush_dgamma(float (&pg)[8], float* sg /* [4][64] */, float* dgamma, float* scratch_row /* this block's [64] row of tfx_attn_args.nr_scratch, or null */, int t = -1) {
+TFX_DEV void nr_flush_dgamma(float (&pg)[8], float* sg /* [4][64] */, float* dgamma, int t = -1) {
   const int tx = t >= 0 ? t : (int)threadIdx.x;
 #pragma unroll
   for (int e = 0; e < 8; e++) {
@@ -311,171 +312,20 @@ TFX_DEV void nr_flush_dgamma(float (&pg)[8], float* sg /* [4][64] */, float* dga
   __syncthreads();
   if (tx < 64) {
     const float s4 = sg[tx] + sg[64 + tx] + sg[128 + tx] + sg[192 + tx];
-    if (scratch_row) scratch_row[tx] = s4;                 // one 256-byte row per block; summed by attn_nr_reduce_kernel
-    else if (s4 != 0.f) atomicAdd(dgamma + tx, s4);
+    if (s4 != 0.f) atomicAdd(dgamma + tx, s4);
   }
 }
-TFX_DEV size_t linear_block() { return blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z); }
-// sums the per-block gain-gradient rows of the dQ (which = 0) and dK/dV (1) kernels: block (chunk, which) takes 256 rows - wave w 64 of them, lane = column
-// (coalesced 256-byte reads) -, the four waves meet in LDS, 64 atomics per block (2 x 16 blocks at the bench size instead of 2 x 4096)
-__global__ __launch_bounds__(256) void attn_nr_reduce_kernel(const float* scratch, int nblocks, float* dgq, float* dgk) {
-  __shared__ float sg[4 * 64];
-  const int which = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float* src = scratch + (size_t)which * nblocks * 64;
-  const int r0 = blockIdx.x * 256 + w * 64, r1 = min(r0 + 64, nblocks);
-  float s = 0.f;
-  for (int r = r0; r < r1; r++) s += src[(size_t)r * 64 + lane];
-  sg[w * 64 + lane] = s;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const float s4 = sg[threadIdx.x] + sg[64 + threadIdx.x] + sg[128 + threadIdx.x] + sg[192 + threadIdx.x];
-    if (s4 != 0.f) atomicAdd((which == 0 ? dgq : dgk) + threadIdx.x, s4);
-  }
-}
-
 struct BlockId { int tile, h, b; };
 TFX_DEV BlockId decode_block(int order, int ntile, bool heavy_last_tile) {     // (scalars only: no reference to the kernel-argument struct)
   BlockId o;
-  if (order == 0) { o.tile = blockIdx.x; o.h = blockIdx.y; o.b = blockIdx.z; return o; }
+  (void)order;
   o.tile = heavy_last_tile ? ntile - 1 - (int)blockIdx.z : (int)blockIdx.z;
   o.h = blockIdx.x; o.b = blockIdx.y;
   return o;
 }
 
-#ifndef TFX_ATTN_FWD_WAVES
-#define TFX_ATTN_FWD_WAVES 2          // waves per SIMD the plain-loop forward (TFX_ATTN_PIPE=0, not the product kernel) is compiled for: three spill since the soft-cap plan
-#endif
-__global__ __launch_bounds__(256, TFX_ATTN_FWD_WAVES) void attn_fwd_kernel(tfx_attn_args p) {
-  __shared__ __attribute__((aligned(1024))) bf16 Ks[2][64 * 64];      // double-buffered LDS-DMA tiles (see swz_f)
-  __shared__ __attribute__((aligned(1024))) bf16 Vs[2][64 * 64];
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, hi = l >> 5;
-  const BlockId bi = decode_block(p.order, (p.n + 127) / 128, true);
-  const int h = bi.h, b = bi.b, q0 = bi.tile * 128;
-  const int n = p.q_cnt ? p.q_cnt[b] : p.n;                      // compacted decode steps: this sample's own row count / first row (tfx.h q_row0, q_cnt)
-  if (q0 >= n) return;                                           // (block-uniform: before any barrier)
-  const int nkv = p.n_kv > 0 ? p.n_kv : n;                       // KV-cache decode: keys live in a longer per-sample buffer
-  const size_t tok0 = p.q_row0 ? (size_t)p.q_row0[b] : (size_t)b * n, tokk = (size_t)b * nkv;
-  const bf16* qb = p.q + tok0 * p.ld_q + h * DH;
-  const bf16* kb_ = p.k + tokk * p.ld_k + h * DH;
-  const bf16* vb = p.v + tokk * p.ld_v + h * DH;
-  const int qrow = q0 + w * 32 + (l & 31);
-  const int qc = min(qrow, n - 1);
-  const int kve = p.kv_end[tok0 + qc];
-  const int kv_limit = tile_kv_limit(p, tok0, q0, n, kve, qrow < n);
-  const int nt = (kv_limit + 63) / 64;
-
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks);
-
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) o[i][r] = 0.f;
-  f32x2 lsum2 = {0.f, 0.f};                     // sum of exp2(s2) (fixed reference 0, see SoftCap)
-  f32x16 zero16;
-#pragma unroll
-  for (int r = 0; r < 16; r++) zero16[r] = 0.f;
-  asm volatile("" : "+v"(zero16));              // keep ONE zero accumulator live instead of 32 v_mov per tile
-  const SoftCap sc_ = make_softcap(p.softcap, p.sc_plan);
-  const int kve_min = wave_min_i(kve);
-
-  // The Q fragments / kv_end loads above are compiler-visible VMEM.  They must be CONSUMED (not just waited for in asm) before the
-  // loop: otherwise hipcc's scoreboard still carries them into the loop header and it emits its own `s_waitcnt vmcnt(3..0)` in front
-  // of the first S MFMAs of every tile - which also drains the LDS-DMA of tile j + 1 issued a few instructions earlier (the prefetch
-  // then overlaps nothing).  The empty asm reads the registers, so the compiler's wait lands here, once.
-  asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  tile_dma(kb_, p.ld_k, 0, nkv, Ks[0]);
-  tile_dma(vb, p.ld_v, 0, nkv, Vs[0]);
-#ifdef TFX_ATTN_TIMING
-  // debug build: per-wave cycle totals of the four sections of the tile loop go to (uint64*)p.dq (unused by the forward)
-  unsigned long long tsec[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define AT_MARK(i) { const unsigned long long tn = __builtin_readcyclecounter(); tsec[i] += tn - tprev; tprev = tn; }
-#else
-#define AT_MARK(i)
-#endif
-  for (int j = 0; j < nt; j++) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile j have landed
-    __builtin_amdgcn_s_barrier();                             // ... everyone's have, and everyone is done with the other buffer
-    if (j + 1 < nt) { tile_dma(kb_, p.ld_k, (j + 1) * 64, nkv, Ks[(j + 1) & 1]); tile_dma(vb, p.ld_v, (j + 1) * 64, nkv, Vs[(j + 1) & 1]); }
-    const bf16* Kt = Ks[j & 1];
-    const bf16* Vt = Vs[j & 1];
-    AT_MARK(0)
-
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-      s[kb] = MFMA(dma_rowfrag(Kt, kb * 32, 0), qf[0], zero16);                                  // S^T[key][q]; shared zero C operand
-#pragma unroll
-      for (int ks = 1; ks < 4; ks++) s[kb] = MFMA(dma_rowfrag(Kt, kb * 32, ks), qf[ks], s[kb]);
-    }
-#ifdef TFX_ATTN_TIMING
-    asm volatile("" : "+v"(s[0]), "+v"(s[1]));
-#endif
-    AT_MARK(1)
-    const bool need_mask = (j + 1) * 64 > kve_min;            // wave-uniform: interior tiles skip the compare/select
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-      softcap16(s[kb], sc_);
-#pragma unroll
-      for (int r = 0; r < 16; r++) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
-      if (need_mask) {                                          // ONE scalar branch per 32-key block (boundary tiles only)
-        const int key0 = j * 64 + kb * 32 + 4 * hi;
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[kb][r] = key0 + (r & 3) + 8 * (r >> 2) < kve ? s[kb][r] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < 8; i++) { const f32x2 e = {s[kb][2 * i], s[kb][2 * i + 1]}; lsum2 += e; }
-    }
-#ifdef TFX_ATTN_TIMING
-    asm volatile("" : "+v"(s[0]), "+v"(s[1]));
-#endif
-    AT_MARK(2)
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-      for (int tt = 0; tt < 2; tt++) {
-        const bf16x8 pf = pack8(s[kb], tt);
-        const int ra = kb * 32 + 16 * tt + 4 * hi;
-#pragma unroll
-        for (int db = 0; db < 2; db++) o[db] = MFMA(dma_tr8(Vt, ra, ra + 8, db * 32), pf, o[db]);   // O^T[d][q]
-      }
-#ifdef TFX_ATTN_TIMING
-    asm volatile("" : "+v"(o[0]), "+v"(o[1]));
-#endif
-    AT_MARK(3)
-  }
-#ifdef TFX_ATTN_TIMING
-  if (l == 0) {
-    unsigned long long* ob = (unsigned long long*)p.dq + ((((size_t)b * p.h + h) * ((n + 127) / 128) + bi.tile) * 4 + w) * 5;
-    for (int i = 0; i < 4; i++) ob[i] = tsec[i];
-    ob[4] = nt;
-  }
-#endif
-#undef AT_MARK
-  float lsum = lsum2[0] + lsum2[1];
-  lsum += __shfl_xor(lsum, 32, 64);
-  if (qrow < n) {
-    const float g = sigmoidf_(bf2f(p.gate[(tok0 + qrow) * p.ld_gate + h]));
-    const float sc = g * __builtin_amdgcn_rcpf(lsum);
-    bf16* op = p.out + (tok0 + qrow) * p.ld_out + h * DH;
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        bf16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = f2bf(o[db][rg * 4 + e] * sc);
-        *(bf16x4*)(op + db * 32 + 8 * rg + 4 * hi) = v;
-      }
-    if (hi == 0) p.lse[((size_t)b * p.h + h) * p.n + qrow] = __log2f(lsum) * LN2;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// forward, software-pipelined form (the product kernel; TFX_ATTN_PIPE=0 selects the plain loop above)
+// forward, software-pipelined form (the plain loop it replaced in round 2 was removed in round 6)
 // ------------------------------------------------------------------------------------------------
 // Measured on gfx950 (tools/valu_probe.hip, tools/overlap_probe.hip): a wave64 v_fma_f32 issues in 2.7 clocks, the PACKED f32 forms in 6.5
 // (slower than two scalar ops), v_exp_f32 in 8.5, v_cvt_pk_bf16_f32 in 4.6 - and one v_mfma_f32_32x32x16_bf16 occupies the SIMD's matrix
@@ -875,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(tfx_attn_args p) {
 #pragma unroll
       for (int e = 0; e < 8; e++) pg[e] = 0.f;
       wave_block_store_nr<0>((w < 2 ? Ks : Vs) + (w & 1) * 2048, ov, p, tok0 + q0 + w * 32, h * DH, n - (q0 + w * 32), pg);
-      nr_flush_dgamma(pg, sg, p.nr_dgamma_q, p.nr_scratch ? p.nr_scratch + linear_block() * 64 : nullptr);
+      nr_flush_dgamma(pg, sg, p.nr_dgamma_q);
     } else
     wave_block_store((w < 2 ? Ks : Vs) + (w & 1) * 2048, ov, p.dq + (tok0 + q0 + w * 32) * p.ld_dq + h * DH, p.ld_dq, n - (q0 + w * 32));
   }
@@ -952,10 +802,15 @@ TFX_DEV void dq_phase_any(f32x16& s_cur, f32x16& dp_cur, f32x16& s_nxt, f32x16& 
                           float lse2, float dlt, const SoftCap& c, int key0, int kve, bool mask, int lane) {
   if constexpr (MODE == 2) softcap16(s_cur, c);                     // no plan: the degree follows the wave's scores (not overlapped with the matrix work)
   // boundary units (one or two per wave): a masked score gets dP = delta, i.e. dS = P (delta - delta) tanh' = 0 - the plain kernel's P = 0 up to the sign of the
-  // zero; ONE straight-line phase (a second, masked instantiation of it pushed the kernel from 230 registers to 256 + 131 spilled)
+  // zero - and the score 0, so that its P = exp2(-lse2) stays finite (a large masked score against a small lse: inf x 0); ONE straight-line phase (a second,
+  // masked instantiation of it pushed the kernel from 230 registers to 256 + 131 spilled)
   if (mask) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) dp_cur[r] = key0 + (r & 3) + 8 * (r >> 2) < kve ? dp_cur[r] : dlt;
+    for (int r = 0; r < 16; r++) {
+      const bool vis = key0 + (r & 3) + 8 * (r >> 2) < kve;
+      dp_cur[r] = vis ? dp_cur[r] : dlt;
+      s_cur[r] = vis ? s_cur[r] : 0.f;
+    }
   }
   dq_phase<MODE>(s_cur, dp_cur, s_nxt, dp_nxt, ds_prev, ds_cur, dq, qf, dof, Kt_nxt, Vt_nxt, kb_nxt, Kt_prev, kb_prev, lse2, dlt, c, lane);
 }
@@ -1037,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(tfx_attn_args 
 #pragma unroll
   for (int ks = 0; ks < 4; ks++) { qf[ks] = g_rowfrag(qb, p.ld_q, qrow, n, ks, l); dof[ks] = g_rowfrag(dob, p.ld_do, qrow, n, ks, l); }
   const SoftCap sc_ = make_softcap(p.softcap, p.sc_plan);
-  // compiler-visible loads are consumed before the counted DMA waits (see attn_fwd_kernel)
+  // compiler-visible loads are consumed before the counted DMA waits (see attn_fwd_pipe_kernel)
   float lse2_ = lse2, dlt_ = dlt;
   asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(dof[0]), "+v"(dof[1]), "+v"(dof[2]), "+v"(dof[3]), "+v"(lse2_), "+v"(dlt_));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1129,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(tfx_attn_args 
 #pragma unroll
       for (int e = 0; e < 8; e++) pg[e] = 0.f;
       wave_block_store_nr<0>(st, ov, p, tok0 + q0 + w * 32, h * DH, n - (q0 + w * 32), pg, l);
-      nr_flush_dgamma(pg, sg, p.nr_dgamma_q, p.nr_scratch ? p.nr_scratch + ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * z)) * 64 : nullptr, tx);
+      nr_flush_dgamma(pg, sg, p.nr_dgamma_q, tx);
     } else
     wave_block_store(st, ov, p.dq + (tok0 + q0 + w * 32) * p.ld_dq + h * DH, p.ld_dq, n - (q0 + w * 32), l);
   }
@@ -1286,8 +1141,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
       for (int e = 0; e < 8; e++) pg[e] = 0.f;
       wave_block_store_nr<1>(st, kv, p, tok0 + k0 + w * 32, (p.h + h) * DH, rows, pg);
       wave_block_store(st, vv, p.dv + (tok0 + k0 + w * 32) * p.ld_dv + h * DH, p.ld_dv, rows);
-      nr_flush_dgamma(pg, sg, p.nr_dgamma_k,
-                      p.nr_scratch ? p.nr_scratch + ((size_t)gridDim.x * gridDim.y * gridDim.z + linear_block()) * 64 : nullptr);
+      nr_flush_dgamma(pg, sg, p.nr_dgamma_k);
     } else {
       wave_block_store(st, kv, p.dk + (tok0 + k0 + w * 32) * p.ld_dk + h * DH, p.ld_dk, rows);
       wave_block_store(st, vv, p.dv + (tok0 + k0 + w * 32) * p.ld_dv + h * DH, p.ld_dv, rows);
@@ -1295,33 +1149,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
   }
 }
 
-static int attn_pipe() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TFX_ATTN_PIPE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v;
-}
-static int attn_order() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TFX_ATTN_ORDER"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v;
-}
-static dim3 attn_grid(const tfx_attn_args& q) {
-  const int ntile = (q.n + 127) / 128;
-  return q.order ? dim3(q.h, q.b, ntile) : dim3(ntile, q.h, q.b);
-}
+static dim3 attn_grid(const tfx_attn_args& q) { return dim3(q.h, q.b, (q.n + 127) / 128); }
 int attn_fwd(const tfx_attn_args& p, hipStream_t s) {
   if (p.n <= 0 || p.b <= 0 || p.h <= 0) return -1;
   if ((p.ld_q | p.ld_k | p.ld_v | p.ld_out) & 7) return -2;
   if (!(p.softcap > 0.f) || p.softcap * LOG2E > 96.f) return -3;     // fixed-reference softmax needs exp2(cap*log2e) finite in fp32 sums
-  tfx_attn_args q = p; q.order = attn_order();
+  tfx_attn_args q = p; q.order = 1;
   // TFX_ATTN_ASM=1: the generated main loop for the unmasked tiles (bit-identical; OFF - measured round 6, profiles/r06_attn_fwd_asm_*: the loop's 88-instruction
   // vector stream is 27 us of the launch, but 76 us of the 134 are prologue, boundary tiles and epilogue, and at 179 registers two blocks share a CU where the
   // hipcc form (165) fits three: 145 against 134 us per launch in the step)
   static int use_asm = -1;
   if (use_asm < 0) { const char* e = getenv("TFX_ATTN_ASM"); use_asm = (e && e[0] == '1') ? 1 : 0; }
-  if (attn_pipe() && use_asm && p.n_kv == 0 && !p.q_cnt && !p.q_row0 && p.sc_plan) hipLaunchKernelGGL(attn_fwd_pipe_kernel<true>, attn_grid(q), dim3(256), 0, s, q);
-  else if (attn_pipe()) hipLaunchKernelGGL(attn_fwd_pipe_kernel<false>, attn_grid(q), dim3(256), 0, s, q);
-  else hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(q), dim3(256), 0, s, q);
+  if (use_asm && p.n_kv == 0 && !p.q_cnt && !p.q_row0 && p.sc_plan) hipLaunchKernelGGL(attn_fwd_pipe_kernel<true>, attn_grid(q), dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(attn_fwd_pipe_kernel<false>, attn_grid(q), dim3(256), 0, s, q);
   return (int)hipGetLastError();
 }
 int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
@@ -1334,7 +1174,7 @@ int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
     if (!p.nr_dqkv || !p.nr_gamma_q || !p.nr_gamma_k || !p.nr_rot_pos || !p.nr_cos || !p.nr_sin || !p.nr_dgamma_q || !p.nr_dgamma_k) return -5;
     if (((p.nr_ld_qkv | p.nr_ld_dqkv) & 7) || (((uintptr_t)p.nr_qkv | (uintptr_t)p.nr_dqkv) & 15)) return -5;
   }
-  tfx_attn_args q = p; q.order = attn_order();
+  tfx_attn_args q = p; q.order = 1;
   // TFX_ATTN_BWD_PIPE=0: the plain-loop dQ kernel (A/B; bit-identical results)
   static int pipe = -1;
   if (pipe < 0) { const char* e = getenv("TFX_ATTN_BWD_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; }
@@ -1342,11 +1182,6 @@ int attn_bwd(const tfx_attn_args& p, hipStream_t s) {
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, attn_grid(q), dim3(256), 0, s, q);
   if (pipe) hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel, attn_grid(q), dim3(256), 0, s, q);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel, attn_grid(q), dim3(256), 0, s, q);
-  if (p.nr_qkv && p.nr_scratch) {
-    const dim3 g = attn_grid(q);
-    const int nblocks = (int)(g.x * g.y * g.z);
-    hipLaunchKernelGGL(attn_nr_reduce_kernel, dim3((nblocks + 255) / 256, 2), dim3(256), 0, s, (const float*)p.nr_scratch, nblocks, p.nr_dgamma_q, p.nr_dgamma_k);
-  }
   return (int)hipGetLastError();
 }
 

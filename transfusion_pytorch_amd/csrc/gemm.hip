@@ -1537,32 +1537,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
   __builtin_amdgcn_s_setprio(0);                                                                              \
   asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));   /* pin: LLVM may sink pure MFMAs past the barrier */
 
-#ifndef TFX_PP_BAL
-#define TFX_PP_BAL 0
-#endif
-  // TFX_PP_BAL=1 (round 5 experiment, `tools/build_variant.sh <name> WORK -DTFX_PP_BAL=1`; OFF): fragment reads balanced over the phases.  The schedule reads
-  // 12 / 4 / 8 / 0 fragments in phases 1 .. 4 - phase 1's 48 KiB per wave group is 384 LDS clocks against the partner group's 256-clock MFMA block.  With the
-  // switch B0 of the NEXT K-tile is read in phase 4 (8 / 4 / 8 / 4): it was issued a whole K-tile earlier, a counted wait ahead of phase 2's closing barrier
-  // (`vmcnt(4)`) certifies every wave's pieces of it, and phase 4's read segment lies two barriers behind that wait for both wave groups.  Correct (45 GEMM /
-  // golden tests), 244-251 registers, no spills - and SLOWER: NT family 10.55-10.68 against 10.43-10.51 ms per step, 8192 x 4096^2 1188 against 1233 TFLOP/s
-  // (same box, gpurun_out/r05n_ab.txt): phase 1's reads are not the long pole; the second counted wait and the 16 moves per K-tile cost more than they return.
-#if TFX_PP_BAL
-  bf16x8 b0[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) b0[ks] = ldB(0, 0, ks);
-#endif
   for (int kt = 0; kt < nk; kt++) {
-#if TFX_PP_BAL
-    bf16x8 a[2][4], b1[4], b0n[4];
-#else
     bf16x8 a[2][4], b0[4], b1[4];
-#endif
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
     // ---- phase 1: read a0 (, b0) ; MFMA (a0, b0) + DMA A1(kt+1)
-#if !TFX_PP_BAL
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) b0[ks] = ldB(kt, 0, ks);
-#endif
 #pragma unroll
     for (int il = 0; il < 2; il++)
 #pragma unroll
@@ -1575,9 +1555,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
     for (int ks = 0; ks < 4; ks++) b1[ks] = ldB(kt, 1, ks);
     PP_BAR()
     PP_MFMA(0, 1, a, b1, if (n1) issueB1(kt + 1, 1, 0), if (n1) issueB1(kt + 1, 1, 1))
-#if TFX_PP_BAL
-    if (n1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // this wave's pieces of A0 / B0 of K-tile kt+1 have landed (issued in phases 3 / 4 of kt-1)
-#endif
     PP_BAR()
     // ---- phase 3: read a1 ; MFMA (a1, b1) + DMA A0(kt+2)
 #pragma unroll
@@ -1588,23 +1565,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pp_kernel(GemmNT p, int stagge
     PP_MFMA(2, 1, a, b1, if (n2) issueA1(kt + 2, 0, 0), if (n2) issueA1(kt + 2, 0, 1))
     PP_BAR()
     // ---- phase 4: (read B0 of K-tile kt+1 ;) certify K-tile kt+1 (only A0(kt+2) may still be outstanding) ; MFMA (a1, b0) + DMA B0(kt+2)
-#if TFX_PP_BAL
-    if (n1) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) b0n[ks] = ldB(kt + 1, 0, ks);
-    }
-#endif
     if (n2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR()
     PP_MFMA(2, 0, a, b0, if (n2) issueB1(kt + 2, 0, 0), if (n2) issueB1(kt + 2, 0, 1))
     PP_BAR()
-#if TFX_PP_BAL
-    if (n1) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) b0[ks] = b0n[ks];
-    }
-#endif
   }
 #undef PP_BAR
 #undef PP_MFMA
@@ -2079,11 +2044,9 @@ TFX_DEV void tn_ow_body(const GemmTN& p, const TnBlock& blk) {
   const uint32_t prow = (uint32_t)((w >> 1) * 32 + (l >> 4));
   const uint32_t pchunk = (uint32_t)((l & 15) ^ (((l >> 4) & 3) << 2));
   uint32_t voA = (((uint32_t)mbeg + prow) * (uint32_t)p.lda + (uint32_t)(n0 + (w & 1) * 128) + pchunk * 8u) * 2u;
-  // split B (tfx.h: B2 / K1): the tile's product columns come from ONE of the two sources (K1 % 256 == 0), a block-uniform choice of base, leading dimension and width
-  const bool second = p.B2 != nullptr && k0 >= p.K1;
-  const uint32_t ldb = (uint32_t)(second ? p.ldb2 : p.ldb), bcols = (uint32_t)(second ? p.K - p.K1 : p.b_cols), kb = (uint32_t)(second ? k0 - p.K1 : k0);
+  const uint32_t ldb = (uint32_t)p.ldb, bcols = (uint32_t)p.b_cols, kb = (uint32_t)k0;
   uint32_t voB = (((uint32_t)mbeg + prow) * ldb + kb + (uint32_t)((w & 1) * 128) + pchunk * 8u) * 2u;
-  const uint64_t baseA = (uint64_t)(uintptr_t)p.A, baseB = (uint64_t)(uintptr_t)(second ? p.B2 : p.B);
+  const uint64_t baseA = (uint64_t)(uintptr_t)p.A, baseB = (uint64_t)(uintptr_t)p.B;
   u32x4 rsA, rsB;
   rsA[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseA); rsA[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseA >> 32) & 0xffffu);
   rsA[2] = __builtin_amdgcn_readfirstlane(((uint32_t)(p.M - 1) * (uint32_t)p.lda + (uint32_t)p.a_cols) * 2u); rsA[3] = 0x00020000u;
@@ -2193,8 +2156,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_ow_group_kernel(TnGroup g, int
 // 208 / 256 / 320 / 384 / 512 blocks.  Past the knee more splits only add fp32 atomics: the kernels run against the power limit, not against
 // idle CUs.  Chunks stay >= 256 rows.
 static int tn_auto_splits(int M, int tiles, int kind) {
-  static double fill2 = -1, fill0 = -1;        // TFX_TN_FILL / TFX_TN_FILL0 (A/B): 256 x 256 tiles (256 slots) / the 4-wave tilings (512 slots)
-  if (fill2 < 0) { const char* e = getenv("TFX_TN_FILL"); fill2 = e ? atof(e) : 0.9; e = getenv("TFX_TN_FILL0"); fill0 = e ? atof(e) : 0.5; }
+  constexpr double fill2 = 0.9, fill0 = 0.5;   // 256 x 256 tiles (256 slots) / the 4-wave tilings (512 slots); swept in round 3 (profiles/r03_c_tn_splits.txt)
   const int slots = kind == 2 ? 256 : 512;
   const double want = (kind == 2 ? fill2 : fill0) * slots;
   int s = 1;
@@ -2221,7 +2183,9 @@ static bool use_glds() {             // TFX_GEMM_GLDS=0 forces the register-stag
 //   2 mid       at most one 128 x 128 tile per CU and K >= 256
 //   1 glds      128 x 128 tiles, LDS-DMA, two stages
 //   0 register-staged fallback: N % 4 != 0 (the LDS-DMA kernels' pipelined epilogue stores whole 4-column groups) or TFX_GEMM_GLDS=0
-enum { NT_FALLBACK = 0, NT_GLDS = 1, NT_MID = 2, NT_PP = 3, NT_SKINNY = 4, NT_DECODE = 5 };
+//   6 one-wave  the 256 x 256 family on the one-wave-per-SIMD kernel, one tile per block (fp32 outputs from K = 1024; bf16 outputs with K < 192)
+//   7 one-wave, persistent (bf16 outputs, K >= 192)
+enum { NT_FALLBACK = 0, NT_GLDS = 1, NT_MID = 2, NT_PP = 3, NT_SKINNY = 4, NT_DECODE = 5, NT_OW = 6, NT_OWP = 7 };
 
 // device copy of the GELU grid of the GEGLU-forward epilogue (geglu_uvh_grid): built once per process and device in double precision.
 // TFX_GELU_TABLE=0 keeps the polynomial form (A/B, tests).  Returns nullptr when disabled or when the allocation fails (the epilogue then evaluates the
@@ -2255,37 +2219,34 @@ static const float* gelu_table() {
   return tab[dev];
 }
 struct NtPlan { int kind, grid; };
+static bool nt_ow_takes(const GemmNT& p);
+static bool nt_owp_takes(const GemmNT& p);
 static NtPlan nt_plan(const GemmNT& p) {
   const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int t256 = ((p.M + BM2 - 1) / BM2) * ((p.N + BN2 - 1) / BN2);
   const bool dma = use_glds() && (p.N & 3) == 0;
-  static int dec64 = -1;              // TFX_NT_DECODE=0: the 64 x 128 skinny kernel for every small M (A/B)
-  if (dec64 < 0) { const char* e = getenv("TFX_NT_DECODE"); dec64 = e ? atoi(e) : 1; }
-  static int mid = -1;                // TFX_NT_MID=0: the 2-stage kernel also when a CU gets at most one tile (A/B)
-  if (mid < 0) { const char* e = getenv("TFX_NT_MID"); mid = e ? atoi(e) : 1; }
   const int grid_sd = ((p.M + 63) / 64) * ((p.N + 63) / 64);
   const int grid_sk = ((p.M + SK_BM - 1) / SK_BM) * ((p.N + SK_BN - 1) / SK_BN);
-  if (dma && p.M <= 1024 && dec64 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) return {NT_DECODE, grid_sd};
+  if (dma && p.M <= 1024 && p.K % SD_BK == 0 && p.K >= 8 * SD_BK && grid_sd <= 256) return {NT_DECODE, grid_sd};
   if (dma && (p.M <= 512 || (p.M <= 1024 && grid_sk <= 256))) return {NT_SKINNY, grid_sk};
-  static int pp_min = -1;             // TFX_NT_PP_MIN: fewest 256 x 256 tiles that still take the ping-pong kernel (A/B; default 512 = two per CU)
+  static int pp_min = -1;             // TFX_NT_PP_MIN: fewest 256 x 256 tiles that still take the 256 x 256 family (tests, probe; default 512 = two per CU)
   if (pp_min < 0) { const char* e = getenv("TFX_NT_PP_MIN"); pp_min = e ? atoi(e) : 512; }
-  if (dma && t256 >= pp_min) return {NT_PP, t256};
-  if (dma && mid && grid <= 256 && p.K >= 4 * BK) return {NT_MID, grid};
+  if (dma && t256 >= pp_min) return {!nt_ow_takes(p) ? NT_PP : nt_owp_takes(p) ? NT_OWP : NT_OW, t256};
+  if (dma && grid <= 256 && p.K >= 4 * BK) return {NT_MID, grid};
   return {dma ? NT_GLDS : NT_FALLBACK, grid};
 }
 
+constexpr int PP_STAGGER = 12000;       // de-phasing delay of the first round's odd blocks in shader clocks (dephase_first_round; swept in rounds 2, 3, 5)
 template <int EPI> static void launch_pp(const GemmNT& p, int grid, hipStream_t s) {
   static uint32_t attr_pp = 0;
   const float* gtab = EPI == EPI_GEGLU ? gelu_table() : nullptr;
   const int smem2 = 2 * (BM2 * BK + BN2 * BK) * 2 + (gtab ? GTAB_N * 8 : 0);       // GEGLU forward / backward: + the 32 KiB GELU table = all 160 KiB of the CU
   ensure_smem_attr((const void*)gemm_nt_pp_kernel<EPI>, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8, attr_pp);
-  static int stagger = -1;          // TFX_PP_STAGGER: de-phasing delay in shader clocks (0 = off), see dephase_first_round
-  if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
-  hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), smem2, s, p, stagger, gtab);
+  hipLaunchKernelGGL(gemm_nt_pp_kernel<EPI>, dim3(grid), dim3(512), smem2, s, p, PP_STAGGER, gtab);
 }
-// TFX_NT_OW: which launches of the 256 x 256 family run on the one-wave-per-SIMD kernels: 0 none (the ping-pong kernel), 1 (default) those that measured faster
-// there inside the training step (bf16 outputs; fp32 outputs from K = 1024), 2 every epilogue (A/B, tests).  Their loops read both operands through raw buffer resources with 32-bit offsets and take
-// neither a row-gathered nor a split A.
+// TFX_NT_OW=0: the ping-pong kernel for every launch of the 256 x 256 family (A/B, tests).  Default: the one-wave-per-SIMD kernels where they measured faster
+// inside the training step (bf16 outputs; fp32 outputs from K = 1024).  Their loops read both operands through raw buffer resources with 32-bit offsets and
+// take neither a row-gathered nor a split A.  (The other epilogues on four waves measured slower and two instantiations spilled: removed in round 6.)
 static int nt_ow_mode() {
   static int ow = -1;
   if (ow < 0) { const char* e = getenv("TFX_NT_OW"); ow = e ? atoi(e) : 1; }
@@ -2293,8 +2254,8 @@ static int nt_ow_mode() {
 }
 static bool nt_ow_takes(const GemmNT& p) {
   const int ow = nt_ow_mode();
-  if (ow == 0 || p.a_rowmap || p.A2 || p.epi == EPI_QKNR) return false;
-  if (ow == 1 && !(p.epi == EPI_BF16 || (p.epi == EPI_F32 && p.K >= 1024))) return false;
+  if (ow == 0 || p.a_rowmap || p.A2) return false;
+  if (!(p.epi == EPI_BF16 || (p.epi == EPI_F32 && p.K >= 1024))) return false;
   if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) != 0) return false;
   const long long lim = 1ll << 32;
   return ((long long)p.M + 2 * BM2) * p.lda * 2 < lim && ((long long)p.N + 2 * BN2) * p.ldb * 2 < lim;
@@ -2309,23 +2270,19 @@ template <int EPI> static void launch_owp(const GemmNT& p, int tiles, hipStream_
   static uint32_t attr_owp = 0;
   const int smem = 2 * (BM2 * BK + BN2 * BK) * 2 + 4 * 8192;      // all 160 KiB of the CU
   ensure_smem_attr((const void*)gemm_nt_owp_kernel<EPI>, smem, attr_owp);
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
   static int cus[16] = {0};
   int dev = 0; (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16) dev = 0;
   if (!cus[dev]) { hipDeviceProp_t pr; cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
   const int grid = std::min(cus[dev] / 8 * 8, (tiles + 7) / 8 * 8);
-  hipLaunchKernelGGL(gemm_nt_owp_kernel<EPI>, dim3(grid), dim3(256), smem, s, p, stagger, tiles);
+  hipLaunchKernelGGL(gemm_nt_owp_kernel<EPI>, dim3(grid), dim3(256), smem, s, p, PP_STAGGER, tiles);
 }
 template <int EPI> static void launch_ow(const GemmNT& p, int grid, hipStream_t s) {
   static uint32_t attr_ow = 0;
   const float* gtab = EPI == EPI_GEGLU ? gelu_table() : nullptr;
   const int smem = 2 * (BM2 * BK + BN2 * BK) * 2 + (gtab ? GTAB_N * 8 : 0);
   ensure_smem_attr((const void*)gemm_nt_ow_kernel<EPI>, 2 * (BM2 * BK + BN2 * BK) * 2 + GTAB_N * 8, attr_ow);
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("TFX_PP_STAGGER"); stagger = e ? atoi(e) : 12000; }
-  hipLaunchKernelGGL(gemm_nt_ow_kernel<EPI>, dim3(grid), dim3(256), smem, s, p, stagger, gtab);
+  hipLaunchKernelGGL(gemm_nt_ow_kernel<EPI>, dim3(grid), dim3(256), smem, s, p, PP_STAGGER, gtab);
 }
 template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
   const NtPlan pl = nt_plan(p);
@@ -2345,11 +2302,9 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
       hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sk, s, p);
       break;
     }
-    case NT_PP:
-      if (!nt_ow_takes(p)) launch_pp<EPI>(p, pl.grid, s);
-      else if constexpr (EPI == EPI_BF16) { if (nt_owp_takes(p)) launch_owp<EPI>(p, pl.grid, s); else launch_ow<EPI>(p, pl.grid, s); }
-      else launch_ow<EPI>(p, pl.grid, s);
-      break;
+    case NT_PP: launch_pp<EPI>(p, pl.grid, s); break;
+    case NT_OW: if constexpr (EPI == EPI_BF16 || EPI == EPI_F32) launch_ow<EPI>(p, pl.grid, s); break;        // (nt_ow_takes: these two epilogues only)
+    case NT_OWP: if constexpr (EPI == EPI_BF16) launch_owp<EPI>(p, pl.grid, s); break;
     case NT_MID: {
       static uint32_t attr_md = 0;
       const int smem_md = MD_ST * MD_STAGE * 2;
@@ -2371,12 +2326,10 @@ int gemm_nt_plan(const GemmNT& p, int* kind, int* grid) {
 }
 
 // TFX_EPI_QKV_NORM_ROPE: fused in the ping-pong kernel when the shape runs there and the staged (16-byte, row-contiguous) stores apply; otherwise the
-// plain projection followed by the token-wise kernel - same results either way.  TFX_QKNR_FUSED=0 forces the two launches (A/B, tests).
+// plain projection followed by the token-wise kernel - same results either way.
 static bool qknr_fusable(const GemmNT& p) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("TFX_QKNR_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
   const int kind = nt_plan(p).kind;
-  if (!on || (kind != NT_PP && kind != NT_DECODE)) return false;
+  if (kind != NT_PP && kind != NT_DECODE) return false;
   if (kind == NT_PP && p.qk_cache) return false;                  // (the cache append exists in the decode-step kernel's instantiation only)
   const int hd = p.qk_heads * 64;
   if (p.qk_cache && (!p.qk_cache_pos || (p.qk_ld_cache & 7) || (((uintptr_t)p.qk_cache) & 15) || p.N < 3 * hd)) return false;
@@ -2433,8 +2386,6 @@ struct TnPlan { int kind, tiles, splits, grid; };
 static int tn_ow_mode();
 static bool tn_ow_operands_ok(const GemmTN& q);
 static TnPlan tn_plan(const GemmTN& q) {
-  static int tile = -2;               // TFX_TN_TILE: force 0 = 128 x 128 blocks or 2 = 256 x 256 (A/B, tests); unset: by tile count
-  if (tile == -2) { const char* e = getenv("TFX_TN_TILE"); tile = e ? atoi(e) : -1; }
 #ifdef TFX_TN_TIMING
   const bool dma_ok = true;
 #else
@@ -2443,7 +2394,7 @@ static TnPlan tn_plan(const GemmTN& q) {
   const int t44 = ((q.N + 255) / 256) * ((q.K + 255) / 256), t22 = ((q.N + 127) / 128) * ((q.K + 127) / 128);
   TnPlan pl;
   // 256 x 256 tiles once there are enough of them to fill the chip at <= 32 splits; below that (512 x 512: 4 tiles) the 128 x 128 blocks
-  pl.kind = !dma_ok ? -1 : tile == 0 || tile == 2 ? tile : (t44 >= 8 ? 2 : 0);
+  pl.kind = !dma_ok ? -1 : (t44 >= 8 ? 2 : 0);
   pl.tiles = pl.kind == 2 ? t44 : t22;
   pl.splits = q.splits == 0 ? tn_auto_splits(q.M, pl.tiles, pl.kind) : q.splits;
   pl.grid = (pl.tiles * pl.splits + 7) / 8 * 8;                   // tn_block: 8 equal runs of (chunk, tile) pairs, one per XCD
@@ -2466,9 +2417,7 @@ static int tn_ow_mode() {
 }
 static bool tn_ow_operands_ok(const GemmTN& q) {        // what the one-wave kernel needs of a product, whatever its tile count
   const long long lim = 1ll << 32;
-  const bool b_ok = q.B2 ? (q.K1 % 256 == 0 && q.K1 > 0 && q.K1 < q.K && q.b_cols >= q.K1 && q.ldb2 >= q.K - q.K1 && (q.ldb2 & 7) == 0 && ((uintptr_t)q.B2 & 15) == 0 && q.k_group == 0 &&
-                                (long long)(q.M + 64) * q.ldb2 * 2 < lim)
-                         : q.b_cols >= q.K;
+  const bool b_ok = q.b_cols >= q.K;
   return use_glds() && q.M % 64 == 0 && !q.a_rowmap && !q.b_rowmap && (((uintptr_t)q.A | (uintptr_t)q.B) & 15) == 0 && ((q.lda | q.ldb | q.a_cols | q.b_cols) & 7) == 0 &&
          (long long)(q.M + 64) * q.lda * 2 < lim && (long long)(q.M + 64) * q.ldb * 2 < lim && q.a_cols >= q.N && b_ok && q.N > 0 && q.K > 0;
 }
@@ -2502,14 +2451,11 @@ static TnGroupPlan tn_group_plan(const GemmTN& head) {
   return gp;
 }
 static int tn_ramp(int M, int tiles, int splits) {   // tn_block_ramp's d for a launch (see the kind-3 branch of gemm_tn)
-  static double ramp_f = -1;
-  if (ramp_f < 0) { const char* e = getenv("TFX_TN_RAMP"); ramp_f = e ? atof(e) : 1.0; }
-  static int ramp_min = -1;            // TFX_TN_RAMP_MIN: fewest row chunks that get a ramp (default 8: 2-5-chunk launches measured nothing to +1 %; 6 - the 7-chunk FeedForward group - 4.19 -> 4.17 ms, noise)
-  if (ramp_min < 0) { const char* e = getenv("TFX_TN_RAMP_MIN"); ramp_min = e ? atoi(e) : 8; }
+  constexpr int ramp_min = 8;          // fewest row chunks that get a ramp (2-5-chunk launches measured nothing to +1 %; 6 - the 7-chunk FeedForward group - 4.19 -> 4.17 ms, noise)
   int ramp = 0;
-  if (splits >= ramp_min && ramp_f > 0 && M % TN_BMK == 0) {
+  if (splits >= ramp_min && M % TN_BMK == 0) {
     const int S = splits, U = M / TN_BMK;
-    ramp = (int)(0.148 * tiles * ramp_f + 0.5);
+    ramp = (int)(0.148 * tiles + 0.5);                                 // (factors 0.5 / 1.5 / 2 all measured worse: profiles/r05b_tn_ramped_chunks.txt)
     while (ramp > 0 && (U - ramp * S * (S - 1) / 2) / S < 8) ramp--;   // the shortest chunk keeps >= 8 steps
   }
   return ramp;
@@ -2554,21 +2500,12 @@ int gemm_tn(const GemmTN& p, hipStream_t s) {
   ensure_smem_attr((const void*)gemm_tn_kernel, smem, attr_set);
   GemmTN q = p;
   const TnPlan pl = tn_plan(q);
-  if (p.B2 && pl.kind != 3) {                                   // split B on the other kernels: the two products, one after the other
-    if (p.K1 <= 0 || p.K1 >= p.K || p.k_group != 0 || (p.ldb2 & 7)) return -6;
-    GemmTN a = p, b = p;
-    a.B2 = nullptr; a.K = p.K1; a.k_valid = std::min(p.k_valid, p.K1);
-    b.B2 = nullptr; b.B = p.B2; b.ldb = p.ldb2; b.b_cols = (p.K - p.K1 + 7) / 8 * 8 <= p.ldb2 ? (p.K - p.K1 + 7) / 8 * 8 : p.ldb2 / 8 * 8; b.K = p.K - p.K1;
-    b.k_valid = std::max(0, p.k_valid - p.K1); b.C = p.C + p.K1; b.colsum = nullptr;
-    const int rc = gemm_tn(a, s);
-    return rc ? rc : (b.k_valid > 0 ? gemm_tn(b, s) : 0);
-  }
   q.splits = pl.splits;
   const int kind = pl.kind, grid = pl.grid;
   if (kind == 3) {
     static uint32_t attr_tnow = 0;
     // ramp (tn_block_ramp): the finish times of the chunks should spread over about the time the launch's atomics take, tiles x chunks x 0.2 us (256 KiB at
-    // 1.25 TB/s), i.e. d = 0.2 us x tiles / (a step's 1.35 us) steps of 64 rows per chunk index.  TFX_TN_RAMP scales it (0 = equal chunks).  Measured
+    // 1.25 TB/s), i.e. d = 0.2 us x tiles / (a step's 1.35 us) steps of 64 rows per chunk index.  Measured
     // (gpurun_out/ow31.txt, steady state): -3.5 ... -7.8 % on the 11-20-chunk launches of config 2 at factor 1, worse at 0.5 / 1.5 / 2, nothing to +1 % on the
     // 2-5-chunk launches - so from 8 chunks on
     const int ramp = tn_ramp(q.M, pl.tiles, q.splits);

@@ -88,12 +88,10 @@ struct SideStream {
   int ensure() {
     if (stream) return 0;
     // non-blocking: no implicit sync with the null stream.  LOWEST priority: the weight-gradient GEMMs fill what the data-gradient chain
-    // leaves idle instead of competing with it (env TFX_SIDE_PRIO=0: default priority, A/B)
+    // leaves idle instead of competing with it
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least urgent (numerically greatest)
-    const char* e = getenv("TFX_SIDE_PRIO");
-    const bool low = !(e && e[0] == '0');
-    if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, low ? lo : 0) != hipSuccess) return -110;
+    if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, lo) != hipSuccess) return -110;
     for (int i = 0; i < 64; ++i)
       if (hipEventCreateWithFlags(&fork_ev[i], hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming) != hipSuccess) return -111;
@@ -251,6 +249,11 @@ extern "C" int tfx_list_fingerprint(const tfx_launch* list, int32_t n, int64_t* 
         break;
       case TFX_OP_ATTNRES_PULL_BWD: h = mix(h, r->p0, sizeof(tfx_attnres_pull_args)); if (r->p1) h = mix(h, r->p1, sizeof(tfx_adaln_post_args)); break;
       case TFX_OP_ADALN_PRE_POST_BWD: h = mix(h, r->p0, sizeof(tfx_adaln_pre_args)); h = mix(h, r->p1, sizeof(tfx_adaln_post_args)); break;
+      case TFX_OP_GEMM_TN: {                                        // a `group_next` chain: the chained structs are copied by value into the launch a capture freezes
+        const tfx_gemm_tn_args* g = static_cast<const tfx_gemm_tn_args*>(l.args);
+        for (int k = 0; k < 8 && g->group_next; ++k) { g = static_cast<const tfx_gemm_tn_args*>(g->group_next); h = mix(h, g, sizeof(tfx_gemm_tn_args)); }
+        break;
+      }
       default: break;
     }
   }

@@ -2040,12 +2040,10 @@ template <typename F> static int resident_blocks(F fn, int threads, size_t dyn) 
   return cache[key] = per_cu * cus;
 }
 // grid of a segment kernel (8 waves = 8 segments per 512-thread block): every block resident at once, each wave walking its share of the
-// length-sorted segments with a grid stride (packing.token_segments balance=True); TFX_SEG_GRID=<n> forces a block count (A/B: 1024 = round 2)
+// length-sorted segments with a grid stride (packing.token_segments balance=True)
 template <typename F> static int seg_grid(F fn, int n_seg) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("TFX_SEG_GRID"); forced = e ? atoi(e) : 0; }
   int g = (n_seg + 7) / 8;
-  const int cap = forced > 0 ? forced : resident_blocks(fn, 512, 0);
+  const int cap = resident_blocks(fn, 512, 0);
   if (g > cap) g = cap;
   return g < 1 ? 1 : g;
 }
@@ -2131,11 +2129,6 @@ int tfx_attnres_finish(const tfx_attnres_src* src, int32_t n, int32_t d, void* s
   if (n <= 0) return 0;
   hipLaunchKernelGGL(attnres_finish_k, dim3((d + 255) / 256, n), dim3(256), 0, ST(s), src, d); RET();
 }
-static int pull_variant() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TFX_PULL_VARIANT"); v = e ? atoi(e) : 0; }
-  return v;
-}
 int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_args* b, void* s) {
   if (!a || a->n_src < 1 || a->n_src > PULL_MAX_SRC || (a->d & 7) || a->d > 2048) return -2;
   if (b && (b->T != a->T || b->d != a->d || (const void*)b->g != (const void*)a->dh)) return -3;
@@ -2145,13 +2138,11 @@ int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_ar
   const size_t acc = (size_t)a->n_src * a->d * sizeof(float);
   // few narrow sources (depth <= 8 at d <= 512): the register form (1.79 ms / step at depth 8 against 1.97 for the ring form, whose per-row issue
   // code is the larger part of its instruction stream there); everything else: the LDS-DMA ring form (depth 24 / d 1024: 18.5 ms / step against
-  // 32.3 for the push form + the separate wrapper launch).  TFX_PULL_VARIANT (A/B): 2 = ring form everywhere, 5 = register form on a 1024-block grid
-  const int var = pull_variant();
+  // 32.3 for the push form + the separate wrapper launch).
   const bool small = a->d <= 512 && a->n_src <= 8 && !a->k1;
-  if ((var == 0 && !small) || var == 2) {
+  if (!small) {
     if (a->d > 1024) return -6;
-    // d w partials in registers for few narrow sources, else exported (a->k1) for one weight-gradient GEMM behind this launch
-    if (small) return pull_dma<1, 8>(*a, bb, hp, ST(s));
+    // d w partials exported (a->k1) for one weight-gradient GEMM behind this launch
     if (!a->k1 || a->ld_k1 < a->n_src) return -5;
     return a->d <= 512 ? pull_dma<1, 0>(*a, bb, hp, ST(s)) : pull_dma<2, 0>(*a, bb, hp, ST(s));
   }
@@ -2159,9 +2150,7 @@ int tfx_attnres_pull_bwd(const tfx_attnres_pull_args* a, const tfx_adaln_post_ar
     // few sources, narrow rows: d w partials in registers, every row of the token in flight at once
     auto fn = (b && b->dbias) ? attnres_pull_reg_k<1, 8, true> : attnres_pull_reg_k<1, 8, false>;
     const int items = a->n_seg > 0 ? a->n_seg : a->T;
-    static int forced = -1;                 // TFX_PULL_GRID (A/B): block count of the register form
-    if (forced < 0) { const char* e = getenv("TFX_PULL_GRID"); forced = e ? atoi(e) : 0; }
-    int grid = (items + 7) / 8; const int cap = forced > 0 ? forced : var == 5 ? 1024 : resident_blocks(fn, 512, acc);
+    int grid = (items + 7) / 8; const int cap = resident_blocks(fn, 512, acc);          // (512 / 1024 blocks measured 180 / 197 against 173 us, round 3)
     if (grid > cap) grid = cap; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), acc, ST(s), *a, bb, hp); RET();
   }
@@ -2180,11 +2169,9 @@ int tfx_qk_norm_rope_bwd(const tfx_qk_norm_rope_args* a, void* s) {
   if (nthreads >= (1ll << 31)) return -3;
   // 1024-thread blocks, at most one per CU: every block ends in 128 global atomics onto the SAME 128 gamma-gradient addresses, and same-address
   // atomics retire at about 15 ns apiece - 1024 blocks of 256 threads spent 15 us of a 94 us launch there, 4096 blocks 61 us of 150
-  // (gpurun_out/r03qkb*_call.log).  TFX_QKB_GRID forces a block count (A/B).
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("TFX_QKB_GRID"); forced = e ? atoi(e) : 0; }
+  // (gpurun_out/r03qkb*_call.log).
   long long g = (nthreads + 1023) / 1024;
-  const long long cap = forced > 0 ? forced : 256;
+  const long long cap = 256;
   if (g > cap) g = cap;
   hipLaunchKernelGGL(qk_norm_rope_bwd_k, dim3((unsigned)g), dim3(1024), 0, ST(s), *a); RET();
 }

@@ -281,7 +281,7 @@ class Plan:
         self.cos_tab = self.sin_tab = None
         # per layer: the soft-cap plan tfx_qk_norm_rope_fwd derives from the layer's QK-RMSNorm gains (tfx.h) and its attention kernels - forward
         # and, later, backward - read: polynomial degree and coefficients from the BOUND on the scores, no look at the data.  TFX_SC_PLAN=0: decide from the scores
-        self.sc_plan = z(D, 8, dtype=torch.float32) if os.environ.get('TFX_SC_PLAN', '1') != '0' else None
+        self.sc_plan = z(D, 8, dtype=torch.float32)
         self.fwd, self.bwd = LaunchList(), LaunchList()
         self.noise_args = {}
         self.loaded_structure = None
@@ -289,7 +289,7 @@ class Plan:
         self.seg_start = z(max(T, 1), dtype=torch.int32); self.seg_len = z(max(T, 1), dtype=torch.int32)
         # AttentionResidual backward in pull form (tfx_attnres_pull_bwd): every layer's depth softmax is kept per token by the forward;
         # TFX_ATTNRES_PULL=0 keeps the push form (tfx_attnres_bwd: one read-modify-write sweep over all earlier hiddens per layer; A/B)
-        self.pull = training and D <= 32 and md.dim <= 1024 and os.environ.get('TFX_ATTNRES_PULL', '1') != '0'
+        self.pull = training and D <= 32 and md.dim <= 1024
         if self.pull:
             self.arsave = [e(T, i + 2, 4, dtype=torch.float32) for i in range(D)]
             self.arerr = e(D, T, d)                          # what rounding each AttentionResidual output to bf16 dropped
@@ -308,7 +308,9 @@ class Plan:
             nb = 2 if self.side else 1
             self.dy_f = [e(T, d) for _ in range(nb)]; self.dy_a = [e(T, d) for _ in range(nb)] if self.side else self.dy_f
             self.dskip = {j: e(T, d) for j in set(skip_sources(md).values())}
-            self.dqkvg_p = [z(T, ldq) for _ in range(nb)]; self.dqk = e(T, 2 * hd); self.dog = e(T, hd); self.do_eff = e(T, hd)
+            self.dqkvg_p = [z(T, ldq) for _ in range(nb)]; self.dog = e(T, hd); self.do_eff = e(T, hd)
+            # d q~ | d k~: written only when the QK-norm / RoPE backward is its own launch (TFX_ATTN_QKNR=0); the fused epilogues never touch dq / dk
+            self.dqk = e(T, 2 * hd) if os.environ.get('TFX_ATTN_QKNR', '1') == '0' else None
             self.delta = e(b, md.heads, n, dtype=torch.float32)
             self.dag_p = [e(T, 2 * dip) for _ in range(nb)]; self.dembed = e(T, d); self.gfin = e(T, d); self.dx0 = e(T, d)
             self.dtables = z(I1, nt3, dtype=torch.float32); self.dtab_bf = e(I1, nt3)
@@ -426,8 +428,8 @@ class Plan:
         fused_pre = {}                        # layer -> its attention-side AdaLN-pre args when the previous layer's end launch runs them
         # token-wise launches that follow each other on the same rows run as ONE launch (bit-identical to the separate kernels, tests/test_kernels_gpu.py):
         # wrapper output + next wrapper input, and the end of a layer (feed-forward output side, AttentionResidual, the next layer's input side).
-        # Decode plans always (launch-bound); training / prefill plans unless TFX_FWD_FUSED=0 (A/B): one HBM round trip of the row instead of two / three
-        fuse = self.cache is not None or os.environ.get('TFX_FWD_FUSED', '1') != '0'
+        # One HBM round trip of the row instead of two / three; decode plans are launch-bound
+        fuse = True
         for i in range(D):
             p = f'transformer.layers.{i}'
             li, lkv = self._li(i), self._lkv(i)
@@ -449,14 +451,12 @@ class Plan:
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             plan_kw = dict(sc_plan=self.sc_plan[i], softcap=50.0) if self.sc_plan is not None else {}
             # decode plans (round 4): the same epilogue in the decode-step GEMM kernel, with the KV-cache append (`qk_cache`): one launch per layer
-            # less in a step that is nothing but ~225 dependent launches (TFX_DECODE_QKNR=0: the separate token-wise launch, A/B)
-            fuse_qk = (os.environ.get('TFX_QKNR', '0') == '1') if self.cache is None else (os.environ.get('TFX_DECODE_QKNR', '1') != '0')
+            # less in a step that is nothing but ~225 dependent launches.  Training plans keep the token-wise launch: fused there the projection grows from 150 to
+            # 195 us for the 53 us launch it removes (27.50 vs 27.50 ms per step, round 4)
+            fuse_qk = self.cache is not None
             if fuse_qk:
                 # SURVEY K4 (T:946-965): QK-RMSNorm + RoPE ride in the epilogue of the [q | k | v | gates] projection (TFX_EPI_QKV_NORM_ROPE: the raw
-                # projection AND q~ | k~ leave the GEMM; shapes off the 256 x 256 kernel run as two launches inside the call).  Decode plans keep the
-                # token-wise launch: it also appends to the KV cache.  Built, bit-identical (tests/test_kernels_gpu.py) - and OFF by default: the
-                # projection grows from 150 to 195 us (the extra q~ | k~ stream alone is 27 us of HBM time; 16 us are the cos / sin row loads) for the
-                # 53 us launch it removes: 27.50 vs 27.50 ms per step in the same-box A/B, and the GEMM family's TFLOP/s falls with the work it absorbs
+                # projection AND q~ | k~ leave the GEMM; shapes off the decode-step kernel run as two launches inside the call), with the KV-cache append
                 self._nt(L, algo_n=md.nq, A=self.ua[li], lda=d, B=S[f'qkvg{i}'], ldb=d, M=T, N=md.nqk, K=d, epi=E['TFX_EPI_QKV_NORM_ROPE'], C=self.qkvg[lkv], ldc=ldq,
                          C2=self.qkr[lkv], ldc2=2 * hd, qk_heads=H, qk_gamma_q=gam('q'), qk_gamma_k=gam('k'), qk_rot_pos=self.rot_pos, qk_cos=0, qk_sin=0,
                          qk_q_scale=md.dim_head ** -0.5, qk_norm_scale=md.dim_head ** 0.5,
@@ -605,15 +605,6 @@ class Plan:
             a[1] = lt['q'].data_ptr() if mode == 'model' else lt['x'].data_ptr()
             a[2] = None if mode == 'model' else self.noise_args[t].eps
 
-    def _nr_scratch(self):
-        """per-block gain-gradient rows of the fused QK-norm / RoPE backward (tfx.h tfx_attn_args.nr_scratch): fp32 [2][heads x samples x ceil(n / 128)][64],
-        one buffer for all layers (the backward runs them one after the other)"""
-        if getattr(self, '_nr_scr', None) is None:
-            blocks = self.md.heads * self.b * ((self.n + 127) // 128)
-            self._nr_scr = torch.zeros(2 * blocks * 64, device=self.ps.device, dtype=torch.float32)
-            self.nbytes += self._nr_scr.numel() * 4
-        return self._nr_scr
-
     def _attn_kw(self, i, bwd=False):
         md, hd, ldq = self.md, self.md.hdk, self.md.ldq
         li, lkv = self._li(i), self._lkv(i)
@@ -630,7 +621,8 @@ class Plan:
         if bwd:
             dqkvg = self.dqkvg_p[i % len(self.dqkvg_p)]
             kw.update(dout=self.dog, ld_dout=hd, do_eff=self.do_eff, ld_do=hd, delta=self.delta,
-                      dgate=dqkvg.data_ptr() + 2 * 3 * hd, ld_dgate=ldq, dq=self.dqk, dk=self.dqk.data_ptr() + 2 * hd,
+                      dgate=dqkvg.data_ptr() + 2 * 3 * hd, ld_dgate=ldq, dq=self.dqk if self.dqk is not None else 0,
+                      dk=self.dqk.data_ptr() + 2 * hd if self.dqk is not None else 0,
                       dv=dqkvg.data_ptr() + 2 * 2 * hd, ld_dq=2 * hd, ld_dk=2 * hd, ld_dv=ldq)
         return kw
 
@@ -810,13 +802,9 @@ class Plan:
             ff_grp = [(d, di, dict(A=dy_f, lda=d, a_cols=d, B=self.hm[i], ldb=dip, b_cols=dip, C=gp(f'{p}.2.fn.net.3.weight'), ldc=di)),
                       (2 * dip, d, dict(algo_n=2 * di, A=dag, lda=2 * dip, a_cols=2 * dip, B=self.uf[i], ldb=d, b_cols=d, rowmap=gmap,
                                         C=gp(f'{p}.2.fn.net.0.weight'), ldc=d, colsum=gp(f'{p}.2.fn.net.0.bias')))]
-            # TFX_TN_LAYER_GROUP=1: these two wait for the attention wrapper's products and the whole layer goes out as ONE launch of up to 6 products (only with
-            # the side stream's separate dy_f / dy_a parity buffers: without it the attention backward overwrites dy_f first).  Measured: weight-gradient family
-            # 4.21 -> 3.97 ms bracketed, but the overlapped step 25.05 / 25.16 -> 25.32 / 25.09 ms (gpurun_out/ow38_step.txt): one big launch late in the layer
-            # overlaps less with the main stream than two - off
-            layer_group = side and os.environ.get('TFX_TN_LAYER_GROUP', '0') == '1' and os.environ.get('TFX_TN_GROUP', '1') != '0'
-            if not layer_group:
-                self._tn_group(L, T, ff_grp, side=side)
+            # (one launch per LAYER - these two waiting for the attention wrapper's products - measured 4.21 -> 3.97 ms on the family and nothing on the overlapped
+            #  step, profiles/r05b_ab_tn_layer_group.txt: removed in round 6)
+            self._tn_group(L, T, ff_grp, side=side)
             self._nt(L, algo_k=2 * di, A=dag, lda=2 * dip, B=S[f'ff1_t{i}'], ldb=2 * dip, M=T, N=d, K=2 * dip, epi=E['TFX_EPI_BF16'], C=self.du, ldc=d)
             a_pref = capi.make_args('tfx_adaln_pre_args', T=T, d=d, x=self.xb[i], tok_inst=self.tok_inst, table=tf, ld_table=nt3,
                                     gamma_text=pp(f'{p}.2.layernorm_gamma'), mean=_p(self.stats, 2, i), rstd=_p(self.stats, 3, i), du=self.du, dx=G,
@@ -826,14 +814,10 @@ class Plan:
                                      layerscale=pp(f'{p}.1.layerscale'), g=G, dy=dy_a, dtable=dta, dlayerscale=gp(f'{p}.1.layerscale'),
                                      seg_start=self.seg_start, seg_len=self.seg_len, n_seg=0)
             self._seg_args += [a_pref, a_posta]
-            if os.environ.get('TFX_BWD_FUSED', '1') != '0':
-                # input side of the feed-forward wrapper + output side of the attention wrapper: the residual-gradient row is written once, not read back
-                self._keep = getattr(self, '_keep', []) + [a_pref, a_posta]
-                self._raw(L, lib.tfx_adaln_pre_post_bwd, ctypes.addressof(a_pref), ctypes.addressof(a_posta))
-                self._hbm(L, 6)                                         # du, x in, residual gradient in / out, y in, dy out
-            else:
-                L.append(('tfx_adaln_pre_bwd', a_pref))
-                L.append(('tfx_adaln_post_bwd', a_posta))
+            # input side of the feed-forward wrapper + output side of the attention wrapper: the residual-gradient row is written once, not read back
+            self._keep = getattr(self, '_keep', []) + [a_pref, a_posta]
+            self._raw(L, lib.tfx_adaln_pre_post_bwd, ctypes.addressof(a_pref), ctypes.addressof(a_posta))
+            self._hbm(L, 6)                                             # du, x in, residual gradient in / out, y in, dy out
             self._nt(L, algo_n=md.hd, A=dy_a, lda=d, B=S[f'out_t{i}'], ldb=d, M=T, N=hd, K=d, epi=E['TFX_EPI_BF16'], C=self.dog, ldc=hd)
             gam = (lambda nm: S[f'g{nm}{i}']) if md.dim_head != 64 else (lambda nm: pp(f'{p}.1.fn.{nm}_norm.gamma'))
             if os.environ.get('TFX_ATTN_QKNR', '1') != '0':
@@ -841,11 +825,9 @@ class Plan:
                 # written out and read back, and the token-wise launch below drops out of the layer
                 self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True), nr_qkv=self.qkvg[i], nr_ld_qkv=ldq, nr_dqkv=dqkvg, nr_ld_dqkv=ldq,
                         nr_gamma_q=gam('q'), nr_gamma_k=gam('k'), nr_rot_pos=self.rot_pos, nr_cos=0, nr_sin=0, nr_q_scale=md.dim_head ** -0.5,
-                        nr_norm_scale=md.dim_head ** 0.5, nr_dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), nr_dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'),
-                        nr_scratch=self._nr_scratch() if os.environ.get('TFX_ATTN_QKNR') == '2' else None)
-                # (TFX_ATTN_QKNR=2: per-block partial rows + a reduction launch instead of 64 same-address atomics per block - measured SLOWER, attention
-                # backward 4.19 vs 4.05 ms per step: the atomics were not what the fused epilogue costs, its ~400 vector instructions per wave in two
-                # VALU-bound kernels are)
+                        nr_norm_scale=md.dim_head ** 0.5, nr_dgamma_q=gp(f'{p}.1.fn.q_norm.gamma'), nr_dgamma_k=gp(f'{p}.1.fn.k_norm.gamma'))
+                # (per-block partial rows + a reduction launch instead of the 64 same-address atomics per block measured SLOWER in round 5 - 4.19 vs 4.05 ms -
+                # and were removed in round 6)
                 self._rope_attn_args = getattr(self, '_rope_attn_args', []) + [L[-1][1]]
             else:
                 self._k(L, 'tfx_attn_bwd', 'tfx_attn_args', **self._attn_kw(i, bwd=True))
@@ -871,17 +853,10 @@ class Plan:
                                     rowmap=ps._maps['heads'] if md.dim_head != 64 else None))]
             if md.has_skip(i):
                 sk = self.xres[src[i]]
-                # d W_skip [d, 2 d] = G^T [x | skip].  TFX_SKIP_TN_SPLIT=1: ONE product with a split B (tfx.h B2 / K1).  Built, tested - and measured neutral as
-                # its own launch (117.6 us against 2 x 64 us; gpurun_out/ow26_step.txt, ow27_*): off; inside the layer's group the two products are two members
-                if os.environ.get('TFX_SKIP_TN_SPLIT', '0') == '1':
-                    grp.append((d, 2 * d, dict(A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, B2=sk, ldb2=d, K1=d, C=gp(f'{p}.0.weight'), ldc=2 * d)))
-                else:
-                    grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)))
-                    grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)))
-            if layer_group and len(ff_grp) + len(grp) <= 6:
-                grp = ff_grp + grp
-            elif layer_group:
-                self._tn_group(L, T, ff_grp, side=side)
+                # d W_skip [d, 2 d] = G^T [x | skip]: two members of the layer's group (as ONE split-B product it measured 117.6 us against 2 x 64 us,
+                # profiles/r05b_ab_skip_tn_split.txt: the split-B form was removed in round 6)
+                grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=x_in, ldb=d, b_cols=d, C=gp(f'{p}.0.weight'), ldc=2 * d)))
+                grp.append((d, d, dict(A=G, lda=d, a_cols=d, B=sk, ldb=d, b_cols=d, C=gp(f'{p}.0.weight', d), ldc=2 * d)))
             self._tn_group(L, T, grp, side=side)
             per = -(-D // self.dp_groups) if self.dp_groups > 0 else D
             if I > 0 and i % per == 0:

@@ -344,7 +344,7 @@ class Sampler:
         # once per plan, a token's instance index says which row it reads, and the conditioning launches drop out of the per-step replay.
         cond_times = torch.tensor([e[0] for e in evals] + [1.], dtype=torch.float32, device=dev)
         n_t = cond_times.numel()
-        tm = {'steps': 0, 'mixed_steps': 0, 'prefill': 0., 'loop': 0., 'host_build': 0., 'host_issue': 0., 'wait': 0., 'host_post': 0.} if os.environ.get('TFX_SAMPLE_TIMING') else None
+        tm = None                                       # (host-side phase timing dict for debugging: set to {'steps': 0, 'mixed_steps': 0, 'prefill': 0., 'loop': 0., 'host_build': 0., 'host_issue': 0., 'wait': 0., 'host_post': 0.})
         t_a = time.perf_counter()
         if use_cfg:
             # null-text twin of the prefill: every token that went through the model so far (the sampled-but-unfed last token excluded)
@@ -592,7 +592,7 @@ class Sampler:
         m, md, dev = self.m, self.md, self.dev
         B = len(states)
         cache = joint[:, :B]
-        tm = {'text': 0., 'text_steps': 0, 'uncond_prefill': 0., 'ode': 0., 'phases': 0} if os.environ.get('TFX_SAMPLE_TIMING') else None
+        tm = None                                       # (host-side phase timing dict for debugging: set to {'text': 0., 'text_steps': 0, 'uncond_prefill': 0., 'ode': 0., 'phases': 0})
         def mark():
             if tm is None:
                 return 0.

@@ -120,7 +120,7 @@ def _bucket(x: int, min_step: int) -> int:
     return -(-x // step) * step
 
 
-_TRAIN_PAD = max(1, int(os.environ.get('TFX_TRAIN_PAD', '64')))
+_TRAIN_PAD = 64
 
 
 class ModalityInfo(NamedTuple):              # T:112-126
@@ -546,6 +546,11 @@ class Transfusion(nn.Module):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def release_decode_cache(self):
+        """drop the KV cache + decode plans `sample_many` keeps between calls (sampling.py; up to TFX_DECODE_KEEP_GB).  `train()` does it too; an EMA / eval model
+        sampled now and then inside a training process never switches modes - call this after sampling to get the memory back."""
+        self._decode_keep = None
+
     def train(self, mode: bool = True):
         """nn.Module.train; switching INTO training drops the decode cache + plans `sample_many` keeps between calls (sampling.py: up to
         TFX_DECODE_KEEP_GB of KV cache stays allocated for a serving process; a training process gets the memory back)"""
@@ -612,7 +617,7 @@ class Transfusion(nn.Module):
                 P.row_pos[t] = ((rp // old) * n_new + (rp % old)).astype(np.int32)
             P.n_full = n_new
         tm = token_maps(P, n, self.num_modalities)
-        seg_start, seg_len = token_segments(tm.tok_inst, balance=os.environ.get('TFX_SEG_BALANCE', '1') != '0')
+        seg_start, seg_len = token_segments(tm.tok_inst, balance=True)
         # every index array of the structure goes up in ONE pinned, asynchronous copy (an int32 arena; the device tensors below are views of it): a
         # structure miss used to issue ~16 pageable host-to-device copies, each a blocking round trip of the host (0.55 ms apiece under load)
         R = {t: int(len(v)) for t, v in P.row_inst.items()}
@@ -792,7 +797,7 @@ class Transfusion(nn.Module):
         if S is None:
             while len(self._struct_cache) >= 32:                      # least recently used structure goes first (dict order = use order)
                 self._struct_cache.pop(next(iter(self._struct_cache)))
-            # training lengths are bucketed to multiples of 64 (TFX_TRAIN_PAD; 1 = exact): ragged data then shares a handful of plans - a plan
+            # training lengths are bucketed to multiples of 64 (_TRAIN_PAD): ragged data then shares a handful of plans - a plan
             # owns every activation of the step and its launch lists, building one costs far more than the padding columns
             S = self._build_structure(modalities, return_loss, add_meta=add_meta, pad_n=_TRAIN_PAD if return_loss else 1, presig=(sig, user_text, latents))
         self._struct_cache[skey] = S
@@ -1049,8 +1054,9 @@ class Transfusion(nn.Module):
                     #  the closure divides (embed - tokens) by max(1 - t, eps): without the caller's times it would silently run at t = 1,
                     # i.e. multiply by 1 / eps - the un-cached forward always has times here (drawn like the reference's, T:3075-3082); a cached
                     # text step that asks for clean flows of its prefix must pass them
-                    assert times is not None and times.ndim == 2 and times.shape[1] > 0, \
-                        '`model_output_clean` with `return_embed`: pass `times` (one column per modality instance) - the clean-to-flow closures need each instance\'s time'
+                    if times is None or times.ndim != 2 or times.shape[1] == 0:       # (a ValueError, not an assert: `python -O` strips asserts)
+                        raise ValueError('`model_output_clean` with `return_embed`: pass `times` (one column per modality instance) - the clean-to-flow closures '
+                                         'need each instance\'s time')
                     tt = times[bi, min(m, times.shape[1] - 1)]
                     out.append((int(part[0]), part[1], tt.to(self.device, torch.float32)))
                     m += 1
@@ -1229,7 +1235,7 @@ class Transfusion(nn.Module):
         if S is None:
             ar = torch.arange(n, dtype=torch.int32)
             tok_inst = np.full((b, n), -1, dtype=np.int32)
-            seg_start, seg_len = token_segments(tok_inst, balance=os.environ.get('TFX_SEG_BALANCE', '1') != '0')
+            seg_start, seg_len = token_segments(tok_inst, balance=True)
             D = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev)
             S = self._struct_cache[key] = dict(tok_inst=D(tok_inst.reshape(-1)), kv_end=D((ar + 1).repeat(b)), q_start=D(ar.repeat(b)),
                                                rot_pos=D(ar.repeat(b)), seg_start=D(seg_start), seg_len=D(seg_len))
