@@ -28,7 +28,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
-MEASURED_PEAK_TFLOPS = 1725.0      # what a register-resident MFMA loop sustains on THIS pool's boxes with random operands (power-limited clock)
+
+
+def measure_mfma_peak(dev):
+    """`roofline.measured_peak`: what a register-resident MFMA loop (no memory traffic, random bf16 operands, two blocks per CU) sustains on THIS box, measured in the
+    run behind the timed region (tfx_mfma_peak_probe; ~3 ms): the chip is power-limited - 1.66-1.86 PFLOP/s by box against the 2.5 PFLOP/s the peak is quoted at,
+    and less again for kernels that keep the vector units busy next to the matrix pipe (profiles/r02_power_clock.txt, profiles/r06_attn_bwd_what_bounds_it.txt)."""
+    from transfusion_pytorch_amd import capi
+    ops = (torch.rand(128, 8, device=dev) * 2 - 1).to(torch.bfloat16)
+    out = torch.zeros(2, device=dev)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    blocks, iters = 2 * cus, 6000
+    st = torch.cuda.current_stream(dev).cuda_stream
+    capi.check(capi.lib().tfx_mfma_peak_probe(ops.data_ptr(), out.data_ptr(), iters // 10, blocks, st), 'tfx_mfma_peak_probe')
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    capi.check(capi.lib().tfx_mfma_peak_probe(ops.data_ptr(), out.data_ptr(), iters, blocks, st), 'tfx_mfma_peak_probe')
+    e1.record(); e1.synchronize()
+    return 2.0 * 32 * 32 * 16 * 4 * iters * blocks * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
 def canonical_batch(b, device, gen, num_text_tokens=256, dim_latent=384, n_inst=32, latent_len=4, text_len=24, last_text_len=23):
@@ -318,6 +335,20 @@ def make_optimizer(model, use_pg):
     return opt, overlap
 
 
+def exchange_prediction(numel, world):
+    """what the per-step gradient exchange moves and how long it should take, so that the first real N > 1 run can be read against a number.
+    Model: all-reduce of S bytes on the node's full xGMI mesh = reduce-scatter + all-gather, each sending S / N to every peer over its own link at once:
+    t = 2 S / (N x link) ; link = 76.5 GB/s (one direction of a 153 GB/s link, the cautious figure) ... 153 GB/s.  With TFX_DP_OVERLAP (default) four fifths of it
+    run under the backward; TFX_DP_BF16=1 halves S."""
+    if world <= 1:
+        return None
+    bf16 = os.environ.get('TFX_DP_BF16') == '1'
+    S = numel * (2 if bf16 else 4)
+    t = lambda link: 2.0 * S / (world * link * 1e9) * 1e3
+    return {'bytes_per_step': S, 'wire_dtype': 'bf16' if bf16 else 'fp32', 'predicted_ms_full_mesh': [round(t(153.0), 3), round(t(76.5), 3)],
+            'model': 't = 2 S / (N x link), link = 153 ... 76.5 GB/s per direction; reduce-scatter + all-gather, every peer over its own xGMI link'}
+
+
 def gather_ranks(elapsed, my_elapsed, exchange_ms, steps, world, use_pg, dev):
     """max-over-ranks wall time (the contract's `value` clock) + every rank's own clock and exposed exchange time"""
     import torch.distributed as dist
@@ -381,7 +412,8 @@ def dry_run(args, world, rank, json_fd):
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                'dry_run': True, 'exchange_ok': ok, 'collective_launches_per_step': opt.reducer.last_launches if overlap else 1,
                'config': {'workload': workload_label(args.dim, args.depth, args.batch, world, use_pg, overlap, args.two), 'global_batch': world * args.batch,
-                          'seq_len': 1024, 'parallelism': f'dp{world}'}, 'per_rank_ms_per_step': per_rank}
+                          'seq_len': 1024, 'parallelism': f'dp{world}'}, 'per_rank_ms_per_step': per_rank,
+               'grad_exchange': exchange_prediction(ps.numel, world), 'bwd_cut_groups': len(plan.bwd_cuts)}
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if use_pg:
         dist.destroy_process_group()
@@ -706,6 +738,7 @@ def main():
                 if tr.get('kernel_family') == args.roofline_kernel:
                     traffic, traffic_src = tr['bytes_per_launch'], tr['source']
                     break
+        measured_peak = measure_mfma_peak(dev)
         out = {
             'metric': f'train samples/sec, dim{args.dim} d{args.depth} seq1024 text+latent', 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
@@ -721,13 +754,14 @@ def main():
             'ragged_ms_per_step': ragged_ms,                    # every batch a never-seen structure, steps back to back (rank 0)
             'per_rank_ms_per_step': per_rank,                   # each rank's own clock over the timed steps (before the closing barrier)
             'grad_exchange_exposed_ms': exchange_ms,            # max over ranks: compute-stream time per step inside the exchange section (tail collective + waits)
+            'grad_exchange': exchange_prediction(model.store.numel, world),       # N > 1: bytes on the wire per step and the predicted xGMI time (null at N = 1)
             'fresh_batch_every_step': True,
             'roofline': {'bound': 'mfma', 'kernel': args.roofline_kernel, 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src, 'launches_per_step': n_launch / max(n_sampled, 1), 'sampled_steps': n_sampled,
                          'note': 'bracketed on every --roofline-every-th timed step; those steps replay on one stream (no side-stream overlap) so the durations are the kernels own',
                          'avg_launch_us': kt / max(n_launch, 1) * 1e6, 'algorithmic_gflop_per_step': kf / max(n_sampled, 1) / 1e9,
-                         'measured_peak': MEASURED_PEAK_TFLOPS, 'measured_peak_frac': achieved / MEASURED_PEAK_TFLOPS,
-                         'measured_peak_source': 'profiles/r02_power_clock.txt (tools/mfma_peak.hip: register-resident MFMA loop, uniform random operands, 1.66-1.77 GHz sustained)'},
+                         'measured_peak': measured_peak, 'measured_peak_frac': achieved / measured_peak,
+                         'measured_peak_source': 'this run, behind the timed region: tfx_mfma_peak_probe - register-resident v_mfma_f32_32x32x16_bf16 loop, random operands, two blocks per CU (the power-limited clock of this box)'},
         }
         if by_family is not None:
             out['roofline_by_family'] = by_family

@@ -76,9 +76,15 @@ typedef struct {
 } tfx_gemm_nt_args;
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
 /* which kernel tfx_gemm_nt would launch for these arguments and on how many blocks, without launching (host logic only, no device needed):
- * 0 register-staged fallback, 1 LDS-DMA 128 x 128, 2 "mid" (<= one 128 x 128 tile per CU), 3 ping-pong 256 x 256, 4 skinny (M <= 512 ... 1024),
- * 5 decode (M <= 1024, K split across the waves). */
+ * 0 register-staged fallback, 1 LDS-DMA 128 x 128, 2 "mid" (<= one 128 x 128 tile per CU), 3 ping-pong 256 x 256 (8 waves: the fused epilogues, row-gathered /
+ * split A), 4 skinny (M <= 512 ... 1024), 5 decode (M <= 1024, K split across the waves), 6 one wave per SIMD 256 x 256, one tile per block (fp32 outputs from
+ * K = 1024, bf16 outputs with K < 192), 7 one wave per SIMD, persistent (bf16 outputs, K >= 192).  Kinds 6 / 7 since round 6 (they reported 3 before). */
 int tfx_gemm_nt_plan(const tfx_gemm_nt_args* a, int32_t* kind, int32_t* grid);
+
+/* Measurement aid (bench.py `roofline.measured_peak`; no reference counterpart): a register-resident loop of `iters` x 4 v_mfma_f32_32x32x16_bf16 per wave on
+ * `blocks` blocks of 4 waves, operands = the 128 x 16 bytes at `ops` (lane-indexed; random bf16 for the power the data toggles cost, zeros read ~20 % higher),
+ * no memory traffic inside the loop.  flops = 2 x 32 x 32 x 16 x 4 x iters x blocks x 4; the caller times the launch.  `out`: 2 floats of scratch. */
+int tfx_mfma_peak_probe(const void* ops, float* out, int32_t iters, int32_t blocks, void* stream);
 
 /* C[rowmap[n]][k] += alpha * sum_m A[m][n] * B[m][k]   (fp32 C, ALWAYS accumulates: split-M partial sums are
  * added with fp32 atomics, the caller zeroes C when it wants a plain product; `accumulate` is ignored).

@@ -373,3 +373,34 @@ def test_bench_two_rank_host_path_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
     assert d['n_gpus'] == 2 and d['exchange_ok'] and 'dim_latent=(384,192)' in d['config']['workload'] and 'dim=768' in d['config']['workload']
+
+
+def test_bench_eight_rank_self_launch_dry_run_at_the_depth_of_config_3():
+    """VERDICT r5 item 9 (multi-GPU pre-flight, no hardware): the PLAIN `python bench.py --gpus 8 --config 3 --dry-run` - bench.py starts its eight ranks itself -
+    with the depth-24 training plan's cut list driving the overlapped exchange on every rank (the model dimension is reduced to keep eight replicas inside this
+    container's memory: the plan's structure - 24 layers, 4 layer groups + tail - is config 3's), and `--gpus 4 --config 4` (two modality types).  One JSON line
+    from rank 0 with all per-rank clocks, the exchange sum verified on every element, and the bytes / predicted xGMI time of the per-step exchange."""
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    for gpus, cfg, dim, frag in ((8, 3, 128, 'depth=24'), (4, 4, 192, 'dim_latent=(384,192)')):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--config', str(cfg), '--dim', str(dim), '--steps', '2', '--warmup', '1',
+                            '--dry-run'], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == gpus and d['dry_run'] and d['exchange_ok'] and d['value'] is None
+        assert len(d['per_rank_ms_per_step']) == gpus and d['config']['parallelism'] == f'dp{gpus}' and d['config']['global_batch'] == 64 * gpus
+        assert frag in d['config']['workload'], d['config']['workload']
+        assert d['collective_launches_per_step'] == 10 and d['bwd_cut_groups'] == 4           # 4 layer groups + tail, two contiguous ranges each
+        ge = d['grad_exchange']
+        assert ge['wire_dtype'] == 'fp32' and ge['bytes_per_step'] % 4 == 0 and 0 < ge['predicted_ms_full_mesh'][0] < ge['predicted_ms_full_mesh'][1]
+    # at the real dimensions: config 3 exchanges ~3.5 GB of fp32 per step, config 2 ~0.32 GB (pure host arithmetic)
+    sys.path.insert(0, ROOT)
+    import bench
+    p3 = bench.exchange_prediction(874_000_000, 8)
+    assert 3.4e9 < p3['bytes_per_step'] < 3.6e9 and 5.0 < p3['predicted_ms_full_mesh'][0] < p3['predicted_ms_full_mesh'][1] < 13.0
+    assert bench.exchange_prediction(79_545_968, 1) is None

@@ -299,5 +299,36 @@ def test_sample_many_keeps_its_decode_plans_between_calls():
         del os.environ['TFX_DECODE_KEEP']
     same(changed, changed_cold)
     same(first, again)
+    # weights rewritten by RAW KERNELS: the fused EMA update / the fused Adam step / mark_weights_changed() bump no autograd version counter -
+    # the store's weights epoch must move the key, or the kept plans' AdaLN tables and bf16 shadows of the OLD weights serve the new ones
+    warm = m.sample_many(ps, **kw)                                  # (the cold call above dropped the keep: build one on the sign-flipped model)
+    same(warm, changed)
+    kept3 = m._decode_keep
+    assert kept3 is not None
+    with torch.no_grad():
+        m.to_text_logits.weight.data.mul_(-1.)                        # in place through .data: no version counter moves, nothing can see it
+    m.mark_weights_changed()
+    raw = m.sample_many(ps, **kw)
+    assert m._decode_keep['joint'] is not kept3['joint'], 'mark_weights_changed() must invalidate the kept decode plans'
+    same(raw, first)                                                  # (the sign flipped twice: the first model again)
+    from transfusion_pytorch_amd.ema import EMA
+    ema = EMA(m, beta=0.5, update_after_step=0, update_every=1)
+    ema.update(); ema.update()                                       # copy, then a real tfx_ema_update
+    ema.ema_model.eval()                                             # (a model in training mode drops its keep when sample_many restores the mode)
+    e1 = ema.ema_model.sample_many(ps, **kw)
+    kept4 = ema.ema_model._decode_keep
+    with torch.no_grad():
+        m.to_text_logits.weight.mul_(-3.)
+    ema.update()                                                     # raw kernel write into the EMA model's flat buffer
+    e2 = ema.ema_model.sample_many(ps, **kw)
+    assert ema.ema_model._decode_keep['joint'] is not kept4['joint'], 'an EMA update must invalidate the EMA model\'s kept decode plans'
+    os.environ['TFX_DECODE_KEEP'] = '0'
+    try:
+        e2_cold = ema.ema_model.sample_many(ps, **kw)
+    finally:
+        del os.environ['TFX_DECODE_KEEP']
+    same(e2, e2_cold)
+    ema.ema_model.release_decode_cache()
+    assert ema.ema_model._decode_keep is None
     m.train()
     assert m._decode_keep is None

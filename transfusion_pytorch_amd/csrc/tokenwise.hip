@@ -2077,6 +2077,22 @@ template <int NC, int NJ> static int pull_dma(const tfx_attnres_pull_args& a, co
 #undef TFX_PULL_GO
 }
 
+// register-resident MFMA loop (tfx.h tfx_mfma_peak_probe; tools/mfma_peak.hip is the stand-alone form with the mixed MFMA + VALU variants)
+__global__ __launch_bounds__(256) void mfma_peak_k(const bf16x8* ops, float* out, int iters) {
+  bf16x8 a = ops[threadIdx.x & 63], b = ops[64 + (threadIdx.x & 63)];
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < iters; i++) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c2) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c3) : "v"(a), "v"(b));
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+  float sm = 0.f;
+  for (int i = 0; i < 16; i++) sm += c0[i] + c1[i] + c2[i] + c3[i];
+  if (sm == 1.2345f) out[1] = sm;
+}
+
 extern "C" {
 
 int tfx_adaln_pre_fwd(const tfx_adaln_pre_args* a, void* s) { DISPATCH_NC(a->d, hipLaunchKernelGGL(adaln_pre_fwd_k<NC>, dim3(grid_tokens(a->T)), dim3(256), 0, ST(s), *a)); RET(); }
@@ -2273,6 +2289,10 @@ int tfx_gemm_nt_plan(const tfx_gemm_nt_args* a, int32_t* kind, int32_t* grid) { 
 int tfx_gemm_tn_plan(const tfx_gemm_tn_args* a, int32_t* kind, int32_t* tiles, int32_t* splits, int32_t* grid) { return gemm_tn_plan(*a, kind, tiles, splits, grid); }
 int tfx_attn_fwd(const tfx_attn_args* a, void* s) { return attn_fwd(*a, ST(s)); }
 int tfx_attn_bwd(const tfx_attn_args* a, void* s) { return attn_bwd(*a, ST(s)); }
+int tfx_mfma_peak_probe(const void* ops, float* out, int32_t iters, int32_t blocks, void* s) {
+  if (!ops || !out || iters <= 0 || blocks <= 0) return -1;
+  hipLaunchKernelGGL(mfma_peak_k, dim3(blocks), dim3(256), 0, ST(s), (const bf16x8*)ops, out, iters); RET();
+}
 const char* tfx_version(void) { return "tfx-hip gfx950 r1"; }
 
 }  // extern "C"
