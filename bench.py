@@ -731,7 +731,7 @@ def main():
         # profiles/ (tools/pmc_traffic.sh; FETCH_SIZE x2 gfx950 correction applied there) - counters cannot be read in-process
         traffic, traffic_src = None, None
         pdir = os.path.join(ROOT, 'profiles')
-        for tname in ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json'):
+        for tname in ('r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json'):
             tj = os.path.join(pdir, tname)
             if os.path.exists(tj) and (args.batch, args.dim, args.depth, args.two) == (64, 512, 8, False):
                 tr = json.load(open(tj))
@@ -769,7 +769,7 @@ def main():
             out['step_kernel_time'] = step_gpu_ms
         # parity: the suite-wide figures (every golden case, measured by tests/test_model_gpu.py on MI355X and committed under profiles/) are QUOTED;
         # `bench_shape` is MEASURED by this process on the bench geometry against the reference's golden (parity_in_run)
-        for pname in ('r05_parity.json', 'r04_parity.json'):
+        for pname in ('r06_parity.json', 'r05_parity.json', 'r04_parity.json'):
             pj = os.path.join(pdir, pname)
             if os.path.exists(pj):
                 out['parity_met'] = json.load(open(pj))

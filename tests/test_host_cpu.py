@@ -416,7 +416,7 @@ def test_nt_gemm_kernel_selection():
 def test_generated_attention_loops_match_their_generator(tmp_path):
     """round 6: the tile loops of the attention kernels that run as generated asm (tools/gen_attn_loops.py: forward unmasked tiles, backward dQ whole loop; soft-cap
     plan modes 0 / 1) are committed under csrc/.  They must be what the generator writes today; MFMA counts per file (forward: 6 tiles x 16 with the fill and the
-    first unit's missing P.V; dQ: 8 tiles x 24 + fill 8 + drain 4 - 4); the LDS wait tracker never asks for more than the 4-bit counter holds; every fixed register
+    first unit's missing P.V; dQ: 8 tiles x 24 + fill 8 + drain 4 - 4, + 4 in each of 15 phases for the dQ a stopping wave still owes); the LDS wait tracker never asks for more than the 4-bit counter holds; every fixed register
     the loops name is in the clobber list the kernels hand to hipcc."""
     import re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -431,7 +431,7 @@ def test_generated_attention_loops_match_their_generator(tmp_path):
         if name == 'attn_asm_clobbers.inc':
             continue
         lines = [ln.strip().strip('"').replace('\\n\\t', '') for ln in old.splitlines() if ln.startswith('"')]
-        assert sum(ln.startswith('v_mfma') for ln in lines) == (200 if '_dq_' in name else 96), name
+        assert sum(ln.startswith('v_mfma') for ln in lines) == (260 if '_dq_' in name else 96), name     # dQ: + 4 per phase for a wave's first dead phase
         assert all(int(m) <= 15 for ln in lines for m in re.findall(r'lgkmcnt\((\d+)\)', ln)), name
         assert sum(ln == 's_barrier' for ln in lines) == (8 if '_dq_' in name else 6), name      # one barrier per tile, in every copy of the unrolled ring
         if '_dq_' in name:                                                                       # (the forward's fixed registers are bound / clobbered by hand in attention.hip)

@@ -176,6 +176,7 @@ static int cmp_main(int argc, char** argv) {
           for (int k = 0; k < ncol; k++) printf(" %.3f", bf2f(b[r0 + k])); printf("\n");
         }
       }
+    }
     printf("%-10s out: %zu of %zu elements differ (max abs %.3g", c.name, diff, nout, mx);
     if (diff) printf(", first at token %zu head %zu col %zu", first / ((size_t)c.h * 64), (first / 64) % c.h, first % 64);
     printf(") ; lse / gradients: %zu of %zu bytes differ\n", rdiff, rest);

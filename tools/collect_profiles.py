@@ -1,6 +1,6 @@
-"""copy the round-5 evidence of one `tools/gpu_r5e.sh` round trip from gpurun_out/ (scratch) into profiles/ (tracked) and derive the two small JSON files
+"""(rounds 5 and 6; `python tools/collect_profiles.py r06` after tools/gpu_r6.sh) copy the evidence of one `tools/gpu_r5e.sh` round trip from gpurun_out/ (scratch) into profiles/ (tracked) and derive the two small JSON files
 bench.py quotes: r05_traffic.json (HBM bytes per launch of the NT GEMM family from the FETCH_SIZE / WRITE_SIZE passes) and r05_parity.json (the suite-wide
-parity figures the GPU tests measured).   python tools/collect_r05_profiles.py"""
+parity figures the GPU tests measured).   python tools/collect_profiles.py"""
 import json
 import os
 import re
@@ -9,11 +9,12 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, 'gpurun_out'), os.path.join(R, 'profiles')
-# python tools/collect_r05_profiles.py            -> the first session's trip (gpurun_out/*r05e* -> profiles/r05_*)
-# python tools/collect_r05_profiles.py r05f       -> the second session's trip (tools/gpu_r5f.sh; gpurun_out/*r05f* -> profiles/r05f_*; r05_traffic.json / r05_parity.json,
+# python tools/collect_profiles.py            -> the first session's trip (gpurun_out/*r05e* -> profiles/r05_*)
+# python tools/collect_profiles.py r05f       -> the second session's trip (tools/gpu_r5f.sh; gpurun_out/*r05f* -> profiles/r05f_*; r05_traffic.json / r05_parity.json,
 #                                                    which bench.py quotes, are rewritten from it)
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r05e'
 PRE = 'r05' if TAG == 'r05e' else TAG
+RND = PRE[:3]                                       # r05 / r06: the small JSON files bench.py quotes are named by round
 COPY_ = {
     'ev_r05e_bench_line.json': 'r05_bench_line.json', 'ev_r05e_cfg2_kernel_summary.txt': 'r05_cfg2_kernel_summary.txt', 'ev_r05e_cfg2_gaps.txt': 'r05_cfg2_gaps.txt',
     'ev_r05e_cfg3_kernel_summary.txt': 'r05_cfg3_kernel_summary.txt', 'ev_r05e_cfg3_gaps.txt': 'r05_cfg3_gaps.txt',
@@ -23,6 +24,9 @@ COPY_ = {
     'r05e_ab_qknr.txt': 'r05_ab_qknr.txt', 'r05e_parity_measured.json': 'r05_parity_measured.json',
 }
 COPY = {k.replace('r05e', TAG): v.replace('r05_', PRE + '_', 1) for k, v in COPY_.items()}
+if TAG.startswith('r06'):
+    COPY.update({f'{TAG}_attn_probe.txt': f'{TAG}_attn_probe.txt', f'{TAG}_attn_kernel_times.txt': f'{TAG}_attn_kernel_times.txt', f'{TAG}_ab_dq.txt': f'{TAG}_ab_dq.txt'})
+    COPY.pop(f'{TAG}_ab_qknr.txt', None)
 if TAG == 'r05f':
     COPY.update({'r05f_ab_ow.txt': 'r05f_ab_ow.txt', 'r05f_cfg_ab.txt': 'r05f_cfg_ab.txt', 'r05f_probe_cmp.txt': 'r05f_probe_cmp.txt', 'r05f_probe_pp.txt': 'r05f_probe_pp.txt',
                  'r05f_probe_ow.txt': 'r05f_probe_ow.txt', 'r05f_probe_steady.txt': 'r05f_probe_steady.txt'})
@@ -58,7 +62,7 @@ json.dump({'kernel_family': 'tfx_gemm_nt',
                      'structure-miss step = 3 steps; the file\'s per-step columns divide by 2)',
            'launches_per_step': calls, 'fetch_kb_raw_per_step': fetch_kb, 'write_kb_per_step': write_kb,
            'correction': 'FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for wide coalesced reads; MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated, taken as reported',
-           'bytes_per_launch': (2 * fetch_kb + write_kb) * 1024 / calls}, open(os.path.join(P, 'r05_traffic.json'), 'w'), indent=1)
+           'bytes_per_launch': (2 * fetch_kb + write_kb) * 1024 / calls}, open(os.path.join(P, RND + '_traffic.json'), 'w'), indent=1)
 
 # ---- suite-wide parity figures
 pm = json.load(open(os.path.join(P, PRE + '_parity_measured.json')))
@@ -72,6 +76,6 @@ out = {'north_star': 'outputs within 1e-3 bf16 tolerance, token argmax bit-exact
                   'unfiltered_agreement': {k: round(pm[k]['argmax_unfiltered'], 4) for k in cases if 'argmax_unfiltered' in pm[k]},
                   'note': 'flips only at near-ties of random-init logits (recorded margins < 0.05)'},
        'gradients': {'norm_weighted_mean_rel': {k: round(pm[k]['grad_mean_rel'], 5) for k in pm if 'grad_mean_rel' in pm[k]}},
-       'source': 'tests/test_model_gpu.py on MI355X (round 5, gpurun_out/parity_measured.json -> profiles/' + PRE + '_parity_measured.json); bench_shape is replaced by the in-run measurement'}
-json.dump(out, open(os.path.join(P, 'r05_parity.json'), 'w'), indent=1)
-print('ok', json.load(open(os.path.join(P, 'r05_traffic.json')))['bytes_per_launch'], out['loss'], len(cases), 'cases')
+       'source': 'tests/test_model_gpu.py on MI355X (round ' + RND[2] + ', gpurun_out/parity_measured.json -> profiles/' + PRE + '_parity_measured.json); bench_shape is replaced by the in-run measurement'}
+json.dump(out, open(os.path.join(P, RND + '_parity.json'), 'w'), indent=1)
+print('ok', json.load(open(os.path.join(P, RND + '_traffic.json')))['bytes_per_launch'], out['loss'], len(cases), 'cases')

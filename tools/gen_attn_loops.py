@@ -257,12 +257,27 @@ def dq_phase(e, mode, h, nxt, prv, tag, first=False):
     nxt = (kslot, vslot, kb) of the unit whose S / dP fragments are read here for the next phase ; prv = (kslot, kb) of the unit whose K^T fragments are read here."""
     s_cur, dp_cur, s_nxt, dp_nxt = (D_SA, D_DPA, D_SB, D_DPB) if h == 0 else (D_SB, D_DPB, D_SA, D_DPA)
     ds_cur, ds_prev = (D_DSA, D_DSB) if h == 0 else (D_DSB, D_DSA)
+    # ---- units past the wave's last visible key (u * 32 >= max kv_end of the wave) contribute exact zeros: the wave stops computing - it still runs the tile
+    #      tops (requests, barriers).  Its first dead phase owes the dQ of the unit before it (dS is packed, its K^T fragments are on their way); `live` then
+    #      drops and every later phase, and the drain, fall through.  (6 of the 72 (wave, unit) pairs of a 128-row block at n = 1024; the kernel is power-bound.)
+    e.op("s_cmp_eq_u32 %[live], 0")
+    e.op(f"s_cbranch_scc1 L_dq_end_{tag}_%=")
+    e.op("s_sub_u32 %[stmp], %[su1], 32")
+    e.op("s_cmp_ge_i32 %[stmp], %[kvemax]")
+    e.op(f"s_cbranch_scc0 L_dq_live_{tag}_%=")
+    e.op("s_mov_b32 %[live], 0")
+    if not first:
+        e.op("s_waitcnt lgkmcnt(0)")
+        for i in range(4):
+            tt, db = i >> 1, i & 1
+            e.op(f"v_mfma_f32_32x32x16_bf16 %[dq{db}], {vr(D_TF + 4 * i, 4)}, {vr(ds_prev + 4 * tt, 4)}, %[dq{db}]")
+    e.op(f"s_branch L_dq_end_{tag}_%=")
+    e.op(f"L_dq_live_{tag}_%=:")
     # ---- boundary units: wave-uniform test (u + 1) * 32 > min kv_end of the wave
     e.op("s_cmp_gt_i32 %[su1], %[kvemin]")
     e.op(f"s_cbranch_scc0 L_dq_nomask_{tag}_%=")
     dq_mask(e, s_cur, dp_cur)
     e.op(f"L_dq_nomask_{tag}_%=:")
-    e.op("s_add_u32 %[su1], %[su1], 32")
     sched = [["S0", "P0"], ["S1"], ["P1", "S2"], ["P2"], ["S3", "P3"], ["Q0"], ["Q1", "Q2"], ["Q3"]]
     valu = dq_valu(mode, s_cur, dp_cur, ds_cur)
     for c in range(8):
@@ -299,6 +314,8 @@ def dq_phase(e, mode, h, nxt, prv, tag, first=False):
             e.op(o)
             if pending and (n + 1) % k == 0: put()
         while pending: put()
+    e.op(f"L_dq_end_{tag}_%=:")
+    e.op("s_add_u32 %[su1], %[su1], 32")
 
 
 def dq_valu(mode, s_cur, dp_cur, ds_cur):
@@ -398,12 +415,16 @@ def program_dq(mode):
     assert e.lds_q == q_entry, (e.lds_q, q_entry)
     e.op("L_dq_exit_%=:")
     e.lds_q = list(q_entry)
-    # drain: dQ of the very last unit (DSB; its K^T fragments were read by the last phase)
+    # drain: dQ of the very last unit (DSB; its K^T fragments were read by the last phase) - unless the wave stopped early
+    e.op("s_cmp_eq_u32 %[live], 0")
+    e.op("s_cbranch_scc1 L_dq_nodrain_%=")
     for f in range(4):
         tt, db = f >> 1, f & 1
         e.need([f"T{f}"])
         e.op(f"v_mfma_f32_32x32x16_bf16 %[dq{db}], {vr(D_TF + 4 * f, 4)}, {vr(D_DSB + 4 * tt, 4)}, %[dq{db}]")
     e.drain()
+    e.op("L_dq_nodrain_%=:")
+    e.op("s_waitcnt lgkmcnt(0)")
     e.op("s_nop 15")
     e.op("s_nop 15")
     return e.lines

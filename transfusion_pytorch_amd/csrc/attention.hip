@@ -157,6 +157,11 @@ TFX_DEV int wave_min_i(int v) {                  // wave-uniform result, returne
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
   return __builtin_amdgcn_readfirstlane(v);
 }
+TFX_DEV int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
 // Number of keys a 128-row query tile has to walk.  Training layouts: kv_end is non-decreasing in the query index (prefix-extension mask), the
 // last row of the tile has the largest.  Decode steps against a KV cache: a sample's new rows need not be ordered by visible length (a text row
 // next to a modality block in the mixed steps of the continuous schedule) - take the true maximum over the tile's rows.
@@ -933,7 +938,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(tfx_attn_args 
       rsV[0] = __builtin_amdgcn_readfirstlane((uint32_t)baseV); rsV[1] = __builtin_amdgcn_readfirstlane((uint32_t)(baseV >> 32) & 0xffffu);
       rsV[2] = __builtin_amdgcn_readfirstlane((uint32_t)(n - 1) * (uint32_t)p.ld_v * 2u + 128u); rsV[3] = 0x00020000u;
       const uint32_t stk = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ld_k), stv = __builtin_amdgcn_readfirstlane(128u * (uint32_t)p.ld_v);
-      uint32_t sko = 2u * stk, svo = 2u * stv, cnt = (uint32_t)__builtin_amdgcn_readfirstlane(nt), su1 = 32u;
+      uint32_t sko = 2u * stk, svo = 2u * stv, cnt = (uint32_t)__builtin_amdgcn_readfirstlane(nt), su1 = 32u, live = 1u, stmp;
+      const int kve_max = wave_max_i(kve);                         // the wave's last visible key + 1: units from there on are skipped (generator: `live`)
       int rem2 = __builtin_amdgcn_readfirstlane(nt - 2);
       const uint32_t mk = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wu * 2048u);
       const int kmaskp = kve - 4 * hi + 32;
@@ -942,11 +948,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_pipe_kernel(tfx_attn_args 
       u32x4 d0f = __builtin_bit_cast(u32x4, dof[0]), d1f = __builtin_bit_cast(u32x4, dof[1]), d2f = __builtin_bit_cast(u32x4, dof[2]), d3f = __builtin_bit_cast(u32x4, dof[3]);
       // in-outs are EARLY-CLOBBER (see the forward's statement): sko / svo start out equal to multiples of the inputs stk / stv
 #define DQ_OPERANDS                                                                                                                                  \
-          : [dq0] "+&v"(dq[0]), [dq1] "+&v"(dq[1]), [sko] "+&s"(sko), [svo] "+&s"(svo), [cnt] "+&s"(cnt), [rem2] "+&s"(rem2), [su1] "+&s"(su1)            \
+          : [dq0] "+&v"(dq[0]), [dq1] "+&v"(dq[1]), [sko] "+&s"(sko), [svo] "+&s"(svo), [cnt] "+&s"(cnt), [rem2] "+&s"(rem2), [su1] "+&s"(su1),           \
+            [live] "+&s"(live), [stmp] "=&s"(stmp)                                                                                                   \
           : [qf0] "v"(q0f), [qf1] "v"(q1f), [qf2] "v"(q2f), [qf3] "v"(q3f), [df0] "v"(d0f), [df1] "v"(d1f), [df2] "v"(d2f), [df3] "v"(d3f),          \
             [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]), [ta0] "v"(ta[0]), [ta1] "v"(ta[1]), [tb0] "v"(tb[0]), [tb1] "v"(tb[1]), \
             [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]), [rsk] "s"(rsK), [rsv] "s"(rsV), [stk] "s"(stk), [stv] "s"(stv),  \
-            [mk] "s"(mk), [kvemin] "s"(kve_min), [p1] "v"(p1), [d1] "v"(d1), [p3] DQ_C3(p3), [d3] DQ_C3(d3), [p5] "s"(p5), [d5] "s"(d5),            \
+            [mk] "s"(mk), [kvemin] "s"(kve_min), [kvemax] "s"(kve_max), [p1] "v"(p1), [d1] "v"(d1), [p3] DQ_C3(p3), [d3] DQ_C3(d3), [p5] "s"(p5), [d5] "s"(d5),            \
             [lse2] "v"(lse2_), [dlt] "v"(dlt_), [kmaskp] "v"(kmaskp)                                                                                 \
           : "memory", "scc", "vcc", TFX_DQ_CLOBBERS
       if (sc_.mode == 0) {
@@ -1087,6 +1094,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(tfx_attn_args p) {
     if (jt + 1 < qt1) { tile_gload(qr, qb, p.ld_q, (jt + 1) * 64, n); tile_gload(dr, dob, p.ld_do, (jt + 1) * 64, n); stats_gload(jt + 1); }
 #pragma unroll
     for (int qb2 = 0; qb2 < 2; qb2++) {
+      // (round 6) a 32-query block none of whose rows sees any of this wave's 32 keys contributes exact zeros: skipped per wave (wave-uniform branch; kv_end is
+      // non-decreasing over a sample's real rows, rows past the end carry 0: the block's largest kv_end sits on its last real row).  The diagonal tiles of a
+      // 128-key block hold 6 such (wave, block) pairs of 16 - 8 % of the kernel's units at n = 1024, and the kernel is power-bound: work not done is time
+      {
+        const int lastr = min(31, n - 1 - (jt * 64 + qb2 * 32));
+        if (__builtin_amdgcn_readfirstlane((int)(lastr < 0 || s_kve[qb2 * 32 + max(lastr, 0)] <= k0 + w * 32)) != 0) continue;
+      }
       f32x16 s, dp;                                                // (no spare registers here for a shared zero accumulator)
 #pragma unroll
       for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
