@@ -73,6 +73,12 @@ typedef struct {
   float qk_q_scale, qk_norm_scale;
   float* qk_plan; float qk_softcap;
   tfx_bf16* qk_cache; int32_t qk_ld_cache; const int32_t* qk_cache_pos;
+  /* Cold-operand prefetch (round 6, decode plans): `prefetch_bytes` bytes at `prefetch` - the weights of the NEXT GEMM of a launch list - are touched by
+   * spare blocks of THIS launch (one load per 64 bytes, nothing written), so that they wait in the 256 MB Infinity Cache when their launch comes.  A decode
+   * forward streams 25 MB of weights per layer through launches of a few dozen blocks whose time is a chain of memory round trips (tools/decode_cold_probe.py:
+   * 10.1 us cold against 6.7 us warm for the out-projection at 64 rows).  Honoured by the small-M kernels (fewer than 512 tiles of 256 x 256), ignored when
+   * null / 0.  Results do not depend on it. */
+  const void* prefetch; int64_t prefetch_bytes;
 } tfx_gemm_nt_args;
 int tfx_gemm_nt(const tfx_gemm_nt_args* a, void* stream);
 /* which kernel tfx_gemm_nt would launch for these arguments and on how many blocks, without launching (host logic only, no device needed):

@@ -1015,9 +1015,35 @@ TFX_DEV void glds16(const bf16* g, bf16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
+// Cold-operand prefetch (tfx.h tfx_gemm_nt_args.prefetch): blocks [grid0, gridDim) of a launch touch the next GEMM's weights - one dword per 64 bytes,
+// 64 KiB per block, all of a thread's loads in flight at once - and leave: the lines then sit in the Infinity Cache (memory side: whichever XCD asks).
+// Measured and not kept (LAB_NOTEBOOK round 6): touching each B tile from the XCD that will read it (into that L2) - the prefetch blocks carry the launch's
+// LDS allocation, so a few of them with several tiles each stretch the launch; and a block touching its OWN panel ahead of its ring requests - the
+// requests queue behind the touches.
+constexpr int PF_BLOCK_BYTES = 64 * 1024;
+TFX_DEV bool prefetch_block(const GemmNT& p, int grid0) {
+  if ((int)blockIdx.x < grid0) return false;
+  const long long o0 = (long long)((int)blockIdx.x - grid0) * PF_BLOCK_BYTES + (long long)threadIdx.x * 64;
+  const char* base = (const char*)p.prefetch;
+  uint32_t acc = 0;                                                 // (compiler-visible loads: an asm load's late result would land in a register hipcc has reused)
+#pragma unroll
+  for (int k = 0; k < PF_BLOCK_BYTES / (256 * 64); k++) {
+    const long long o = o0 + (long long)k * 256 * 64;
+    if (o + 4 <= (long long)p.prefetch_bytes) acc ^= *(const uint32_t*)(base + o);
+  }
+  asm volatile("" ::"v"(acc));
+  return true;
+}
+static int prefetch_blocks(const GemmNT& p) {
+  if (!p.prefetch || p.prefetch_bytes <= 0) return 0;
+  const long long n = ((long long)p.prefetch_bytes + PF_BLOCK_BYTES - 1) / PF_BLOCK_BYTES;
+  return (int)(n < 512 ? n : 512);
+}
+
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p, int grid0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (prefetch_block(p, grid0)) return;                           // (block-uniform, before any barrier)
   bf16* As = (bf16*)smem_raw;                 // [2][128*64], row r chunk c' holds global chunk c' ^ ((r >> 1) & 7): conflict-free for the ds_read_b128 lane groups
   bf16* Bs = As + 2 * BM * BK;
 
@@ -1025,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(GemmNT p) {
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int ntn = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = xcd_remap(blockIdx.x, grid0);
   const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
   const int nk = p.K / BK;
 
@@ -1104,15 +1130,16 @@ constexpr int MD_ST = 4;
 constexpr int MD_STAGE = (BM + BN) * BK;                // elements per ring slot: A [128][64] then B [128][64]
 
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_nt_mid_kernel(GemmNT p) {
+__global__ __launch_bounds__(256, 1) void gemm_nt_mid_kernel(GemmNT p, int grid0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (prefetch_block(p, grid0)) return;                           // (block-uniform, before any barrier)
   bf16* ring = (bf16*)smem_raw;
 
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w >> 1, wn = w & 1;
   const int ntn = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = xcd_remap(blockIdx.x, grid0);
   const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
   const int nk = p.K / BK;
 
@@ -1193,8 +1220,9 @@ constexpr int SK_BM = 64, SK_BN = 128, SK_ST = 6;
 constexpr int SK_STAGE = (SK_BM + SK_BN) * BK;          // elements per ring slot: A [64][64] then B [128][64]
 
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_nt_skinny_kernel(GemmNT p) {
+__global__ __launch_bounds__(256, 1) void gemm_nt_skinny_kernel(GemmNT p, int grid0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (prefetch_block(p, grid0)) return;                           // (block-uniform, before any barrier)
   bf16* ring = (bf16*)smem_raw;
 
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
@@ -1278,8 +1306,9 @@ constexpr int SD_BK = 32, SD_ST = 4;
 constexpr int SD_SLOT = (64 + 64) * SD_BK;              // elements per ring slot: A [64][32] then B [64][32]
 
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_nt_decode_kernel(GemmNT p) {
+__global__ __launch_bounds__(256, 1) void gemm_nt_decode_kernel(GemmNT p, int grid0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (prefetch_block(p, grid0)) return;                           // (block-uniform, before any barrier)
   const int t = threadIdx.x, l = t & 63, hi = l >> 5;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   bf16* ring = (bf16*)smem_raw + w * SD_ST * SD_SLOT;              // this wave's private ring (32 KiB)
@@ -2292,14 +2321,14 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
       static uint32_t attr_sd = 0;
       const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
       ensure_smem_attr((const void*)gemm_nt_decode_kernel<EPI>, smem_sd, attr_sd);
-      hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sd, s, p);
+      hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI>, dim3(pl.grid + prefetch_blocks(p)), dim3(256), smem_sd, s, p, pl.grid);
       break;
     }
     case NT_SKINNY: {
       static uint32_t attr_sk = 0;
       const int smem_sk = SK_ST * SK_STAGE * 2;
       ensure_smem_attr((const void*)gemm_nt_skinny_kernel<EPI>, smem_sk, attr_sk);
-      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid), dim3(256), smem_sk, s, p);
+      hipLaunchKernelGGL(gemm_nt_skinny_kernel<EPI>, dim3(pl.grid + prefetch_blocks(p)), dim3(256), smem_sk, s, p, pl.grid);
       break;
     }
     case NT_PP: launch_pp<EPI>(p, pl.grid, s); break;
@@ -2309,10 +2338,10 @@ template <int EPI> static int launch_nt(const GemmNT& p, hipStream_t s) {
       static uint32_t attr_md = 0;
       const int smem_md = MD_ST * MD_STAGE * 2;
       ensure_smem_attr((const void*)gemm_nt_mid_kernel<EPI>, smem_md, attr_md);
-      hipLaunchKernelGGL(gemm_nt_mid_kernel<EPI>, dim3(pl.grid), dim3(256), smem_md, s, p);
+      hipLaunchKernelGGL(gemm_nt_mid_kernel<EPI>, dim3(pl.grid + prefetch_blocks(p)), dim3(256), smem_md, s, p, pl.grid);
       break;
     }
-    case NT_GLDS: hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(pl.grid), dim3(256), smem, s, p); break;
+    case NT_GLDS: hipLaunchKernelGGL(gemm_nt_glds_kernel<EPI>, dim3(pl.grid + prefetch_blocks(p)), dim3(256), smem, s, p, pl.grid); break;
     default: hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(pl.grid), dim3(256), smem, s, p); break;
   }
   return (int)hipGetLastError();
@@ -2343,7 +2372,7 @@ static int gemm_nt_qknr(const GemmNT& p, hipStream_t s) {
     static uint32_t attr_sd = 0;
     const int smem_sd = 4 * SD_ST * SD_SLOT * 2;
     ensure_smem_attr((const void*)gemm_nt_decode_kernel<EPI_QKNR>, smem_sd, attr_sd);
-    hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI_QKNR>, dim3(pl.grid), dim3(256), smem_sd, s, p);
+    hipLaunchKernelGGL(gemm_nt_decode_kernel<EPI_QKNR>, dim3(pl.grid + prefetch_blocks(p)), dim3(256), smem_sd, s, p, pl.grid);
     return (int)hipGetLastError();
   }
   GemmNT q = p; q.epi = EPI_BF16; q.C2 = nullptr;
