@@ -63,6 +63,26 @@ def test_gemm_nt_bf16_bias(M, N, K):
     check(f'gemm_nt f32 {M}x{N}x{K}', C32, ref, 1e-5 * 50)
 
 
+@pytest.mark.parametrize('M,N,K', [(64, 1024, 1024), (300, 1544, 512), (640, 5504, 1024), (4096, 512, 384), (37, 2816, 1408)])   # decode / skinny / mid / 128 x 128 kernels
+def test_gemm_nt_prefetch_of_the_next_weights_changes_nothing(M, N, K):
+    """round 6 (tfx_gemm_nt_args.prefetch): spare blocks of a small-M launch touch `prefetch_bytes` of another buffer (the next GEMM's weights).  They
+    must leave the launch's own tiles alone (its block -> tile map ignores them), write nothing, and stay inside the span - ragged byte counts, a span shorter
+    than one block's share, and a span that needs the 512-block cap."""
+    torch.manual_seed(0)
+    A, B = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    bias = torch.randn((N + 3) // 4 * 4, device=DEV)
+    kw = dict(A=A, lda=K, B=B, ldb=K, M=M, N=N, K=K, epi=capi.ENUMS['TFX_EPI_BF16'], ldc=N, bias=bias)
+    C0 = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+    gemm_nt(C=C0, **kw)
+    for nbytes in (100, 65536, 3 * 65536 + 4, 40 * 2 ** 20):
+        W = torch.full((nbytes // 2 + 64,), 1.0, device=DEV, dtype=BF)          # the guard elements behind the span are read back below
+        C1 = torch.full((M, N), float('nan'), device=DEV, dtype=BF)
+        gemm_nt(C=C1, prefetch=W, prefetch_bytes=nbytes, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(C0.view(torch.int16), C1.view(torch.int16)), (M, N, K, nbytes)
+        assert bool((W == 1.0).all())
+
+
 def test_gemm_nt_one_wave_kernels_bit_identical_to_ping_pong():
     """round 5: the one-wave-per-SIMD NT kernels (gemm_nt_ow_kernel: one tile per block; gemm_nt_owp_kernel: persistent, K-tile stream across tile boundaries;
     hand-scheduled inline-asm K loops from tools/gen_nt_ow_loop.py) keep the ping-pong kernel's LDS layout, per-accumulator k order and epilogues: the same bits.

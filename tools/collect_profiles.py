@@ -25,7 +25,8 @@ COPY_ = {
 }
 COPY = {k.replace('r05e', TAG): v.replace('r05_', PRE + '_', 1) for k, v in COPY_.items()}
 if TAG.startswith('r06'):
-    COPY.update({f'{TAG}_attn_probe.txt': f'{TAG}_attn_probe.txt', f'{TAG}_attn_kernel_times.txt': f'{TAG}_attn_kernel_times.txt', f'{TAG}_ab_dq.txt': f'{TAG}_ab_dq.txt'})
+    COPY.update({f'{TAG}_attn_probe.txt': f'{TAG}_attn_probe.txt', f'{TAG}_attn_kernel_times.txt': f'{TAG}_attn_kernel_times.txt', f'{TAG}_ab_dq.txt': f'{TAG}_ab_dq.txt',
+                 f'{TAG}_decode_kernels_cfg5.txt': f'{TAG}_decode_kernels_cfg5.txt', f'{TAG}_decode_prefetch.txt': f'{TAG}_decode_prefetch.txt'})
     COPY.pop(f'{TAG}_ab_qknr.txt', None)
 if TAG == 'r05f':
     COPY.update({'r05f_ab_ow.txt': 'r05f_ab_ow.txt', 'r05f_cfg_ab.txt': 'r05f_cfg_ab.txt', 'r05f_probe_cmp.txt': 'r05f_probe_cmp.txt', 'r05f_probe_pp.txt': 'r05f_probe_pp.txt',
