@@ -498,7 +498,7 @@ def parity_in_run(dev):
         num += e * gn; den += gn
     ref = float(g['loss'])
     out = {'case': 'canon512 golden (unmodified reference, fp32 CPU) x32 = b 64 x 1024, dim512/depth8, measured in this run',
-           'loss_native': float(loss), 'loss_reference': ref, 'loss_rel': abs(float(loss) - ref) / max(1., abs(ref)),
+           'loss_native': float(loss.detach()), 'loss_reference': ref, 'loss_rel': abs(float(loss.detach()) - ref) / max(1., abs(ref)),
            'text_loss_delta': abs(float(bd.text) - float(g['text_loss'])), 'flow_loss_delta': abs(float(bd.flow[0]) - float(g['flow_losses'][0])),
            'logits_rel': rel(lg, lr), 'logits_rel_worst_sample': max(rel(lg[i], lr[i]) for i in range(lg.shape[0])),
            'argmax_unfiltered': float(same.float().mean()), 'argmax_margin_gt_0p05': float(same[safe].float().mean()), 'margin_gt_0p05_share': float(safe.float().mean()),
