@@ -200,6 +200,16 @@ def test_schedules_and_null_text_cache_forms_agree(monkeypatch):
     monkeypatch.setenv('TFX_SAMPLE_SCHEDULE', 'continuous')
     cont = m.sample_many(prompts, **kw)
     cont_nocfg = m.sample_many(prompts, **{**kw, 'cfg_scale': 1.})
+    # round 6: decode plans built WITHOUT the weight prefetch by spare blocks (tfx_gemm_nt_args.prefetch; read when a plan is built) - the very same bits
+    monkeypatch.setenv('TFX_DECODE_PREFETCH', '0')
+    m.release_decode_cache()
+    cont_nopf = m.sample_many(prompts, **kw)
+    monkeypatch.delenv('TFX_DECODE_PREFETCH')
+    m.release_decode_cache()
+    for a, b in zip(cont, cont_nopf):
+        assert len(a) == len(b)
+        for pa, pb in zip(a, b):
+            assert (pa[0] == pb[0] and torch.equal(pa[1], pb[1])) if isinstance(pa, tuple) else torch.equal(pa, pb), 'weight prefetch changed a result'
     # the compacted form of the mixed steps (TFX_DECODE_COMPACT=1): each step carries only the rows its live samples need, two modality types with
     # blocks of 4 and 9 rows out of step with each other - same samples
     from transfusion_pytorch_amd import sampling
